@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference; the GPU box never runs it).
+The reference module ``openmeasure/sparse_sensing.py`` imports cvxpy at module top
+(:15) and cvxpy is not installed here.  The single cvxpy symbol executed on the SPR
+path is ``cp.multiply(a, b) + c`` followed by ``.value`` (:233-238), i.e. an
+element-wise multiply-then-add of float64 arrays.  This script registers an
+in-memory module named ``cvxpy`` that offers exactly that (``multiply`` returning an
+object with ``.value`` and ``+``), nothing else, then imports the reference file as
+it lies on disk.  No reference source is copied, no bytecode is written.
+Every X_rec fixture is additionally checked here against the plain NumPy expression
+``X_scl*x0 + X_cnt`` so the stand-in cannot leak into the expected values.
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, '..', 'tests', 'golden')
+
+
+class _ConstExpr:
+    def __init__(self, v):
+        self.value = v
+
+    def __add__(self, o):
+        return _ConstExpr(self.value + (o.value if isinstance(o, _ConstExpr) else o))
+
+    __radd__ = __add__
+
+
+def _import_reference():
+    cp = types.ModuleType('cvxpy')
+    cp.multiply = lambda a, b: _ConstExpr(np.multiply(a, b))
+    sys.modules['cvxpy'] = cp
+    sys.path.insert(0, '/root/reference/src')
+    import openmeasure.sparse_sensing as sps
+    return sps
+
+
+def synth(n_points, n_features, m, k, rho, eps, seed):
+    """Low-rank + noise snapshot matrix with a designed spectrum, then a per-feature
+    affine map so centring and scaling are non-trivial."""
+    rng = np.random.default_rng(seed)
+    n = n_points * n_features
+    L = rng.standard_normal((n, k))
+    R = (rho ** np.arange(k))[:, None] * rng.standard_normal((k, m))
+    X = L @ R + eps * rng.standard_normal((n, m))
+    for f in range(n_features):
+        X[f * n_points:(f + 1) * n_points] = (f + 1) * X[f * n_points:(f + 1) * n_points] + 10.0 * f
+    return np.ascontiguousarray(X)
+
+
+def run_case(sps, name, X, n_features, select_modes, n_modes, seed, mask_frac=None, store_X0=False):
+    n, m = X.shape
+    n_points = n // n_features
+    rng = np.random.default_rng(seed + 7)
+    xyz = rng.random((n_points, 3))
+    spr = sps.SPR(X.copy(), n_features, xyz)
+    spr.fit(select_modes=select_modes, n_modes=n_modes)
+    out = dict(X=X, n_features=np.int64(n_features), select_modes=np.array(select_modes),
+               n_modes=np.float64(n_modes), X_cnt=spr.X_cnt, X_scl=spr.X_scl,
+               Ur=np.array(spr.Ur), Ar=np.array(spr.Ar), Vr=spr.Vr, Sigma_r=spr.Sigma_r,
+               r=np.int64(spr.r))
+    if store_X0:
+        out['X0'] = spr.X0
+    # singular values / explained variance as the reference computes them (:272-275)
+    _, _, expv = spr.decomposition(spr.X0, select_modes, n_modes)
+    out['exp_variance'] = expv
+    out['S_full'] = np.linalg.svd(spr.X0, full_matrices=False)[1]   # same dgesdd job as :272
+
+    mask = None
+    if mask_frac is not None:
+        mask = rng.random(n) < mask_frac
+        out['mask'] = mask
+    C = spr.optimal_placement(mask=mask)          # zeroes Ur rows in place when masked (:738)
+    piv = np.argmax(C, axis=1).astype(np.int64)
+    assert C.sum() == spr.r and (C.sum(axis=1) == 1).all()
+    out['piv'] = piv
+    out['C_shape'] = np.array(C.shape, dtype=np.int64)
+    if mask is not None:                             # only differs from Ur when masked
+        out['Ur_after_placement'] = np.array(spr.Ur)
+    spr.train(C, cond=True)
+    out['Theta'] = spr.Theta
+    out['k'] = np.float64(spr.k)
+
+    # measurement vectors: held-out states = random combinations of snapshots + noise
+    s = spr.r
+    ys = []
+    for j in range(3):
+        w = rng.standard_normal(m) / np.sqrt(m)
+        xt = X @ w + X.mean(axis=1) * (1 - w.sum())
+        y = np.zeros((s, 3))
+        y[:, 0] = C @ xt
+        y[:, 2] = piv // n_points
+        if j == 1:                                   # weighted branch (:872-874)
+            y[:, 1] = 0.01 * (1 + rng.random(s)) * np.abs(y[:, 0]).mean()
+        ys.append(y)
+    out['ys'] = np.stack(ys)
+    y0 = spr.scale_vector(ys[1])
+    out['y0_1'] = y0
+    out['cnt_vector'] = spr.cnt_vector
+    out['scl_vector'] = spr.scl_vector
+    A1, S1 = spr.predict(ys[0])                      # single ndarray form (:844-845)
+    A3, S3 = spr.predict(ys)                         # list form
+    out['Ar_pred1'], out['Ar_sigma1'] = A1, S1
+    out['Ar_pred3'], out['Ar_sigma3'] = A3, S3
+    X1 = spr.reconstruct(A1[0])                      # 1-D coefficient vector (:362-363)
+    X3 = spr.reconstruct(A3)
+    chk = (spr.Ur @ A3.T) * spr.X_scl + spr.X_cnt    # stand-in independence check
+    assert np.array_equal(chk, X3), 'cvxpy stand-in changed the arithmetic'
+    out['X_rec1'], out['X_rec3'] = X1, X3
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: n={n} m={m} r={spr.r} piv[:6]={piv[:6]} cond={spr.k:.3g} '
+          f'-> {os.path.getsize(path)/1e6:.2f} MB')
+
+
+def main():
+    sps = _import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    # G1: the reference tests' own shape (tests/test_rom.py:9-12), seeded
+    X = np.random.default_rng(101).random((20, 5))
+    run_case(sps, 'g1_full', X, 2, 'variance', 100, 101, store_X0=True)
+    run_case(sps, 'g1_num4', X, 2, 'number', 4, 102, store_X0=True)
+    # G2: 500 cells x 3 features x 12 snapshots, r in {4, 12}, default 99 % variance
+    X = synth(500, 3, 12, 12, 0.7, 1e-3, 202)
+    run_case(sps, 'g2_num4', X, 3, 'number', 4, 203, store_X0=True)
+    run_case(sps, 'g2_full', X, 3, 'variance', 100, 204)
+    run_case(sps, 'g2_var99', X, 3, 'variance', 99, 205)
+    run_case(sps, 'g2_num4_mask', X, 3, 'number', 4, 206, mask_frac=0.5)
+    # G3: 2000 x 4 x 24 with a designed spectrum (sigma_1/sigma_16 ~ 1e3), r = s = 8, 16
+    X = synth(2000, 4, 24, 24, 10 ** (-3 / 15), 1e-4, 303)
+    run_case(sps, 'g3_num8', X, 4, 'number', 8, 304)
+    run_case(sps, 'g3_num16', X, 4, 'number', 16, 305)
+    # odd m / odd r / ragged: 333 cells x 3 x 7 snapshots, r = 5
+    X = synth(333, 3, 7, 7, 0.6, 1e-3, 404)
+    run_case(sps, 'g4_num5', X, 3, 'number', 5, 405)
+
+
+if __name__ == '__main__':
+    main()

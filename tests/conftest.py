@@ -1,0 +1,35 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+GOLDEN = sorted(os.path.splitext(os.path.basename(p))[0]
+                for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    g = {k: z[k] for k in z.files}
+    g['n_features'] = int(g['n_features'])
+    g['r'] = int(g['r'])
+    g['select_modes'] = str(g['select_modes'])
+    nm = float(g['n_modes'])
+    g['n_modes'] = int(nm) if g['select_modes'] == 'number' else nm
+    g['name'] = name
+    return g
+
+
+@pytest.fixture(params=GOLDEN)
+def golden(request):
+    return load_golden(request.param)

@@ -1,0 +1,164 @@
+/*
+ * spr_hip.h -- C ABI of libspr_hip.so: the MI355X (gfx950) kernels under
+ * openmeasure_amd.sparse_sensing.SPR.
+ *
+ * The reference (burn-research/OpenMEASURE, src/openmeasure/sparse_sensing.py) has no
+ * FFI; its "operator interface" for this path is the set of NumPy/SciPy calls listed in
+ * SURVEY.md section 2 (K1..K11).  Each entry point below replaces one of those call
+ * sites and says which (file:line of sparse_sensing.py).  The Python class in
+ * openmeasure_amd/sparse_sensing.py binds them with ctypes; INTEGRATION.md shows the
+ * same binding as a maintainer of the reference would add it.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM) owned by the caller; the
+ *     library allocates nothing and keeps no state between calls;
+ *   - matrices are row-major float64; "ld*" is the row stride in elements;
+ *   - rows of the snapshot matrix are feature-major (global row = f*n_points + cell,
+ *     sparse_sensing.py:110); a rank holds the contiguous global rows
+ *     [row0, row0+n_rows) and passes the GLOBAL n_points so kernels can tell the
+ *     feature of every local row;
+ *   - stream is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises the host;
+ *   - return value: 0 = ok, <0 = error (SPR_E_*); spr_last_error() gives the text for
+ *     the calling thread.  No C++ exception crosses this boundary.
+ */
+#ifndef SPR_HIP_H
+#define SPR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPR_OK 0
+#define SPR_E_INVALID (-1)   /* bad argument (shape, alignment, NULL)            */
+#define SPR_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for   */
+#define SPR_E_HIP (-3)       /* a HIP runtime call failed                        */
+#define SPR_E_WORKSPACE (-4) /* workspace too small                              */
+
+#define SPR_MAX_M 256        /* snapshots (columns of X) supported by the Gram kernel */
+#define SPR_MAX_R 128        /* retained modes / sensors                              */
+
+int spr_abi_version(void);
+const char *spr_last_error(void);
+/* number of compute units of the current device (used to size persistent grids) */
+int spr_device_cus(int *out_cus);
+
+/* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
+ * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised
+ * X0 = (X - X_cnt)/X_scl (:169) and the X0^T X0 half of np.linalg.svd (:272).
+ * One read of X.  For every local row i: d_rowmean[i] = mean_j X[i,j].  For every
+ * feature f (0..n_features-1), over the LOCAL rows of f:
+ *   d_fstats[3f..3f+2] = (count, mean, M2) of the row means (Welford/Chan form),
+ *   d_gram[f*m*m ..]   = sum_i (x_i - mean_i)(x_i - mean_i)^T            (m x m, full).
+ * The caller combines: var_f = (trace(G_f) + m*M2_f) / (count_f*m) -> X_scl; G = sum_f G_f/var_f.
+ * Across ranks d_gram is summed (all-reduce) and d_fstats Chan-merged.
+ * center = 1: as above.  center = 0: rows are taken as they are (d_rowmean is written as
+ * zeros) -- the plain X^T X needed by ROM.decomposition(X0) on a caller-supplied X0 (:272).
+ * Workspace: spr_stats_gram_workspace() bytes, 16-byte aligned.  m <= SPR_MAX_M. */
+size_t spr_stats_gram_workspace(int32_t m, int32_t n_features);
+int spr_stats_gram_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx,
+                       int64_t row0, int64_t n_points, int32_t n_features, int32_t center,
+                       double *d_rowmean, double *d_fstats, double *d_gram,
+                       void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- K4 : basis projection  Ur = X0 . W,  W = V_r Sigma_r^-1 (m x r) ----------------
+ * Replaces the U factor of np.linalg.svd (:272) and the truncation U[:, :r] (:336).
+ * Second read of X; centring is recomputed from the row itself and the per-feature
+ * 1/X_scl (d_inv_scale[n_features]) is applied in the epilogue, so X0 never exists. */
+int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx,
+                    int64_t row0, int64_t n_points, int32_t n_features, int32_t center,
+                    const double *d_inv_scale, const double *d_W, int32_t r,
+                    double *d_Ur, int64_t ldu, void *stream);
+
+/* ---- K2 / K11 as stand-alone calls (ROM.scale_data's return value, ROM.unscale_data) --
+ * spr_scale_rows:  X0 = (X - rowmean) * inv_scale[feature]   (:169), n_rows x m.
+ * spr_unscale:     x  = scale[feature] * x0 + rowmean        (:235), n_rows. */
+int spr_scale_rows_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                       int64_t n_points, int32_t n_features, const double *d_rowmean,
+                       const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream);
+int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0, int64_t n_points,
+                    int32_t n_features, const double *d_rowmean, const double *d_scale,
+                    double *d_x, void *stream);
+
+/* ---- K10 + K11 : reconstruction  x = X_scl * (Ur a) + X_cnt -------------------------
+ * Replaces Ur @ Ar.T (:371) and unscale_data (:235, :372-373) in one streaming pass.
+ * d_A is n_p x r row-major (the Ar argument); output d_Xrec is COLUMN-major
+ * (n_p columns of ldo >= n_rows doubles each). d_scale[n_features] = X_scl per feature. */
+int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                        int64_t row0, int64_t n_points, int32_t n_features,
+                        const double *d_rowmean, const double *d_scale,
+                        const double *d_A, int32_t n_p, double *d_Xrec, int64_t ldo,
+                        void *stream);
+
+/* ---- K6 : QR column pivoting of Ur^T (sensor selection) -----------------------------
+ * Replaces scipy.linalg.qr(Ur.T, pivoting=True) (:739) -- only the first s pivots are
+ * used by the reference (:740-743).  Greedy max-residual-norm selection with norm
+ * down-dating, identical in exact arithmetic to dgeqp3's choice; ties go to the lowest
+ * global row index (LAPACK idamax).
+ *
+ * spr_mask_rows      Ur[~mask,:] = 0 in place (:737-738); d_mask is n_rows bytes.
+ * spr_qr_init        d_nrm[i] = |Ur[i,:]|^2 and this rank's best candidate
+ *                    d_cand[0..r+1] = (value, global row as double, that row of Ur).
+ * spr_qr_step        given n_cand candidates (one per rank, d_cands[n_cand][r+2]) picks
+ *                    the winner, writes d_piv[step] (int64 global row) and the new
+ *                    orthonormal direction d_Q[step][r], then down-dates d_nrm with it
+ *                    and leaves this rank's next candidate in d_cand.
+ * Single GPU: d_cands == d_cand, n_cand = 1.  Multi GPU: all-gather d_cand between steps.
+ * d_gap (optional, may be NULL): d_gap[step] = relative gap between the local best and
+ * second-best residual at selection time (diagnostic for pivot uniqueness).
+ * Workspace: spr_qr_workspace(n_rows) bytes. */
+#define SPR_QR_CAND_LEN(r) ((r) + 3)
+size_t spr_qr_workspace(int64_t n_rows);
+int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                      const uint8_t *d_mask, void *stream);
+int spr_qr_init_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                    int64_t row0, double *d_nrm, double *d_cand,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_step_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                    int64_t row0, int32_t step, const double *d_cands, int32_t n_cand,
+                    double *d_Q, int64_t *d_piv, double *d_nrm, double *d_cand,
+                    double *d_gap, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- K7 + K8 : Theta = C . Ur and cnt = C . X_cnt for a CSR measurement matrix ------
+ * Replaces C.dot(self.Ur) (:797) and self.C.dot(self.X_cnt[:,0]) (:573).  The one-hot C
+ * of optimal_placement is the 1-nnz-per-row case (a row gather).  Column indices are
+ * GLOBAL rows; entries outside [row0,row0+n_rows) are skipped, so per-rank results are
+ * partial sums to be all-reduced.  d_Theta is s x r row-major, d_cnt has s entries. */
+int spr_measure_csr_f64(const int64_t *d_indptr, const int64_t *d_indices,
+                        const double *d_vals, int32_t s, const double *d_Ur,
+                        int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                        const double *d_rowmean, double *d_Theta, double *d_cnt,
+                        void *stream);
+
+/* ---- K8 + K9 : scale_vector + (weighted) least squares ------------------------------
+ * Replaces scale_vector (:571-582) and the OLS branch of predict (:868-878) for n_p
+ * measurement vectors at once.  d_y is n_p x s x 3 (value, std-dev, feature id).
+ * Per vector: y0 = ((y-cnt)/scl, sigma/scl); W = I if every sigma is 0 else diag(1/y0_sigma);
+ * normal equations (W Theta)^T (W Theta) a = (W Theta)^T W y0 by f64 MFMA + Cholesky.
+ * Outputs: d_Ar, d_Ar_sigma (n_p x r), d_y0 (n_p x s x 2, may be NULL),
+ * d_info (n_p x 2: [0] = 0 ok / 1 Cholesky breakdown, [1] = (max L_jj / min L_jj)^2). */
+int spr_solve_ols_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt,
+                      const double *d_scale, int32_t n_features, const double *d_y,
+                      int32_t n_p, double *d_Ar, double *d_Ar_sigma, double *d_y0,
+                      double *d_info, void *stream);
+
+/* ---- synthetic snapshot matrices (benchmark input) -------------------
+ * X[i,j] = (f+1) * ( sum_k L[i,k] R[k,j] + eps * N[i,j] ) + 10 f, with L, N standard
+ * normal from a counter-based generator keyed by (seed, GLOBAL row, column), so any row
+ * range is reproducible on any rank count.  d_R is k x ldr (ldr >= col0+ncols).
+ * Columns [col0, col0+ncols) of the virtual matrix are written to d_X (n_rows x ldx). */
+int spr_synth_f64(double *d_X, int64_t n_rows, int32_t ncols, int64_t ldx, int64_t row0,
+                  int64_t n_points, int32_t col0, const double *d_R, int32_t k, int32_t ldr,
+                  double eps, uint64_t seed, void *stream);
+/* the same generator evaluated at arbitrary global rows for one column (held-out state) */
+int spr_synth_gather_f64(const int64_t *d_rows, int32_t n, int64_t n_points, int32_t col,
+                         const double *d_R, int32_t k, int32_t ldr, double eps,
+                         uint64_t seed, double *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPR_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libspr_hip.so (include/spr_hip.h).
+
+The library is the product: there is no Python/NumPy fallback behind it.  ``load()``
+raises ``RuntimeError`` when the shared object is missing or cannot be loaded, and
+every call goes through ``check()`` which turns a negative status into a Python
+exception carrying ``spr_last_error()``.
+
+``import torch`` happens before the ``CDLL`` so that the HIP runtime already mapped
+by PyTorch (SONAME libamdhip64.so.7) is the one the kernels' launch stubs bind to --
+device pointers and streams handed over from torch tensors are only meaningful
+inside that runtime instance.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libspr_hip.so')
+
+SPR_MAX_M = 256
+SPR_MAX_R = 128
+
+_i32, _i64, _u64, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+_p = C.c_void_p
+_dbl = C.c_double
+
+# name -> (restype, argtypes); mirrors include/spr_hip.h one to one
+PROTOTYPES = {
+    'spr_abi_version': (C.c_int, []),
+    'spr_last_error': (C.c_char_p, []),
+    'spr_device_cus': (C.c_int, [C.POINTER(C.c_int)]),
+    'spr_stats_gram_workspace': (_sz, [_i32, _i32]),
+    'spr_stats_gram_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _i32, _p, _i64, _p]),
+    'spr_scale_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
+    'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
+    'spr_reconstruct_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
+    'spr_qr_workspace': (_sz, [_i64]),
+    'spr_mask_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
+    'spr_qr_init_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _p, _sz, _p]),
+    'spr_qr_step_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'spr_measure_csr_f64': (C.c_int, [_p, _p, _p, _i32, _p, _i64, _i32, _i64, _i64, _p, _p, _p, _p]),
+    'spr_solve_ols_f64': (C.c_int, [_p, _i32, _i32, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
+    'spr_synth_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p]),
+    'spr_synth_gather_f64': (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p, _p]),
+}
+
+_lib = None
+
+
+class SprError(RuntimeError):
+    """A libspr_hip.so call returned a negative status."""
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly if it cannot be done."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `make -C openmeasure_amd/csrc` '
+            '(or __graft_entry__.build()). There is no CPU fallback for the SPR kernels.')
+    import torch  # noqa: F401  -- maps PyTorch's HIP runtime first (see module docstring)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc == 0:
+        return
+    msg = load().spr_last_error().decode('utf-8', 'replace')
+    kinds = {-1: ValueError, -2: NotImplementedError, -3: SprError, -4: MemoryError}
+    raise kinds.get(rc, SprError)(f'{what or "libspr_hip"} failed (status {rc}): {msg}')

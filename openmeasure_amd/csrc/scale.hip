@@ -1,0 +1,69 @@
+// K2 / K11 as stand-alone calls: the explicit scaled matrix X0 = (X - X_cnt)/X_scl that
+// ROM.scale_data returns (sparse_sensing.py:169) and ROM.unscale_data (:235).  The fitted
+// path never materialises X0 (the Gram and projection kernels fold the scaling into their
+// loads); these exist so the two public methods keep working.  Plain grid-stride
+// element-wise kernels, 16-byte accesses when the layout allows.
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(
+    const double *__restrict__ X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
+    int n_features, const double *__restrict__ rowmean, const double *__restrict__ inv_scale,
+    double *__restrict__ X0, int64_t ldo) {
+  // one wave per row at a time: the feature lookup is a wave-uniform division
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave_id; row < n_rows; row += n_waves) {
+    int64_t f = (row0 + row) / n_points;
+    if (f > n_features - 1) f = n_features - 1;
+    const double mu = rowmean[row], is = inv_scale[f];
+    for (int c = lane; c < m; c += 64) X0[row * ldo + c] = (X[row * ldx + c] - mu) * is;
+  }
+}
+
+__global__ __launch_bounds__(256) void unscale_kernel(
+    const double *__restrict__ x0, int64_t n_rows, int64_t row0, int64_t n_points, int n_features,
+    const double *__restrict__ rowmean, const double *__restrict__ scale, double *__restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t f = (row0 + i) / n_points;
+    if (f > n_features - 1) f = n_features - 1;
+    x[i] = scale[f] * x0[i] + rowmean[i];
+  }
+}
+
+int grid_for(int64_t work_items, int per_block) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  const int cus = spr_cached_cus();
+  const int64_t cap = 16LL * (cus > 0 ? cus : 256);
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int spr_scale_rows_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, const double *d_rowmean,
+                                  const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_inv_scale && d_X0, SPR_E_INVALID, "spr_scale_rows_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && ldo >= m && row0 >= 0 && n_points > 0 && n_features > 0,
+              SPR_E_INVALID, "spr_scale_rows_f64: bad shape");
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(n_rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     d_X, n_rows, (int)m, ldx, row0, n_points, (int)n_features, d_rowmean, d_inv_scale, d_X0, ldo);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+extern "C" int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0, int64_t n_points,
+                               int32_t n_features, const double *d_rowmean, const double *d_scale, double *d_x,
+                               void *stream) {
+  SPR_REQUIRE(d_x0 && d_rowmean && d_scale && d_x, SPR_E_INVALID, "spr_unscale_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && row0 >= 0 && n_points > 0 && n_features > 0, SPR_E_INVALID,
+              "spr_unscale_f64: bad shape");
+  hipLaunchKernelGGL(unscale_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     d_x0, n_rows, row0, n_points, (int)n_features, d_rowmean, d_scale, d_x);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}

@@ -1,0 +1,294 @@
+// K1 + K3a: fused row mean / per-feature statistics / per-feature Gram matrix.
+//
+// One pass over the row shard.  Persistent 512-thread workgroups are dealt to the feature
+// segments of the shard; each keeps the upper-triangular 16x16 tiles of the m x m Gram
+// matrix of its feature in MFMA accumulators (v_mfma_f64_16x16x4_f64) for its whole
+// life, consuming R-row panels that are centred on the way into LDS (rowtile.hpp).
+// At the end every wave stores its tiles to a slab; a second tiny kernel sums the slabs
+// in a fixed order (bitwise reproducible, no float atomics), mirrors the lower triangle
+// and Chan-merges the row-mean statistics.
+//
+// MFMA operand pattern.  G[i][j] += sum_k P[k][i] P[k][j] over panel rows k.  For
+// v_mfma_f64_16x16x4_f64 lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15],
+// so both operands of tile (ti,tj) are "16 consecutive doubles of panel row k0+(l>>4)":
+// conflict-free ds_read_b64 when consecutive rows sit 32 banks apart (MP == 16 mod 32).
+// The result lane map is col = l&15, row = (l>>4) + 4*reg.
+#include "rowtile.hpp"
+
+namespace {
+
+constexpr int NW = 8;  // waves per workgroup
+
+template <int MT>
+struct GramShape {
+  static constexpr int MPAD = 16 * MT;
+  static constexpr int MP = MPAD + ((MT % 2 == 0) ? 16 : 0);
+  static constexpr int T = MT * (MT + 1) / 2;
+};
+
+// tile-group x k-slice split of the 8 waves and the panel height, per padded width
+template <int MT> struct GramCfg;
+template <> struct GramCfg<1>  { static constexpr int R = 64, TG = 1, KS = 8; };
+template <> struct GramCfg<2>  { static constexpr int R = 64, TG = 1, KS = 8; };
+template <> struct GramCfg<3>  { static constexpr int R = 64, TG = 1, KS = 8; };
+template <> struct GramCfg<4>  { static constexpr int R = 64, TG = 2, KS = 4; };
+template <> struct GramCfg<6>  { static constexpr int R = 32, TG = 4, KS = 2; };
+template <> struct GramCfg<8>  { static constexpr int R = 32, TG = 4, KS = 2; };
+template <> struct GramCfg<12> { static constexpr int R = 32, TG = 8, KS = 1; };
+template <> struct GramCfg<16> { static constexpr int R = 32, TG = 8, KS = 1; };
+
+// linear index over the upper triangle (row-major) -> tile row / column
+template <int MT>
+__device__ inline void tile_coords(int idx, int &ti, int &tj) {
+  ti = 0;
+  while (ti < MT - 1 && idx >= MT - ti) { idx -= MT - ti; ++ti; }
+  tj = ti + idx;
+  if (tj > MT - 1) tj = MT - 1;  // surplus slots of the last wave: harmless duplicate
+}
+
+template <int MT>
+__global__ __launch_bounds__(NW * 64) void stats_gram_kernel(
+    const double *__restrict__ X, int64_t ldx, int m, int vec_ok_i, int center_i, SegPlan plan,
+    double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab) {
+  using S = GramShape<MT>;
+  using C = GramCfg<MT>;
+  constexpr int R = C::R, TG = C::TG, KS = C::KS, MP = S::MP, T = S::T;
+  constexpr int TPW = (T + TG - 1) / TG;
+  constexpr int KROWS = R / KS;
+  static_assert(TG * KS == NW, "waves = tile groups x k slices");
+  static_assert(KROWS % 4 == 0, "k slice must be a multiple of the MFMA depth");
+  using RT = RowTile<MT, R, MP, NW>;
+
+  __shared__ double lds[2][R * MP];
+
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tg = wave % TG, ks = wave / TG;
+  const bool vec_ok = vec_ok_i != 0;
+
+  // tiles of this wave: linear upper-triangle index -> (ti, tj)
+  int offA[TPW], offB[TPW];
+  int nt = T - tg * TPW;
+  if (nt > TPW) nt = TPW;
+  if (nt < 0) nt = 0;
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    int ti, tj;
+    tile_coords<MT>(tg * TPW + u, ti, tj);
+    offA[u] = ti * 16;
+    offB[u] = tj * 16;
+  }
+
+  f64x4 acc[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) acc[u] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  RowStats st;
+  st.init();
+  RT tile;
+
+  const int64_t nchunks = (hi - lo + R - 1) / R;
+  int64_t c = wl;
+  if (c < nchunks) tile.load(X, ldx, m, vec_ok, lo + c * R, hi, wave, lane);
+  int buf = 0;
+  const int frag = (lane >> 4) * MP + (lane & 15);
+  while (c < nchunks) {
+    tile.template center_store<true>(lds[buf], m, center_i != 0, lo + c * R, hi, wave, lane, rowmean, &st);
+    const int64_t cn = c + wpf;
+    if (cn < nchunks) tile.load(X, ldx, m, vec_ok, lo + cn * R, hi, wave, lane);
+    __syncthreads();
+    const double *p = lds[buf] + frag + ks * KROWS * MP;
+#pragma unroll 1
+    for (int k0 = 0; k0 < KROWS; k0 += 4) {
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        if (u < nt) {
+          const double a = p[k0 * MP + offA[u]];
+          const double b = p[k0 * MP + offB[u]];
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+        }
+      }
+    }
+    buf ^= 1;
+    c = cn;
+  }
+
+  // tiles -> slab[(block*KS + ks)][tile][reg][lane]
+  {
+    double *sp = slab + ((int64_t)blockIdx.x * KS + ks) * T * 256;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      if (u < nt) {
+        double *tp = sp + (int64_t)(tg * TPW + u) * 256 + lane;
+        tp[0] = acc[u].x; tp[64] = acc[u].y; tp[128] = acc[u].z; tp[192] = acc[u].w;
+      }
+    }
+  }
+  // Welford partials: one slot per lane group
+  if ((lane % RT::LPR) == 0) {
+    double *q = stat_part + ((int64_t)blockIdx.x * RT::ROWS_PER_IT + wave * RT::RPW + lane / RT::LPR) * 3;
+    q[0] = st.cnt; q[1] = st.mean; q[2] = st.m2;
+  }
+}
+
+// grid (T, n_features), 256 threads: fixed-order sum of the slabs of feature f for one tile
+template <int MT>
+__global__ __launch_bounds__(256) void gram_finalize_kernel(
+    const double *__restrict__ slab, const double *__restrict__ stat_part, int m, SegPlan plan,
+    int slots_per_wg, double *__restrict__ gram, double *__restrict__ fstats) {
+  constexpr int T = GramShape<MT>::T;
+  constexpr int KS = GramCfg<MT>::KS;
+  const int f = blockIdx.y;
+  const int tile = blockIdx.x;
+  // blocks of feature f
+  int base = 0, wpf = 0;
+  {
+    int acc = 0;
+    const int f0 = seg_first_feature(plan), f1 = seg_last_feature(plan);
+    for (int ff = f0; ff <= f1; ++ff) {
+      int64_t lo, hi;
+      seg_range(plan, ff, lo, hi);
+      const int w = seg_wgs(plan, hi - lo);
+      if (ff == f) { base = acc; wpf = w; }
+      acc += w;
+    }
+  }
+  int ti, tj;
+  tile_coords<MT>(tile, ti, tj);
+  const int e = threadIdx.x;
+  double sum = 0.0;
+  const double *sp = slab + ((int64_t)base * KS * T + tile) * 256 + e;
+  for (int p = 0; p < wpf * KS; ++p) sum += sp[(int64_t)p * T * 256];
+  const int l = e & 63, reg = e >> 6;
+  const int gi = ti * 16 + (l >> 4) + 4 * reg, gj = tj * 16 + (l & 15);
+  if (gi < m && gj < m) {
+    double *G = gram + (int64_t)f * m * m;
+    G[(int64_t)gi * m + gj] = sum;
+    if (ti != tj) G[(int64_t)gj * m + gi] = sum;
+  }
+  if (tile == 0 && e == 0) {
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    const double *q = stat_part + (int64_t)base * slots_per_wg * 3;
+    for (int p = 0; p < wpf * slots_per_wg; ++p) {
+      const double nb = q[3 * p], mb = q[3 * p + 1], sb = q[3 * p + 2];
+      if (nb > 0.0) {
+        const double tot = n + nb, d = mb - mu;
+        mu += d * nb / tot;
+        m2 += sb + d * d * n * nb / tot;
+        n = tot;
+      }
+    }
+    fstats[3 * f] = n; fstats[3 * f + 1] = mu; fstats[3 * f + 2] = m2;
+  }
+}
+
+template <int MT>
+int occupancy_wgs() {
+  static int cached = 0;
+  if (cached) return cached;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT>, NW * 64, 0) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  const int cus = spr_cached_cus();
+  cached = per_cu * (cus > 0 ? cus : 256);
+  return cached;
+}
+
+template <int MT>
+SegPlan make_plan(int64_t n_rows, int64_t row0, int64_t n_points, int32_t n_features) {
+  SegPlan p;
+  p.row0 = row0; p.n_rows = n_rows; p.n_points = n_points; p.n_features = n_features;
+  p.total_wg = occupancy_wgs<MT>();
+  p.chunk_rows = GramCfg<MT>::R;
+  return p;
+}
+
+template <int MT>
+size_t workspace_bytes(int32_t n_features) {
+  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, NW>;
+  const int64_t max_grid = (int64_t)occupancy_wgs<MT>() + n_features;
+  return (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256 * sizeof(double) +
+         (size_t)max_grid * RT::ROWS_PER_IT * 3 * sizeof(double);
+}
+
+template <int MT>
+int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
+           int32_t n_features, int center, double *rowmean, double *fstats, double *gram, void *ws, size_t ws_bytes,
+           hipStream_t st) {
+  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, NW>;
+  SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
+              "spr_stats_gram_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
+  SegPlan plan = make_plan<MT>(n_rows, row0, n_points, n_features);
+  const int grid = seg_total_wgs(plan);
+  const int64_t max_grid = (int64_t)occupancy_wgs<MT>() + n_features;
+  SPR_REQUIRE(grid >= 1 && grid <= max_grid, SPR_E_INVALID, "spr_stats_gram_f64: bad grid %d", grid);
+  double *slab = static_cast<double *>(ws);
+  double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  hipLaunchKernelGGL(stats_gram_kernel<MT>, dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, vec_ok, center, plan,
+                     rowmean, stat_part, slab);
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_finalize_kernel<MT>, dim3(GramShape<MT>::T, n_features), dim3(256), 0, st, slab,
+                     stat_part, (int)m, plan, (int)RT::ROWS_PER_IT, gram, fstats);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+int check_args(const char *who, const void *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+               int64_t n_points, int32_t n_features) {
+  SPR_REQUIRE(X != nullptr, SPR_E_INVALID, "%s: X is NULL", who);
+  SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "%s: bad shape n_rows=%lld m=%d ldx=%lld", who,
+              (long long)n_rows, m, (long long)ldx);
+  SPR_REQUIRE(n_points > 0 && n_features > 0 && row0 >= 0, SPR_E_INVALID, "%s: bad feature layout", who);
+  SPR_REQUIRE(row0 + n_rows <= n_points * (int64_t)n_features, SPR_E_INVALID,
+              "%s: rows [%lld,%lld) exceed n_points*n_features=%lld", who, (long long)row0,
+              (long long)(row0 + n_rows), (long long)(n_points * (int64_t)n_features));
+  SPR_REQUIRE(m <= SPR_MAX_M, SPR_E_UNSUPPORTED, "%s: m=%d > %d not built", who, m, SPR_MAX_M);
+  return SPR_OK;
+}
+
+}  // namespace
+
+#define SPR_DISPATCH_MT(mt, CALL)            \
+  switch (mt) {                              \
+    case 1: CALL(1); break;                  \
+    case 2: CALL(2); break;                  \
+    case 3: CALL(3); break;                  \
+    case 4: CALL(4); break;                  \
+    case 6: CALL(6); break;                  \
+    case 8: CALL(8); break;                  \
+    case 12: CALL(12); break;                \
+    case 16: CALL(16); break;                \
+    default: break;                          \
+  }
+
+extern "C" size_t spr_stats_gram_workspace(int32_t m, int32_t n_features) {
+  if (m <= 0 || m > SPR_MAX_M || n_features <= 0) return 0;
+  size_t out = 0;
+#define WS_CALL(MTV) out = workspace_bytes<MTV>(n_features)
+  SPR_DISPATCH_MT(spr_round_mt(m), WS_CALL)
+#undef WS_CALL
+  return out;
+}
+
+extern "C" int spr_stats_gram_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
+                                  double *d_fstats, double *d_gram, void *d_workspace, size_t workspace_bytes_, void *stream) {
+  int rc = check_args("spr_stats_gram_f64", d_X, n_rows, m, ldx, row0, n_points, n_features);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_rowmean && d_fstats && d_gram && d_workspace, SPR_E_INVALID,
+              "spr_stats_gram_f64: NULL output/workspace");
+  rc = SPR_E_UNSUPPORTED;
+#define RUN_CALL(MTV)                                                                                   \
+  rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_fstats, d_gram,       \
+                   d_workspace, workspace_bytes_, static_cast<hipStream_t>(stream))
+  SPR_DISPATCH_MT(spr_round_mt(m), RUN_CALL)
+#undef RUN_CALL
+  return rc;
+}

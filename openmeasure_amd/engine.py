@@ -1,0 +1,194 @@
+"""HipEngine: the device half of the SPR path -- torch tensors in, libspr_hip.so calls out.
+
+PyTorch is plumbing here: it owns the HBM allocations (``torch.empty(..., device='cuda')``),
+the current HIP stream and, through ``torch.distributed``, the RCCL communicator.  All
+arithmetic on the snapshot matrix and the basis happens in the hand-written gfx950 kernels
+reached through the C ABI (``include/spr_hip.h``).  Every method enqueues on the current
+stream and returns device tensors; nothing here synchronises the host.
+
+The ROM/SPR classes talk to an *engine* object with exactly this method set.  The product
+has one engine (this one).  ``tests/numpy_engine.py`` holds a NumPy stand-in with the same
+interface that exists only so the sharding/collective logic can be exercised with the gloo
+backend on machines without a GPU; nothing in this package imports it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class HipEngine:
+    name = 'hip-gfx950'
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('openmeasure_amd needs an AMD GPU visible to PyTorch-ROCm; '
+                               'there is no CPU fallback for the SPR kernels.')
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self._ws = {}
+
+    # ---- plumbing ---------------------------------------------------------------------
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        return self.torch.zeros(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def to_device(self, a, dtype=None):
+        """Host ndarray -> contiguous device tensor (float64 unless told otherwise)."""
+        t = self.torch.as_tensor(np.ascontiguousarray(a))
+        if dtype is None:
+            dtype = self.torch.float64
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    def _workspace(self, key, nbytes):
+        cur = self._ws.get(key)
+        if cur is None or cur.numel() < nbytes:
+            cur = self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+            self._ws[key] = cur
+        return cur
+
+    def _check_matrix(self, X):
+        t = self.torch
+        if not (isinstance(X, t.Tensor) and X.is_cuda and X.dtype == t.float64 and X.dim() == 2
+                and X.stride(1) == 1):
+            raise TypeError('device snapshot matrix must be a 2-D float64 CUDA tensor with unit column stride')
+        return X.shape[0], X.shape[1], X.stride(0)
+
+    # ---- K1 + K3a ------------------------------------------------------------------------
+    def stats_gram(self, X, row0, n_points, n_features, center=True):
+        """-> rowmean (n,), fstats (F,3) = (count, mean, M2) of the local row means,
+        gram (F,m,m) = per-feature sum of centred outer products over the local rows."""
+        n, m, ld = self._check_matrix(X)
+        rowmean = self.empty((n,))
+        fstats = self.empty((n_features, 3))
+        gram = self.empty((n_features, m, m))
+        nbytes = self.lib.spr_stats_gram_workspace(m, n_features)
+        if nbytes == 0:
+            raise NotImplementedError(f'stats_gram: m={m} outside the built range (1..{_lib.SPR_MAX_M})')
+        ws = self._workspace('gram', nbytes)
+        _lib.check(self.lib.spr_stats_gram_f64(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
+                                               _ptr(rowmean), _ptr(fstats), _ptr(gram), _ptr(ws), ws.numel(),
+                                               self._stream()), 'spr_stats_gram_f64')
+        return rowmean, fstats, gram
+
+    # ---- K4 --------------------------------------------------------------------------------
+    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True):
+        """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even."""
+        n, m, ld = self._check_matrix(X)
+        r = W.shape[1]
+        ldu = r + (r & 1)
+        buf = self.empty((n, ldu))
+        _lib.check(self.lib.spr_project_f64(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
+                                            _ptr(inv_scale), _ptr(W.contiguous()), r, _ptr(buf), ldu,
+                                            self._stream()), 'spr_project_f64')
+        return buf[:, :r]
+
+    # ---- K2 / K11 stand-alone ---------------------------------------------------------------
+    def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
+        n, m, ld = self._check_matrix(X)
+        out = self.empty((n, m))
+        _lib.check(self.lib.spr_scale_rows_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(rowmean),
+                                               _ptr(inv_scale), _ptr(out), m, self._stream()),
+                   'spr_scale_rows_f64')
+        return out
+
+    def unscale(self, x0, row0, n_points, n_features, rowmean, scale):
+        n = x0.shape[0]
+        out = self.empty((n,))
+        _lib.check(self.lib.spr_unscale_f64(_ptr(x0.contiguous()), n, row0, n_points, n_features, _ptr(rowmean),
+                                            _ptr(scale), _ptr(out), self._stream()), 'spr_unscale_f64')
+        return out
+
+    # ---- K10 + K11 ---------------------------------------------------------------------------
+    def reconstruct(self, Ur, row0, n_points, n_features, rowmean, scale, A, out=None):
+        """x = X_scl (Ur a) + X_cnt for the n_p rows of A. -> (n_p, n) tensor (column-major (n, n_p))."""
+        n, r, ldu = self._check_matrix(Ur)
+        n_p = A.shape[0]
+        if out is None:
+            out = self.empty((n_p, n))
+        _lib.check(self.lib.spr_reconstruct_f64(_ptr(Ur), n, r, ldu, row0, n_points, n_features, _ptr(rowmean),
+                                                _ptr(scale), _ptr(A.contiguous()), n_p, _ptr(out), out.stride(0),
+                                                self._stream()), 'spr_reconstruct_f64')
+        return out
+
+    # ---- K6 ----------------------------------------------------------------------------------
+    def mask_rows(self, Ur, mask_u8):
+        n, r, ldu = self._check_matrix(Ur)
+        _lib.check(self.lib.spr_mask_rows_f64(_ptr(Ur), n, r, ldu, _ptr(mask_u8), self._stream()),
+                   'spr_mask_rows_f64')
+
+    def qr_begin(self, Ur, row0, n_steps):
+        """Allocate the pivoting state and compute the initial norms / local candidate."""
+        n, r, ldu = self._check_matrix(Ur)
+        t = self.torch
+        st = dict(Ur=Ur, n=n, r=r, ldu=ldu, row0=row0,
+                  nrm=self.empty((n,)), cand=self.empty((r + 3,)), Q=self.zeros((n_steps, r)),
+                  piv=self.zeros((n_steps,), dtype=t.int64), gap=self.zeros((n_steps,)),
+                  ws=self._workspace('qr', self.lib.spr_qr_workspace(n)))
+        _lib.check(self.lib.spr_qr_init_f64(_ptr(Ur), n, r, ldu, row0, _ptr(st['nrm']), _ptr(st['cand']),
+                                            _ptr(st['ws']), st['ws'].numel(), self._stream()), 'spr_qr_init_f64')
+        return st
+
+    def qr_step(self, st, step, cands):
+        """cands: (n_cand, r+3) tensor of the ranks' candidate records (st['cand'][None] on one GPU)."""
+        _lib.check(self.lib.spr_qr_step_f64(_ptr(st['Ur']), st['n'], st['r'], st['ldu'], st['row0'], step,
+                                            _ptr(cands), cands.shape[0], _ptr(st['Q']), _ptr(st['piv']),
+                                            _ptr(st['nrm']), _ptr(st['cand']), _ptr(st['gap']), _ptr(st['ws']),
+                                            st['ws'].numel(), self._stream()), 'spr_qr_step_f64')
+
+    # ---- K7 + K8 -------------------------------------------------------------------------------
+    def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean):
+        n, r, ldu = self._check_matrix(Ur)
+        s = indptr.shape[0] - 1
+        Theta = self.empty((s, r))
+        cnt = self.empty((s,))
+        _lib.check(self.lib.spr_measure_csr_f64(_ptr(indptr), _ptr(indices), _ptr(vals), s, _ptr(Ur), n, r, ldu,
+                                                row0, _ptr(rowmean), _ptr(Theta), _ptr(cnt), self._stream()),
+                   'spr_measure_csr_f64')
+        return Theta, cnt
+
+    # ---- K8 + K9 -------------------------------------------------------------------------------
+    def solve_ols(self, Theta, cnt, scale, y):
+        """y: (n_p, s, 3) device tensor. -> Ar (n_p,r), Ar_sigma (n_p,r), y0 (n_p,s,2), info (n_p,2)."""
+        s, r = Theta.shape
+        n_p = y.shape[0]
+        Ar = self.empty((n_p, r))
+        Ar_sigma = self.empty((n_p, r))
+        y0 = self.empty((n_p, s, 2))
+        info = self.empty((n_p, 2))
+        _lib.check(self.lib.spr_solve_ols_f64(_ptr(Theta.contiguous()), s, r, _ptr(cnt), _ptr(scale),
+                                              scale.shape[0], _ptr(y.contiguous()), n_p, _ptr(Ar), _ptr(Ar_sigma),
+                                              _ptr(y0), _ptr(info), self._stream()), 'spr_solve_ols_f64')
+        return Ar, Ar_sigma, y0, info
+
+    # ---- synthetic data ---------------------------------------------------------------------------
+    def synth(self, n_rows, m, row0, n_points, R, eps, seed, out=None):
+        """Rows [row0, row0+n_rows) of the synthetic matrix; R is (k, >=m) on the device."""
+        if out is None:
+            out = self.empty((n_rows, m))
+        k, ldr = R.shape[0], R.stride(0)
+        _lib.check(self.lib.spr_synth_f64(_ptr(out), n_rows, m, out.stride(0), row0, n_points, 0, _ptr(R), k, ldr,
+                                          float(eps), int(seed), self._stream()), 'spr_synth_f64')
+        return out
+
+    def synth_gather(self, rows, n_points, col, R, eps, seed):
+        out = self.empty((rows.shape[0],))
+        _lib.check(self.lib.spr_synth_gather_f64(_ptr(rows), rows.shape[0], n_points, col, _ptr(R), R.shape[0],
+                                                 R.stride(0), float(eps), int(seed), _ptr(out), self._stream()),
+                   'spr_synth_gather_f64')
+        return out

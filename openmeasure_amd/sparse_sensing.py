@@ -1,0 +1,509 @@
+"""MI355X-native ``ROM`` / ``SPR`` with the class surface of
+``openmeasure.sparse_sensing`` (reference: src/openmeasure/sparse_sensing.py).
+
+Same constructor, method names, keyword defaults, return shapes and exception types as
+the reference for the SPR hot path
+
+    fit -> optimal_placement('qr') -> train -> predict('OLS') -> reconstruct
+
+but the arithmetic runs in hand-written gfx950 kernels behind ``libspr_hip.so``
+(include/spr_hip.h) instead of NumPy/LAPACK:
+
+  reference call (file:line)                       here
+  -----------------------------------------------  ------------------------------------------
+  np.average / np.std / X0 = (X-cnt)/scl           one fused pass: row means, per-feature
+    (:112, :115, :169)                               Welford stats, per-feature f64-MFMA Gram
+  np.linalg.svd(X0) (:272)                         m x m eigen-problem of the Gram matrix (host,
+                                                     tiny) + MFMA projection Ur = X0 V S^-1
+  scipy.linalg.qr(Ur.T, pivoting=True) (:739)      greedy residual-norm pivoting, r streaming
+                                                     sweeps over Ur
+  C.dot(Ur), C.dot(X_cnt) (:797, :573)             CSR row gather / SpMM
+  np.linalg.pinv(W Theta) ... (:873-878)           MFMA normal equations + Cholesky per vector
+  Ur @ Ar.T, unscale_data (:371-373, :235)         one streaming GEMV with fused un-scaling
+
+What differs from the reference, by design:
+  * X0 is never materialised by ``fit`` (``self.X0`` is built on first access);
+  * singular vectors come from the Gram route, so columns of Ur/Ar/Vr may differ from
+    LAPACK's by a sign, and a mode whose singular value is below ~1e-7 sigma_1 (the null
+    mode that row-centring always creates when r = m) is numerically meaningless in both;
+  * fitted arrays live in HBM; ``X_cnt``, ``X_scl``, ``Ur``, ... are copied to NumPy on
+    first access;
+  * options that have no device implementation yet ('gem' placement, 'COLS', scalings
+    other than 'std', ``axis_cnt=None``, ``sampling=``) raise ``NotImplementedError`` --
+    they never fall back to a CPU path.
+
+Row sharding: pass ``shard=RowShard(row0, n_global, group)`` and the local block of rows;
+the Gram matrix is all-reduced, pivot candidates are all-gathered per step, Theta is
+all-reduced and the reconstructed field is all-gathered (RCCL through torch.distributed).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix']
+
+_DENSE_C_LIMIT = 1 << 30   # optimal_placement returns a dense ndarray below this many bytes
+
+
+class RowShard:
+    """This process's slice of the global feature-major snapshot matrix.
+
+    row0      first global row held locally
+    n_global  total rows (= n_points * n_features) over all ranks
+    group     torch.distributed process group (None = default group); world size 1 if
+              torch.distributed is not initialised.
+    Every rank must hold the same number of rows (the field all-gather needs it).
+    """
+
+    def __init__(self, row0, n_global, group=None):
+        self.row0 = int(row0)
+        self.n_global = int(n_global)
+        self.group = group
+
+    @property
+    def world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        import torch.distributed as dist
+        return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+
+
+class DeviceMatrix:
+    """A snapshot block that already lives in HBM (2-D float64 CUDA tensor, rows contiguous)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+
+def _sign_fix(V):
+    """Deterministic eigenvector signs: the entry of largest magnitude is positive."""
+    idx = np.argmax(np.abs(V), axis=0)
+    sgn = np.sign(V[idx, np.arange(V.shape[1])])
+    sgn[sgn == 0] = 1.0
+    return V * sgn
+
+
+class ROM:
+    """Reduced-order-model utilities (reference: ROM, sparse_sensing.py:18-511)."""
+
+    def __init__(self, X, n_features, xyz, shard=None, engine=None):
+        # reference :69-81 -- same checks, same exception types, in the same order
+        if isinstance(X, DeviceMatrix):
+            pass
+        elif type(X) is not np.ndarray:
+            raise TypeError('The matrix X is not a numpy array.')
+        if type(n_features) is not int:
+            raise TypeError('The parameter n_features is not an integer.')
+        self.X = X
+        self.n_features = n_features
+        self.xyz = xyz
+        self._shard = shard
+        n = shard.n_global if shard is not None else X.shape[0]
+        self.n_points = n // self.n_features
+        if n % self.n_features != 0:
+            raise Exception('The number of rows of X is not a multiple of n_features')
+        self._n_global = n
+        self._row0 = shard.row0 if shard is not None else 0
+        if self._row0 + X.shape[0] > n:
+            raise ValueError('The local row block does not fit in the global matrix.')
+        self._eng = engine
+        self._d = {}            # device-resident state
+        self._host = {}         # lazily downloaded copies
+
+    # ------------------------------------------------------------------ plumbing
+    def _engine(self):
+        if self._eng is None:
+            from .engine import HipEngine
+            self._eng = HipEngine()
+        return self._eng
+
+    def _world(self):
+        return self._shard.world if self._shard is not None else 1
+
+    def _Xd(self):
+        if 'X' not in self._d:
+            eng = self._engine()
+            if isinstance(self.X, DeviceMatrix):
+                self._d['X'] = self.X.tensor
+            else:
+                if self.X.ndim != 2:
+                    raise ValueError('X must be a 2-D array.')
+                self._d['X'] = eng.to_device(self.X)
+        return self._d['X']
+
+    def _all_reduce(self, t):
+        if self._world() > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self._shard.group)
+        return t
+
+    def _all_gather(self, t):
+        """-> tensor (world, *t.shape)"""
+        if self._world() == 1:
+            return t[None]
+        import torch.distributed as dist
+        out = t.new_empty((self._world(),) + tuple(t.shape))
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self._shard.group)
+        return out
+
+    def _lazy(self, key, make):
+        if key not in self._host:
+            self._host[key] = make()
+        return self._host[key]
+
+    def _feature_rows(self):
+        """per local row: its feature id (host, int) -- only used to expand per-feature scalars"""
+        n_loc = self.X.shape[0]
+        return (self._row0 + np.arange(n_loc)) // self.n_points
+
+    # ------------------------------------------------------------------ fitted attributes
+    @property
+    def X_cnt(self):
+        """(n_local, 1) row means (reference attribute set at :166)."""
+        return self._lazy('X_cnt', lambda: self._engine().to_host(self._d['rowmean'])[:, None])
+
+    @property
+    def X_scl(self):
+        """(n_local, 1) per-feature population std, repeated per row (:167)."""
+        return self._lazy('X_scl', lambda: self._scl_f[self._feature_rows()][:, None])
+
+    @property
+    def Ur(self):
+        """(n_local, r) POD basis rows held by this rank."""
+        return self._lazy('Ur', lambda: np.ascontiguousarray(self._engine().to_host(self._d['Ur'])))
+
+    @property
+    def X0(self):
+        """(n_local, m) centred/scaled matrix (:169, :492); built on first access only."""
+        def make():
+            eng = self._engine()
+            t = eng.scale_rows(self._Xd(), self._row0, self.n_points, self.n_features, self._d['rowmean'],
+                               self._d['inv_scale'])
+            return eng.to_host(t)
+        return self._lazy('X0', make)
+
+    # ------------------------------------------------------------------ a2 scale_data
+    def _check_scaling(self, scale_type, axis_cnt):
+        known = ['std', 'none', 'pareto', 'vast', 'range', 'level', 'max', 'variance', 'median', 'poisson',
+                 'vast_2', 'vast_3', 'vast_4', 'l2-norm']
+        if scale_type not in known:
+            raise NotImplementedError('The scaling method selected has not been implemented yet')   # :164
+        if scale_type != 'std' or axis_cnt != 1:
+            raise NotImplementedError(f"scale_type={scale_type!r}, axis_cnt={axis_cnt!r}: only 'std' with "
+                                      'axis_cnt=1 has a device implementation (no CPU fallback).')
+
+    def _stats_pass(self):
+        """Fused K1+K3a pass, cross-rank merge, per-feature scale. Leaves rowmean/scale on the device."""
+        eng = self._engine()
+        Xd = self._Xd()
+        m = Xd.shape[1]
+        F = self.n_features
+        rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+        gram = self._all_reduce(gram)
+        fs = eng.to_host(self._all_gather(fstats))          # (world, F, 3)
+        G_f = eng.to_host(gram)                              # (F, m, m)
+        cnt = np.zeros(F); mu = np.zeros(F); m2 = np.zeros(F)
+        for w in range(fs.shape[0]):                         # Chan merge in rank order
+            nb, mb, sb = fs[w, :, 0], fs[w, :, 1], fs[w, :, 2]
+            tot = cnt + nb
+            with np.errstate(invalid='ignore', divide='ignore'):
+                d = mb - mu
+                frac = np.where(tot > 0, nb / np.where(tot > 0, tot, 1), 0.0)
+                m2 = m2 + sb + d * d * cnt * frac
+                mu = mu + d * frac
+            cnt = tot
+        tr = np.trace(G_f, axis1=1, axis2=2)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            var_f = (tr + m * m2) / (cnt * m)                # population variance of the raw block (:115)
+        self._scl_f = np.sqrt(var_f)
+        self._var_f = var_f
+        self._G_f = G_f
+        self._d['rowmean'] = rowmean
+        self._d['scale'] = eng.to_device(self._scl_f)
+        with np.errstate(divide='ignore'):
+            self._d['inv_scale'] = eng.to_device(1.0 / self._scl_f)
+        for k in ('X_cnt', 'X_scl', 'X0'):
+            self._host.pop(k, None)
+
+    def scale_data(self, scale_type='std', axis_cnt=1):
+        """Reference :83-171.  Sets X_cnt / X_scl and returns the scaled matrix X0."""
+        self._check_scaling(scale_type, axis_cnt)
+        self._stats_pass()
+        return self.X0
+
+    # ------------------------------------------------------------------ a11 unscale_data
+    def unscale_data(self, x0, sampling=None):
+        """Reference :212-240: x = X_scl * x0 + X_cnt for an (n_local,) vector."""
+        if sampling is not None:
+            raise NotImplementedError('unscale_data(sampling=...) has no device implementation yet.')
+        if type(x0) is not np.ndarray:
+            raise NotImplementedError('unscale_data of a cvxpy expression is outside the device path.')
+        eng = self._engine()
+        t = eng.unscale(eng.to_device(x0), self._row0, self.n_points, self.n_features, self._d['rowmean'],
+                        self._d['scale'])
+        return eng.to_host(t)
+
+    # ------------------------------------------------------------------ a4 reduction
+    def _select_rank(self, exp_variance, n_cols, select_modes, n_modes):
+        """Integer logic of ROM.reduction (:314-333), same exceptions."""
+        if select_modes == 'variance':
+            if not 0 <= n_modes <= 100:
+                raise ValueError('The parameter n_modes is outside the[0-100] range.')
+            if n_modes == 100:
+                r = n_cols
+            else:
+                r = 1
+                while exp_variance[r - 1] < n_modes:
+                    r += 1
+        elif select_modes == 'number':
+            if not type(n_modes) is int:
+                raise TypeError('The parameter n_modes is not an integer.')
+            if not 1 <= n_modes <= n_cols:
+                raise ValueError('The parameter n_modes is outside the [1-m] range.')
+            r = n_modes
+        else:
+            raise ValueError('The select_mode value is wrong.')
+        return r
+
+    def reduction(self, U, A, exp_variance, select_modes, n_modes):
+        """Reference :281-340 (host arrays in, views out)."""
+        r = self._select_rank(exp_variance, A.shape[1], select_modes, n_modes)
+        self.r = r
+        return U[:, :r], A[:, :r]
+
+    # ------------------------------------------------------------------ a3 decomposition
+    def _spectrum(self, G):
+        """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
+        lam, V = np.linalg.eigh(G)
+        lam = lam[::-1]
+        V = _sign_fix(V[:, ::-1])
+        lam_pos = np.maximum(lam, 0.0)
+        S = np.sqrt(lam_pos)
+        exp_variance = 100 * np.cumsum(lam_pos) / np.sum(lam_pos)
+        return S, V, exp_variance
+
+    def _basis_from_gram(self, G, select_modes, n_modes, center, inv_scale_d):
+        eng = self._engine()
+        Xd = self._Xd()
+        m = Xd.shape[1]
+        S, V, exp_variance = self._spectrum(G)
+        r = self._select_rank(exp_variance, m, select_modes, n_modes)
+        # modes below sqrt(m eps) sigma_1 carry no information on the Gram route; keep the
+        # projection finite for them (their reference counterparts are LAPACK rounding noise)
+        floor = S[0] * np.sqrt(m * np.finfo(float).eps)
+        S_safe = np.maximum(S[:r], floor if floor > 0 else 1.0)
+        W = V[:, :r] / S_safe
+        Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, eng.to_device(W),
+                           center=center)
+        Ar = V[:, :r] * S[:r]                                # A = (diag(S) Vt).T  (:273)
+        return Ur_d, Ar, exp_variance[:r], S, r
+
+    def decomposition(self, X0, select_modes='variance', n_modes=99):
+        """Reference :242-279 on a caller-supplied scaled matrix X0 (host ndarray, local rows).
+        Returns (Ur, Ar, exp_variance[:r]) as host arrays."""
+        eng = self._engine()
+        X0d = eng.to_device(X0)
+        _, _, gram = eng.stats_gram(X0d, 0, X0d.shape[0], 1, center=False)
+        G = eng.to_host(self._all_reduce(gram))[0]
+        ones = eng.to_device(np.ones(1))
+        S, V, exp_variance = self._spectrum(G)
+        m = X0d.shape[1]
+        r = self._select_rank(exp_variance, m, select_modes, n_modes)
+        floor = S[0] * np.sqrt(m * np.finfo(float).eps)
+        W = V[:, :r] / np.maximum(S[:r], floor if floor > 0 else 1.0)
+        Ur_d = eng.project(X0d, 0, X0d.shape[0], 1, ones, eng.to_device(W), center=False)
+        self.r = r
+        return np.ascontiguousarray(eng.to_host(Ur_d)), V[:, :r] * S[:r], exp_variance[:r]
+
+    # ------------------------------------------------------------------ a5 fit
+    def fit(self, scale_type='std', axis_cnt=1, select_modes='variance', n_modes=99, basis=None):
+        """Reference :463-511."""
+        self._check_scaling(scale_type, axis_cnt)
+        if basis is None and select_modes not in ('variance', 'number'):
+            raise ValueError('The select_mode value is wrong.')
+        eng = self._engine()
+        self.scale_type = scale_type
+        self._stats_pass()
+        self._host.clear()
+        if basis is None:
+            with np.errstate(invalid='ignore', divide='ignore'):
+                G = np.sum(self._G_f / self._var_f[:, None, None], axis=0)
+            Ur_d, Ar, expv, S, r = self._basis_from_gram(G, select_modes, n_modes, True, self._d['inv_scale'])
+            self.exp_variance_ = expv
+            self.S_ = S
+        else:
+            Ur_d = eng.to_device(basis[0])
+            Ar = np.asarray(basis[1])
+        self._d['Ur'] = Ur_d
+        self.Ar = Ar
+        self.r = Ar.shape[1]
+        Sigma_r = np.linalg.norm(Ar, axis=0)                  # :504-508
+        self.Sigma_r = Sigma_r
+        self.Vr = Ar / Sigma_r
+        for k in ('C', 'Theta'):
+            self.__dict__.pop(k, None)
+
+    # ------------------------------------------------------------------ a10 reconstruct
+    def reconstruct(self, Ar, sampling=None, to_host=True):
+        """Reference :342-375.  Returns X_rec of shape (n, n_p) (all ranks' rows, gathered).
+
+        ``to_host=False`` returns the device tensor of shape (n_p, n) instead (same values,
+        column-major) and skips the PCIe copy."""
+        if sampling is not None:
+            raise NotImplementedError('reconstruct(sampling=...) has no device implementation yet.')
+        eng = self._engine()
+        Ar = np.asarray(Ar, dtype=np.float64) if not hasattr(Ar, 'is_cuda') else Ar
+        if Ar.ndim < 2:
+            Ar = Ar[None, :]
+        A_d = Ar if hasattr(Ar, 'is_cuda') else eng.to_device(Ar)
+        Ur_d = self._d['Ur']
+        n_loc = Ur_d.shape[0]
+        n_p = A_d.shape[0]
+        world = self._world()
+        if world == 1:
+            out = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
+                                  self._d['scale'], A_d)
+        else:
+            import torch.distributed as dist
+            loc = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
+                                  self._d['scale'], A_d)
+            out = eng.empty((n_p, world * n_loc))
+            for p in range(n_p):                              # one contiguous all-gather per column
+                dist.all_gather_into_tensor(out[p], loc[p], group=self._shard.group)
+        if not to_host:
+            return out
+        return eng.to_host(out).T                             # (n, n_p), Fortran-ordered view
+
+
+class SPR(ROM):
+    """Sparse Placement for Reconstruction (reference: SPR, sparse_sensing.py:513-901)."""
+
+    def __init__(self, X, n_features, xyz, shard=None, engine=None):
+        super().__init__(X, n_features, xyz, shard=shard, engine=engine)
+
+    # ------------------------------------------------------------------ a6 optimal_placement
+    def optimal_placement(self, calc_type='qr', n_sensors=10, mask=None, d_min=0., verbose=False):
+        """Reference :700-756.  Returns the one-hot measurement matrix C of shape (s, n):
+        a dense ndarray when it is small (< 1 GiB), a scipy.sparse CSR matrix otherwise.
+        The ordered global sensor rows are also kept in ``self.sensors_``."""
+        if calc_type == 'gem':
+            raise NotImplementedError("calc_type='gem' has no device implementation yet (no CPU fallback).")
+        if calc_type != 'qr':
+            raise NotImplementedError('The sensor selection method has not been implemented yet')
+        eng = self._engine()
+        n = self._n_global
+        Ur_d = self._d['Ur']
+        if mask is not None:
+            mask = np.asarray(mask)
+            if mask.dtype != np.bool_ or mask.shape != (Ur_d.shape[0],):
+                raise IndexError('mask must be a boolean array with one entry per (local) row')
+            eng.mask_rows(Ur_d, eng.to_device(mask.astype(np.uint8), dtype=eng.torch.uint8))   # :737-738
+            self._host.pop('Ur', None)
+        s = self.r
+        st = eng.qr_begin(Ur_d, self._row0, s)
+        for j in range(s):
+            eng.qr_step(st, j, self._all_gather(st['cand']))
+        piv = eng.to_host(st['piv']).astype(np.int64)
+        self.sensors_ = piv
+        self.pivot_gap_ = eng.to_host(st['gap'])
+        import scipy.sparse as sp
+        C = sp.csr_matrix((np.ones(s), piv, np.arange(s + 1)), shape=(s, n))
+        if s * n * 8 <= _DENSE_C_LIMIT:
+            C = C.toarray()
+        self._placed = (C, piv)
+        return C
+
+    # ------------------------------------------------------------------ a7 train
+    def train(self, C, is_Theta=False, limits=None, method='OLS', solver='CLARABEL', cond=False, verbose=False):
+        """Reference :758-820."""
+        n = self._n_global
+        if (C.shape[1] != n) and not is_Theta:
+            raise ValueError('The number of columns of C does not match the number'
+                             ' of rows of X.')
+        if method == 'COLS':
+            raise NotImplementedError("method='COLS' needs a conic solver; it has no device implementation "
+                                      '(no CPU fallback).')
+        eng = self._engine()
+        if not is_Theta:
+            placed = getattr(self, '_placed', None)
+            import scipy.sparse as sp
+            if placed is not None and placed[0] is C:
+                piv = placed[1]
+                indptr, indices, vals = np.arange(len(piv) + 1), piv, np.ones(len(piv))
+            else:
+                Cs = C.tocsr() if sp.issparse(C) else sp.csr_matrix(np.asarray(C, dtype=np.float64))
+                Cs.sort_indices()
+                indptr, indices, vals = Cs.indptr, Cs.indices, Cs.data
+            t = eng.torch
+            Theta_d, cnt_d = eng.measure_csr(eng.to_device(indptr, dtype=t.int64), eng.to_device(indices, dtype=t.int64),
+                                             eng.to_device(vals), self._d['Ur'], self._row0, self._d['rowmean'])
+            Theta_d = self._all_reduce(Theta_d)
+            cnt_d = self._all_reduce(cnt_d)
+            self.C = C
+            self._d['cnt'] = cnt_d
+            Theta = eng.to_host(Theta_d)
+        else:
+            Theta = np.asarray(C, dtype=np.float64)
+            Theta_d = None
+        if Theta.shape[1] != self.r:
+            raise ValueError('The number of columns of Theta does not match the number'
+                             ' of columns of Ur.')
+        self._d['Theta'] = Theta_d if Theta_d is not None else eng.to_device(Theta)
+        self.Theta = Theta
+        self.limits = limits
+        self.method = method
+        self.solver = solver
+        self.verbose = verbose
+        if cond == True:                                      # noqa: E712  (:813-820; s x r, host-sized)
+            if Theta.shape[0] == Theta.shape[1]:
+                S_theta = np.linalg.svd(Theta, compute_uv=False)
+            else:
+                S_theta = np.linalg.svd(np.linalg.pinv(Theta), compute_uv=False)
+            self.k = S_theta[0] / S_theta[-1]
+
+    # ------------------------------------------------------------------ a8 / a9
+    def _solve(self, ys):
+        eng = self._engine()
+        if 'cnt' not in self._d:
+            raise AttributeError("'SPR' object has no attribute 'C'")      # reference fails at self.C (:573)
+        Y = eng.to_device(np.stack([np.asarray(y, dtype=np.float64) for y in ys]))
+        Ar_d, As_d, y0_d, info_d = eng.solve_ols(self._d['Theta'], self._d['cnt'], self._d['scale'], Y)
+        info = eng.to_host(info_d)
+        if np.any(info[:, 0] != 0) or np.any(info[:, 1] > 1e10):
+            raise np.linalg.LinAlgError(
+                'predict: the normal equations of W*Theta are numerically singular '
+                f'(pivot ratio^2 up to {np.nanmax(info[:, 1]):.3g}); refusing to return a degraded solution.')
+        return eng.to_host(Ar_d), eng.to_host(As_d), eng.to_host(y0_d)
+
+    def scale_vector(self, y):
+        """Reference :553-584.  Returns y0 (s,2); sets cnt_vector / scl_vector."""
+        _, _, y0 = self._solve([y])
+        self.cnt_vector = self._engine().to_host(self._d['cnt'])
+        self.scl_vector = self._scl_f[np.asarray(y)[:, 2].astype('int')]
+        return y0[0]
+
+    def predict(self, y):
+        """Reference :822-901 (OLS branch).  Returns (Ar, Ar_sigma), each (n_p, r)."""
+        if isinstance(y, np.ndarray):
+            y = [y]
+        for i in range(len(y)):
+            if self.Theta.shape[0] != y[i].shape[0]:
+                raise ValueError('The number of rows of Theta does not match the number'
+                                 ' of rows of y.')
+            if y[i].shape[1] != 3:
+                raise ValueError('The y array has the wrong number of columns. y has'
+                                 ' to have dimensions (s,3).')
+        if self.method != 'OLS':
+            raise NotImplementedError('The prediction method selected has not been '
+                                      'implemented yet')
+        Ar, Ar_sigma, y0 = self._solve(y)
+        self.cnt_vector = self._engine().to_host(self._d['cnt'])
+        self.scl_vector = self._scl_f[np.asarray(y[-1])[:, 2].astype('int')]
+        return Ar, Ar_sigma

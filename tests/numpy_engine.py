@@ -1,0 +1,163 @@
+"""NumPy stand-in for openmeasure_amd.engine.HipEngine -- TEST DOUBLE, lives under tests/ only.
+
+Same method set and tensor conventions as HipEngine, but on CPU torch tensors, so that the
+host half of the SPR classes (validation, Gram-route algebra, Chan merges, sharding and the
+collective call pattern over the gloo backend) can be exercised on machines without a GPU.
+It models what the kernels compute (per-feature centred Gram, greedy residual-norm
+pivoting with norm down-dating, normal equations + Cholesky), not how.  The package never
+imports this file; without libspr_hip.so and a GPU the product raises instead.
+"""
+import numpy as np
+import torch
+
+
+class NumpyEngine:
+    name = 'numpy-test-double'
+
+    def __init__(self):
+        self.torch = torch
+        self.device = torch.device('cpu')
+
+    # plumbing
+    def empty(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or torch.float64)
+
+    def zeros(self, shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or torch.float64)
+
+    def to_device(self, a, dtype=None):
+        return torch.as_tensor(np.ascontiguousarray(a)).to(dtype or torch.float64).contiguous()
+
+    def to_host(self, t):
+        return t.detach().numpy()
+
+    @staticmethod
+    def _feat(n, row0, n_points, F):
+        return np.minimum((row0 + np.arange(n)) // n_points, F - 1)
+
+    # K1 + K3a
+    def stats_gram(self, X, row0, n_points, n_features, center=True):
+        x = X.numpy()
+        n, m = x.shape
+        mean = x.mean(axis=1) if center else np.zeros(n)
+        c = x - mean[:, None]
+        feat = self._feat(n, row0, n_points, n_features)
+        fstats = np.zeros((n_features, 3))
+        gram = np.zeros((n_features, m, m))
+        for f in range(n_features):
+            sel = feat == f
+            if sel.any():
+                mu = mean[sel].mean()
+                fstats[f] = (sel.sum(), mu, ((mean[sel] - mu) ** 2).sum())
+                gram[f] = c[sel].T @ c[sel]
+        return torch.from_numpy(mean.copy()), torch.from_numpy(fstats), torch.from_numpy(gram)
+
+    # K4
+    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True):
+        x = X.numpy()
+        n = x.shape[0]
+        mean = x.mean(axis=1) if center else np.zeros(n)
+        feat = self._feat(n, row0, n_points, n_features)
+        U = ((x - mean[:, None]) @ W.numpy()) * inv_scale.numpy()[feat][:, None]
+        return torch.from_numpy(np.ascontiguousarray(U))
+
+    def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
+        feat = self._feat(X.shape[0], row0, n_points, n_features)
+        return torch.from_numpy((X.numpy() - rowmean.numpy()[:, None]) * inv_scale.numpy()[feat][:, None])
+
+    def unscale(self, x0, row0, n_points, n_features, rowmean, scale):
+        feat = self._feat(x0.shape[0], row0, n_points, n_features)
+        return torch.from_numpy(scale.numpy()[feat] * x0.numpy() + rowmean.numpy())
+
+    # K10 + K11
+    def reconstruct(self, Ur, row0, n_points, n_features, rowmean, scale, A, out=None):
+        feat = self._feat(Ur.shape[0], row0, n_points, n_features)
+        x = (Ur.numpy() @ A.numpy().T) * scale.numpy()[feat][:, None] + rowmean.numpy()[:, None]
+        return torch.from_numpy(np.ascontiguousarray(x.T))
+
+    # K6
+    def mask_rows(self, Ur, mask_u8):
+        Ur[mask_u8 == 0, :] = 0.0
+
+    def _candidate(self, st):
+        nrm = st['nrm'].numpy()
+        i = int(np.argmax(nrm))                      # first index on ties
+        second = np.partition(nrm, -2)[-2] if nrm.size > 1 else -2.0
+        cand = np.concatenate([[nrm[i], st['row0'] + i, second], st['Ur'].numpy()[i]])
+        st['cand'] = torch.from_numpy(cand)
+
+    def qr_begin(self, Ur, row0, n_steps):
+        n, r = Ur.shape
+        st = dict(Ur=Ur, n=n, r=r, row0=row0, nrm=torch.from_numpy((Ur.numpy() ** 2).sum(axis=1)),
+                  Q=torch.zeros((n_steps, r), dtype=torch.float64),
+                  piv=torch.zeros((n_steps,), dtype=torch.int64),
+                  gap=torch.zeros((n_steps,), dtype=torch.float64))
+        self._candidate(st)
+        return st
+
+    def qr_step(self, st, step, cands):
+        c = cands.numpy()
+        order = np.lexsort((c[:, 1], -c[:, 0]))      # max value, then lowest index
+        w = order[0]
+        piv = int(c[w, 1])
+        st['piv'][step] = piv
+        others = [c[w, 2]] + [c[i, 0] for i in range(c.shape[0]) if i != w]
+        st['gap'][step] = (c[w, 0] - max(others)) / c[w, 0] if c[w, 0] > 0 else 0.0
+        v = c[w, 3:].copy()
+        Q = st['Q'].numpy()
+        for _ in range(2):
+            v -= Q[:step].T @ (Q[:step] @ v)
+        nn = np.linalg.norm(v)
+        q = v / nn if nn > 0 else np.zeros_like(v)
+        Q[step] = q
+        nrm = st['nrm'].numpy()
+        d = st['Ur'].numpy() @ q
+        new = np.maximum(nrm - d * d, 0.0)
+        new[nrm < 0] = -1.0
+        li = piv - st['row0']
+        if 0 <= li < st['n']:
+            new[li] = -1.0
+        nrm[:] = new
+        self._candidate(st)
+
+    # K7 + K8
+    def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean):
+        ip, ix, v = indptr.numpy(), indices.numpy(), vals.numpy()
+        s, n, r = len(ip) - 1, Ur.shape[0], Ur.shape[1]
+        Theta = np.zeros((s, r))
+        cnt = np.zeros(s)
+        U, mu = Ur.numpy(), rowmean.numpy()
+        for i in range(s):
+            for e in range(ip[i], ip[i + 1]):
+                col = ix[e] - row0
+                if 0 <= col < n:
+                    Theta[i] += v[e] * U[col]
+                    cnt[i] += v[e] * mu[col]
+        return torch.from_numpy(Theta), torch.from_numpy(cnt)
+
+    # K8 + K9
+    def solve_ols(self, Theta, cnt, scale, y):
+        Th, c, sc, Y = Theta.numpy(), cnt.numpy(), scale.numpy(), y.numpy()
+        n_p, s, r = Y.shape[0], Th.shape[0], Th.shape[1]
+        Ar = np.zeros((n_p, r)); As = np.zeros((n_p, r)); y0 = np.zeros((n_p, s, 2)); info = np.zeros((n_p, 2))
+        for p in range(n_p):
+            scl = sc[Y[p, :, 2].astype(int)]
+            y0[p, :, 0] = (Y[p, :, 0] - c) / scl
+            y0[p, :, 1] = Y[p, :, 1] / scl
+            weighted = np.any(Y[p, :, 1] != 0)
+            w = 1.0 / y0[p, :, 1] if weighted else np.ones(s)
+            A = Th * w[:, None]
+            dn = np.sqrt(np.sum(A * A, axis=0))
+            dn[dn == 0] = 1.0
+            A = A / dn                                   # column equilibration, as the kernel does
+            N = A.T @ A
+            try:
+                L = np.linalg.cholesky(N)
+                d = np.diag(L)
+                info[p, 1] = (d.max() / d.min()) ** 2
+                Ar[p] = np.linalg.solve(N, A.T @ (w * y0[p, :, 0])) / dn
+                if weighted:
+                    As[p] = np.abs(np.linalg.solve(N, A.T @ y0[p, :, 1]) / dn)
+            except np.linalg.LinAlgError:
+                info[p, 0] = 1
+        return (torch.from_numpy(Ar), torch.from_numpy(As), torch.from_numpy(y0), torch.from_numpy(info))

@@ -1,0 +1,91 @@
+"""Parity checks of openmeasure_amd.SPR against a golden fixture -- shared by the CPU
+tests (NumPy test double engine: host logic only) and the GPU tests (HIP engine)."""
+import numpy as np
+
+from openmeasure_amd.sparse_sensing import SPR
+
+REL_FRO = 1e-6          # north_star: reconstructed fields within 1e-6 relative Frobenius
+
+
+def rel_fro(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def align_signs(A, B):
+    """column signs that best map A onto B"""
+    s = np.sign(np.sum(A * B, axis=0))
+    s[s == 0] = 1.0
+    return s
+
+
+def well_defined_rank(g):
+    """modes whose singular value is far enough above the Gram route's noise floor"""
+    S = g['S_full']
+    return int(np.sum(S[:g['r']] > 1e-6 * S[0]))
+
+
+def run_fixture(g, engine, check_pivots=True):
+    """fit -> optimal_placement -> train -> predict -> reconstruct on fixture g; returns the model."""
+    X = g['X'].copy()
+    n, m = X.shape
+    F = g['n_features']
+    spr = SPR(X, F, None, engine=engine)
+    spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+    r = g['r']
+    assert spr.r == r
+    # a2: centring / scaling
+    np.testing.assert_allclose(spr.X_cnt, g['X_cnt'], rtol=1e-13, atol=1e-13 * np.abs(g['X_cnt']).max())
+    np.testing.assert_allclose(spr.X_scl, g['X_scl'], rtol=1e-12)
+    assert spr.X_cnt.shape == (n, 1) and spr.X_scl.shape == (n, 1)
+    # a3/a5: spectrum and basis (up to column sign; only modes above the noise floor)
+    rw = well_defined_rank(g)
+    S0 = g['S_full'][0]
+    np.testing.assert_allclose(spr.Sigma_r[:rw], g['Sigma_r'][:rw], rtol=1e-8, atol=1e-9 * S0)
+    np.testing.assert_allclose(spr.exp_variance_[:rw], g['exp_variance'][:rw], rtol=1e-9)
+    sg = align_signs(spr.Ar[:, :rw], g['Ar'][:, :rw])
+    np.testing.assert_allclose(spr.Ar[:, :rw] * sg, g['Ar'][:, :rw], rtol=0, atol=1e-8 * S0)
+    np.testing.assert_allclose(spr.Vr[:, :rw] * sg, g['Vr'][:, :rw], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(spr.Ur[:, :rw] * sg, g['Ur'][:, :rw], rtol=0, atol=1e-8)
+    assert spr.Ur.shape == (n, r) and spr.Ar.shape == (m, r)
+    # a6: sensors -- exact, ordered; only meaningful when every retained mode is well defined
+    mask = g.get('mask')
+    C = spr.optimal_placement(mask=mask)
+    assert C.shape == tuple(g['C_shape'])
+    if rw == r and check_pivots:
+        np.testing.assert_array_equal(spr.sensors_, g['piv'])
+        np.testing.assert_array_equal(np.argmax(np.asarray(C), axis=1), g['piv'])
+        assert spr.pivot_gap_.min() > 1e-9
+    if mask is not None:
+        assert not spr.Ur[~mask].any()                       # :737-738 zeroes the basis rows in place
+    # from here on compare on the reference's own sensors (independent of pivot parity)
+    piv = g['piv']
+    Cg = np.zeros((len(piv), n))
+    Cg[np.arange(len(piv)), piv] = 1
+    spr.train(Cg, cond=True)
+    sg_r = np.ones(r)
+    sg_r[:rw] = sg
+    if rw == r:
+        np.testing.assert_allclose(spr.Theta * sg_r, g['Theta'], rtol=0, atol=1e-8)
+        assert spr.k == np.float64(spr.k) and abs(spr.k - float(g['k'])) <= 1e-6 * float(g['k'])
+    # a8
+    y0 = spr.scale_vector(g['ys'][1])
+    np.testing.assert_allclose(y0, g['y0_1'], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(spr.cnt_vector, g['cnt_vector'], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(spr.scl_vector, g['scl_vector'], rtol=1e-12)
+    # a9 + a10: coefficients (sign-aligned) and the reconstructed fields
+    A1, S1 = spr.predict(g['ys'][0])
+    A3, S3 = spr.predict(list(g['ys']))
+    assert A1.shape == (1, r) and A3.shape == (3, r) and S3.shape == (3, r)
+    if rw == r:
+        scale = np.abs(g['Ar_pred3']).max()
+        np.testing.assert_allclose(A3 * sg_r, g['Ar_pred3'], rtol=0, atol=1e-7 * scale)
+        np.testing.assert_allclose(S3, g['Ar_sigma3'], rtol=1e-6, atol=1e-9 * np.abs(g['Ar_sigma3']).max())
+        np.testing.assert_allclose(A1 * sg_r, g['Ar_pred1'], rtol=0, atol=1e-7 * scale)
+    assert not S1.any() and not S3[0].any() and S3[1].any()
+    X1 = spr.reconstruct(A1[0])
+    X3 = spr.reconstruct(A3)
+    assert X1.shape == (n, 1) and X3.shape == (n, 3)
+    if rw == r:
+        assert rel_fro(X1, g['X_rec1']) <= REL_FRO
+        assert rel_fro(X3, g['X_rec3']) <= REL_FRO
+    return spr

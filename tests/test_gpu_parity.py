@@ -1,0 +1,236 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  * the golden fixtures produced by the reference (tests/golden), and
+  * the NumPy oracle (oracle/spr_oracle.py) on seeded inputs at sizes it finishes in seconds,
+plus size-independent properties at larger sizes.
+Tolerances: sensor indices exact and ordered; reconstructed fields <= 1e-6 relative
+Frobenius (BASELINE.json north_star); intermediate quantities as stated inline."""
+import numpy as np
+import pytest
+
+from oracle import spr_oracle as orc
+from tests.parity import REL_FRO, align_signs, rel_fro, run_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from openmeasure_amd.engine import HipEngine
+    return HipEngine()
+
+
+def synth_host(n_points, F, m, k, rho, eps, seed):
+    rng = np.random.default_rng(seed)
+    n = n_points * F
+    L = rng.standard_normal((n, k))
+    R = (rho ** np.arange(k))[:, None] * rng.standard_normal((k, m))
+    X = L @ R + eps * rng.standard_normal((n, m))
+    for f in range(F):
+        X[f * n_points:(f + 1) * n_points] = (f + 1) * X[f * n_points:(f + 1) * n_points] + 10.0 * f
+    return np.ascontiguousarray(X)
+
+
+def test_native_library_is_loaded(eng):
+    import os
+    maps = open(f'/proc/{os.getpid()}/maps').read()
+    assert 'libspr_hip.so' in maps
+    assert eng.lib.spr_abi_version() == 1
+
+
+def test_golden_fixture(golden, eng):
+    run_fixture(golden, eng)
+
+
+# ---- kernel-level parity against the oracle, shapes chosen to hit every template family ----
+@pytest.mark.parametrize('n_points,F,m', [
+    (10, 2, 5), (333, 3, 7), (257, 1, 16), (1000, 3, 33), (4099, 2, 48), (700, 4, 64),
+    (513, 2, 80), (1200, 3, 128), (640, 2, 190), (900, 9, 256), (31, 1, 256),
+])
+def test_stats_gram_vs_oracle(eng, n_points, F, m):
+    X = synth_host(n_points, F, m, min(m, 12), 0.8, 1e-3, 1000 + m)
+    X_cnt, X_scl, X0 = orc.scale_data_std(X, F)
+    rowmean, fstats, gram = eng.stats_gram(eng.to_device(X), 0, n_points, F)
+    rowmean, fstats, gram = eng.to_host(rowmean), eng.to_host(fstats), eng.to_host(gram)
+    np.testing.assert_allclose(rowmean, X_cnt[:, 0], rtol=1e-13, atol=1e-13)
+    np.testing.assert_array_equal(fstats[:, 0], n_points)
+    var = (np.trace(gram, axis1=1, axis2=2) + m * fstats[:, 2]) / (n_points * m)
+    np.testing.assert_allclose(np.sqrt(var), X_scl[::n_points, 0], rtol=1e-12)
+    G = np.sum(gram / var[:, None, None], axis=0)
+    Gref = X0.T @ X0
+    assert np.abs(G - Gref).max() <= 1e-12 * np.abs(Gref).max()
+    np.testing.assert_array_equal(G, G.T)               # mirrored exactly
+
+
+@pytest.mark.parametrize('n_points,F,m,r', [
+    (10, 2, 5, 4), (333, 3, 7, 5), (1000, 3, 33, 17), (700, 4, 64, 32), (513, 2, 80, 40),
+    (1200, 3, 128, 64), (900, 9, 256, 64), (300, 2, 256, 128), (2000, 1, 48, 1),
+])
+def test_project_vs_oracle(eng, n_points, F, m, r):
+    X = synth_host(n_points, F, m, min(m, 2 * r), 0.9, 1e-3, 2000 + m + r)
+    X_cnt, X_scl, X0 = orc.scale_data_std(X, F)
+    rng = np.random.default_rng(1)
+    W = rng.standard_normal((m, r))
+    inv = eng.to_device(1.0 / X_scl[::n_points, 0])
+    U = eng.to_host(eng.project(eng.to_device(X), 0, n_points, F, inv, eng.to_device(W)))
+    ref = X0 @ W
+    assert np.abs(U - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('n,r,n_p', [(20, 5, 1), (999, 5, 3), (4096, 32, 1), (5000, 64, 5), (3001, 128, 2), (777, 1, 1), (1234, 14, 2)])
+def test_reconstruct_vs_oracle(eng, n, r, n_p):
+    rng = np.random.default_rng(n + r)
+    F = 1 if n % 3 else 3
+    n_points = n // F
+    Ur = rng.standard_normal((n, r))
+    X_cnt = rng.standard_normal((n, 1)) * 10
+    scl_f = 1.0 + rng.random(F)
+    X_scl = np.repeat(scl_f, n_points)[:, None]
+    A = rng.standard_normal((n_p, r))
+    ref = orc.reconstruct(A, Ur, X_cnt, X_scl)
+    Ud = eng.to_device(np.pad(Ur, ((0, 0), (0, r & 1))))[:, :r]
+    out = eng.to_host(eng.reconstruct(Ud, 0, n_points, F, eng.to_device(X_cnt[:, 0]), eng.to_device(scl_f),
+                                      eng.to_device(A))).T
+    assert out.shape == (n, n_p)
+    assert rel_fro(out, ref) <= 1e-14
+
+
+def _full_path(eng, X, F, r, engine_kwargs=None):
+    from openmeasure_amd.sparse_sensing import SPR
+    n, m = X.shape
+    n_points = n // F
+    spr = SPR(X, F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    C = spr.optimal_placement()
+    rng = np.random.default_rng(99)
+    w = rng.standard_normal(m) / np.sqrt(m)
+    xt = X @ w + X.mean(axis=1) * (1 - w.sum())          # held-out state in the span of the data
+
+    def y_fn(piv):
+        y = np.zeros((len(piv), 3))
+        y[:, 0] = xt[piv]
+        y[:, 2] = piv // n_points
+        return y
+    ref = orc.fit_place_train_predict_reconstruct(X, F, r, y_fn)
+    spr.train(C)
+    a, _ = spr.predict(y_fn(spr.sensors_))
+    xr = spr.reconstruct(a)
+    return spr, ref, xr
+
+
+@pytest.mark.parametrize('n_points,F,m,r', [(18362, 9, 41, 14), (20000, 4, 64, 32), (6000, 3, 128, 16)])
+def test_end_to_end_vs_oracle(eng, n_points, F, m, r):
+    """config-1 shape (18 362 cells x 9 features x 41 snapshots, 14 sensors) and two others:
+    ordered sensor indices exact, reconstructed field within 1e-6 rel-Frobenius."""
+    rho = 10 ** (-3 / (r - 1))
+    X = synth_host(n_points, F, m, min(m, 2 * r), rho, 1e-3, 31 + m)
+    spr, ref, xr = _full_path(eng, X, F, r)
+    np.testing.assert_allclose(spr.Sigma_r, ref['Sigma_r'], rtol=1e-8)
+    np.testing.assert_array_equal(spr.sensors_, ref['piv'])
+    assert spr.pivot_gap_.min() > 1e-9
+    assert rel_fro(xr, ref['X_rec']) <= REL_FRO
+    sg = align_signs(spr.Ur, ref['Ur'])
+    assert np.abs(spr.Ur * sg - ref['Ur']).max() <= 1e-9
+
+
+def test_masked_placement_vs_oracle(eng):
+    from openmeasure_amd.sparse_sensing import SPR
+    X = synth_host(3000, 3, 24, 24, 0.75, 1e-3, 77)
+    st = orc.fit(X, 3, 'number', 8)
+    mask = np.random.default_rng(3).random(X.shape[0]) < 0.4
+    piv, Ur_m = orc.qr_pivots(st['Ur'], mask)
+    spr = SPR(X, 3, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=8)
+    spr.optimal_placement(mask=mask)
+    np.testing.assert_array_equal(spr.sensors_, piv)
+    assert mask[spr.sensors_].all() and not spr.Ur[~mask].any()
+
+
+def test_duplicate_rows_tie_goes_to_lowest_index(eng):
+    """exact ties (duplicated cells) must resolve like LAPACK's idamax: first index wins"""
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((500, 6))
+    U[400] = U[17] = U[3] * 0 + 5.0 * rng.standard_normal(6)   # two identical dominant rows
+    Ud = eng.to_device(U)
+    st = eng.qr_begin(Ud, 0, 6)
+    for j in range(6):
+        eng.qr_step(st, j, st['cand'][None])
+    piv = eng.to_host(st['piv'])
+    ref, _ = orc.qr_pivots(U)
+    assert piv[0] == 17 and 400 not in piv[:1]
+    np.testing.assert_array_equal(piv, ref)
+
+
+def test_weighted_predict_batch_vs_oracle(eng):
+    rng = np.random.default_rng(8)
+    s, r, F, n_p = 40, 12, 3, 4
+    Theta = rng.standard_normal((s, r))
+    cnt = rng.standard_normal(s)
+    scl_f = 1 + rng.random(F)
+    ys = []
+    for p in range(n_p):
+        y = np.zeros((s, 3))
+        y[:, 0] = rng.standard_normal(s)
+        y[:, 2] = rng.integers(0, F, s)
+        if p % 2:
+            y[:, 1] = 0.05 + rng.random(s)
+        ys.append(y)
+    n_points = 7
+    X_cnt = np.zeros((F * n_points, 1))
+    X_scl = np.repeat(scl_f, n_points)[:, None]
+
+    class _C:                                            # C.dot(X_cnt) -> cnt
+        def dot(self, v):
+            return cnt
+    Ar_ref, As_ref = orc.predict_ols(ys, Theta, _C(), X_cnt, X_scl, n_points)
+    Ar, As, y0, info = eng.solve_ols(eng.to_device(Theta), eng.to_device(cnt), eng.to_device(scl_f),
+                                     eng.to_device(np.stack(ys)))
+    np.testing.assert_allclose(eng.to_host(Ar), Ar_ref, rtol=0, atol=1e-10 * np.abs(Ar_ref).max())
+    np.testing.assert_allclose(eng.to_host(As), As_ref, rtol=0, atol=1e-10 * np.abs(As_ref).max())
+    assert not eng.to_host(info)[:, 0].any()
+
+
+def test_general_csr_measurement_matrix(eng):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    n, r, s = 5000, 24, 37
+    U = rng.standard_normal((n, r))
+    mu = rng.standard_normal(n)
+    C = sp.random(s, n, density=0.01, random_state=4, format='csr')
+    t = eng.torch
+    Th, cnt = eng.measure_csr(eng.to_device(C.indptr, dtype=t.int64), eng.to_device(C.indices, dtype=t.int64),
+                              eng.to_device(C.data), eng.to_device(U), 0, eng.to_device(mu))
+    np.testing.assert_allclose(eng.to_host(Th), C @ U, atol=1e-12)
+    np.testing.assert_allclose(eng.to_host(cnt), C @ mu, atol=1e-12)
+
+
+# ---- size-independent properties at a larger size (too big for the oracle's full path in seconds) ----
+def test_properties_at_scale(eng):
+    """1M cells x 4 features x 64 snapshots generated on the device (BASELINE config 2 shape):
+    U_r^T U_r = I, Gram trace identity, reconstruct(Ar[j]) == X[:, j] restricted to the span,
+    and run-to-run determinism of the pivots."""
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    from openmeasure_amd.synth import make_R
+    n_points, F, m, r = 1_000_000, 4, 64, 32
+    R = eng.to_device(make_R(m, r, seed=1234))
+    Xd = eng.synth(n_points * F, m, 0, n_points, R, 1e-3, 1234)
+    spr = SPR(DeviceMatrix(Xd), F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    t = eng.torch
+    Ur = spr._d['Ur']
+    I = eng.to_host(Ur.T @ Ur)                             # torch only as the checker here
+    assert np.abs(I - np.eye(r)).max() < 1e-9
+    assert spr.S_[0] / spr.S_[r - 1] < 1e4                 # designed spectrum
+    # total variance: sum_f trace(G_f)/var_f == n*m - (row-mean part)  <=> sum(S^2) == ||X0||_F^2
+    x0 = (Xd - spr._d['rowmean'][:, None]) * spr._d['inv_scale'].repeat_interleave(n_points)[:, None]
+    assert abs(float((x0 * x0).sum()) - float(np.sum(spr.S_ ** 2))) <= 1e-10 * float(np.sum(spr.S_ ** 2))
+    # projection round trip: Ur Ar^T is the best rank-r approximation of X0 -> residual energy = tail of S
+    rec = spr.reconstruct(spr.Ar[:3], to_host=False)       # (3, n)
+    tail = np.sqrt(np.sum(spr.S_[r:] ** 2))
+    for j in range(3):
+        err = float(t.linalg.norm((rec[j] - Xd[:, j]) / spr._d['scale'].repeat_interleave(n_points)))
+        assert err <= 1.05 * tail
+    spr.optimal_placement()
+    p1 = spr.sensors_.copy()
+    spr.optimal_placement()
+    np.testing.assert_array_equal(p1, spr.sensors_)
+    assert len(set(p1.tolist())) == r and spr.pivot_gap_.min() > 1e-9

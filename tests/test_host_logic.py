@@ -1,0 +1,165 @@
+"""CPU tests of the host half of openmeasure_amd (class surface, validation, Gram-route
+algebra, merges) with the NumPy test-double engine.  The HIP kernels are NOT exercised
+here -- that is tests/test_gpu_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from openmeasure_amd.sparse_sensing import ROM, SPR
+from tests.numpy_engine import NumpyEngine
+from tests.parity import run_fixture
+
+
+def test_fixture_through_host_logic(golden):
+    run_fixture(golden, NumpyEngine())
+
+
+@pytest.fixture
+def small():
+    rng = np.random.default_rng(11)
+    return rng.random((20, 5)), 2, rng.random((10, 3))
+
+
+def test_constructor_errors(small):                    # sparse_sensing.py:69-81
+    X, F, xyz = small
+    with pytest.raises(TypeError):
+        ROM(X.tolist(), F, xyz)
+    with pytest.raises(TypeError):
+        ROM(X, 2.0, xyz)
+    with pytest.raises(Exception):
+        ROM(X, 3, xyz)
+    rom = ROM(X, F, xyz)
+    assert rom.n_points == 10 and rom.X is X           # keeps a reference, no copy (:74)
+
+
+def test_mode_selection_errors(small):                 # :314-333
+    X, F, xyz = small
+    rom = ROM(X, F, xyz, engine=NumpyEngine())
+    with pytest.raises(ValueError):
+        rom.fit(select_modes='variance', n_modes=101)
+    with pytest.raises(TypeError):
+        rom.fit(select_modes='number', n_modes=2.0)
+    with pytest.raises(ValueError):
+        rom.fit(select_modes='number', n_modes=6)
+    with pytest.raises(ValueError):
+        rom.fit(select_modes='bogus')
+    rom.fit(select_modes='number', n_modes=4)
+    assert rom.r == 4
+    rom.fit(select_modes='variance', n_modes=100)
+    assert rom.r == 5
+
+
+def test_unsupported_options_raise_not_fallback(small):
+    X, F, xyz = small
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    with pytest.raises(NotImplementedError):
+        spr.fit(scale_type='pareto')
+    with pytest.raises(NotImplementedError):
+        spr.fit(scale_type='bogus')                    # :164
+    with pytest.raises(NotImplementedError):
+        spr.fit(axis_cnt=None)
+    spr.fit(n_modes=100)
+    with pytest.raises(NotImplementedError):
+        spr.optimal_placement(calc_type='gem')
+    with pytest.raises(NotImplementedError):
+        spr.optimal_placement(calc_type='bogus')       # :752-754
+    with pytest.raises(NotImplementedError):
+        spr.train(np.eye(20), method='COLS')
+    with pytest.raises(NotImplementedError):
+        spr.reconstruct(np.zeros(5), sampling=np.eye(20))
+
+
+def test_train_predict_errors(small):                  # :791-793, :801-803, :848-854
+    X, F, xyz = small
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    spr.fit(select_modes='number', n_modes=3)
+    with pytest.raises(ValueError):
+        spr.train(np.eye(19))
+    with pytest.raises(ValueError):
+        spr.train(np.zeros((4, 2)), is_Theta=True)
+    with pytest.raises(AttributeError):
+        spr.predict(np.zeros((3, 3)))                  # predict before train: no Theta
+    C = spr.optimal_placement()
+    spr.train(C)
+    with pytest.raises(ValueError):
+        spr.predict(np.zeros((4, 3)))
+    with pytest.raises(ValueError):
+        spr.predict(np.zeros((3, 2)))
+    spr.method = 'bogus'
+    with pytest.raises(NotImplementedError):           # :894-896
+        spr.predict(np.zeros((3, 3)))
+    spr2 = SPR(X, F, xyz, engine=NumpyEngine())
+    spr2.fit(select_modes='number', n_modes=3)
+    spr2.train(np.zeros((3, 3)), is_Theta=True)
+    with pytest.raises(AttributeError):                # no C -> scale_vector cannot run (:573)
+        spr2.predict(np.zeros((3, 3)))
+
+
+def test_reference_unit_tests_on_class(small):         # tests/test_rom.py, tests/test_spr.py restated
+    X, F, xyz = small
+    n_points = 10
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    X0 = spr.scale_data()
+    np.testing.assert_allclose(spr.X_cnt, np.mean(X, axis=1)[:, None], rtol=1e-14)
+    scl = np.zeros((20, 1))
+    for f in range(F):
+        scl[f * n_points:(f + 1) * n_points] = np.std(X[f * n_points:(f + 1) * n_points])
+    np.testing.assert_allclose(spr.X_scl, scl, rtol=1e-13)
+    np.testing.assert_allclose(X0, (X - np.mean(X, axis=1)[:, None]) / scl, rtol=1e-12, atol=1e-14)
+    spr.fit(n_modes=100)
+    assert spr.r == 5
+    _, S, Vt = np.linalg.svd(X0, full_matrices=False)
+    np.testing.assert_allclose(spr.Sigma_r[:4], S[:4], rtol=1e-9)
+    np.testing.assert_allclose(np.abs(np.sum(spr.Vr[:, :4] * Vt.T[:, :4], axis=0)), 1.0, rtol=1e-9)
+    np.testing.assert_allclose(spr.unscale_data(X0[:, 0]), X[:, 0])
+    np.testing.assert_allclose(spr.reconstruct(spr.Ar[0, :]), X[:, [0]])            # test_rom.py:82-85
+    Cq = spr.optimal_placement()
+    assert Cq.shape == (5, 20)                                                         # test_spr.py:21-25
+    C = np.eye(20)
+    spr.train(C)
+    y = np.zeros((20, 3))
+    y[:, 0] = C @ X[:, 0]
+    y[n_points:, 2] = 1
+    y0 = spr.scale_vector(y)
+    chk = np.zeros((20, 2))
+    chk[:, 0] = (y[:, 0] - np.mean(X, axis=1)) / scl[:, 0]
+    np.testing.assert_allclose(y0, chk, atol=1e-13)                                    # test_spr.py:27-46
+    a, _ = spr.predict(y)
+    np.testing.assert_allclose(spr.reconstruct(a), X[:, [0]])                          # test_spr.py:48-60
+
+
+def test_decomposition_public(small):
+    X, F, xyz = small
+    rom = ROM(X, F, xyz, engine=NumpyEngine())
+    X0 = rom.scale_data()
+    Ur, Ar, ev = rom.decomposition(X0, select_modes='number', n_modes=4)
+    U, S, Vt = np.linalg.svd(X0, full_matrices=False)
+    assert rom.r == 4 and Ur.shape == (20, 4) and Ar.shape == (5, 4)
+    np.testing.assert_allclose(np.abs(np.sum(Ur * U[:, :4], axis=0)), 1.0, rtol=1e-9)
+    np.testing.assert_allclose(Ur @ Ar.T, (U[:, :4] * S[:4]) @ Vt[:4], atol=1e-10)
+    np.testing.assert_allclose(ev, (100 * np.cumsum(S ** 2) / np.sum(S ** 2))[:4])
+
+
+def test_train_accepts_sparse_and_dense_general_C(small):
+    X, F, xyz = small
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    spr.fit(select_modes='number', n_modes=3)
+    rng = np.random.default_rng(5)
+    C = rng.random((6, 20)) * (rng.random((6, 20)) < 0.3)
+    spr.train(C)
+    np.testing.assert_allclose(spr.Theta, C @ spr.Ur, atol=1e-13)
+    T1 = spr.Theta.copy()
+    spr.train(sp.csr_matrix(C))
+    np.testing.assert_allclose(spr.Theta, T1, atol=1e-15)
+
+
+def test_fit_with_given_basis(small):                  # :493-497
+    X, F, xyz = small
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    spr.fit(select_modes='number', n_modes=3)
+    Ur, Ar = spr.Ur.copy(), spr.Ar.copy()
+    spr2 = SPR(X, F, xyz, engine=NumpyEngine())
+    spr2.fit(basis=(Ur, Ar))
+    assert spr2.r == 3
+    np.testing.assert_allclose(spr2.Sigma_r, spr.Sigma_r)
+    np.testing.assert_allclose(spr2.reconstruct(Ar[1]), spr.reconstruct(Ar[1]))

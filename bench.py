@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""SPR fit+reconstruct throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|...]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path over a synthetic snapshot shard that already sits in
+HBM:   SPR.fit(select_modes='number', n_modes=s)  +  SPR.reconstruct(a)  (one vector).
+value = bytes of the snapshot matrix (all ranks) / max-over-ranks wall time of K steps.
+Weak scaling: every rank holds one workload-sized shard, the global matrix has N times the
+cells; per step there is one RCCL all-reduce (per-feature Gram) and one all-gather (field).
+
+The JSON line also carries
+  roofline      the dominant kernel (the fused stats+Gram pass), timed live with HIP events on
+                its launch stream; algorithmic flops/bytes per launch from SURVEY.md 8(d);
+  cpu_baseline  the NumPy/LAPACK oracle (oracle/spr_oracle.py) timed on this host's cores on a
+                bounded sample of the same workload (rank 0, N=1 only);
+  phases, parity  extra evidence (per-kernel ms, GPU-vs-oracle agreement on the sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# BASELINE.json configs (cells, features, snapshots, sensors); c1 is the reference's own
+# CPU-sized case, c2/c3 the single-GPU cases, c3 the one the north_star target is quoted on.
+WORKLOADS = {
+    'c1': dict(cells=18_362, features=9, m=41, s=14, cpu_cells=18_362),
+    'c2': dict(cells=1_000_000, features=4, m=64, s=32, cpu_cells=250_000),
+    'c3': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=12_000),
+    'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=12_000),   # c3 at 1/10 of the rows
+}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F64_PEAK_TF = 78.6     # AMD public spec for MI355X FP64 matrix; tools/mfma_probe measures 73.6 on the box
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default=os.environ.get('SPR_BENCH_WORKLOAD', 'c2'), choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline / parity leg')
+    ap.add_argument('--extra', action='store_true', help='also time placement/train/predict')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from openmeasure_amd.engine import HipEngine
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix, RowShard
+    from openmeasure_amd.synth import make_R
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        log(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+
+    wl = WORKLOADS[args.workload]
+    F, m, s = wl['features'], wl['m'], wl['s']
+    cells_loc = wl['cells']                       # cells added per rank (weak scaling)
+    n_points = cells_loc * world                  # global cells
+    n_glob = n_points * F
+    n_loc = cells_loc * F                         # rows per rank: contiguous block of the global matrix
+    row0 = rank * n_loc
+    seed, eps = 1234, 1e-3
+
+    eng = HipEngine(f'cuda:{local_rank}')
+    R = eng.to_device(make_R(m, s, seed=seed))
+    t0 = time.time()
+    Xd = eng.synth(n_loc, m, row0, n_points, R, eps, seed)
+    torch.cuda.synchronize()
+    log(f'[rank {rank}] generated {n_loc} x {m} f64 shard ({n_loc * m * 8 / 1e9:.2f} GB) in {time.time() - t0:.2f}s')
+
+    shard = RowShard(row0, n_glob) if world > 1 else None
+    spr = SPR(DeviceMatrix(Xd), F, None, shard=shard, engine=eng)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    spr.fit(select_modes='number', n_modes=s)     # first call: allocations, RCCL warm-up
+    a_d = eng.to_device(spr.Ar[:1].copy())        # (1, r) coefficient vector, resident
+
+    def step(timers=None):
+        if timers is not None:
+            timers.append((eng.time_next('stats_gram'), eng.time_next('project'), eng.time_next('reconstruct')))
+        spr.fit(select_modes='number', n_modes=s)
+        return spr.reconstruct(a_d, to_host=False)
+
+    for _ in range(args.warmup):
+        step()
+    timers = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        field = step(timers)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = 1e3 * dt / args.steps
+    x_bytes = float(n_glob) * m * 8
+    value = x_bytes / (dt / args.steps) / 1e9
+
+    k_ms = {k: float(np.mean([tm[i][0].elapsed_time(tm[i][1]) for tm in timers]))
+            for i, k in enumerate(('stats_gram', 'project', 'reconstruct'))}
+    r = spr.r
+    # per-launch algorithmic work of each kernel on THIS rank's shard
+    alg = {
+        'stats_gram': dict(bytes=n_loc * m * 8 + n_loc * 8, flops=float(n_loc) * m * m),
+        'project': dict(bytes=n_loc * m * 8 + n_loc * r * 8, flops=2.0 * n_loc * m * r),
+        'reconstruct': dict(bytes=n_loc * r * 8 + 2 * n_loc * 8, flops=2.0 * n_loc * r),
+    }
+    phases = {k: dict(ms=round(k_ms[k], 4), GBs=round(alg[k]['bytes'] / k_ms[k] / 1e6, 1),
+                      TFLOPs=round(alg[k]['flops'] / k_ms[k] / 1e9, 3)) for k in k_ms}
+    dom = max(k_ms, key=k_ms.get)
+    t_bytes = alg[dom]['bytes'] / (HBM_PEAK_GBS * 1e9)
+    t_flops = alg[dom]['flops'] / (MFMA_F64_PEAK_TF * 1e12)
+    if t_flops > t_bytes:
+        roof = dict(kernel=dom, bound='mfma', achieved=round(alg[dom]['flops'] / k_ms[dom] / 1e9, 3),
+                    peak=MFMA_F64_PEAK_TF, unit='TFLOP/s')
+    else:
+        roof = dict(kernel=dom, bound='hbm', achieved=round(alg[dom]['bytes'] / k_ms[dom] / 1e6, 1),
+                    peak=HBM_PEAK_GBS, unit='GB/s')
+    roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+    roof['traffic'] = None                           # PMC pass: profiles/ (separate rocprofv3 --pmc runs)
+    roof['ms'] = round(k_ms[dom], 4)
+    # whole-step algorithmic bytes: (2m + 2r + 1) n B + 16 n
+    step_bytes = (2 * m + 2 * r + 1) * float(n_glob) * 8 + 16.0 * n_glob
+    hbm_frac = step_bytes / (dt / args.steps) / (world * HBM_PEAK_GBS * 1e9)
+
+    extra = {}
+    if args.extra:
+        barrier(); t1 = time.perf_counter()
+        spr.optimal_placement()
+        barrier(); t2 = time.perf_counter()
+        spr.train(spr._placed[0])
+        rows = eng.to_device(spr.sensors_, dtype=torch.int64)
+        yv = eng.to_host(eng.synth_gather(rows, n_points, m, R, eps, seed))
+        y = np.zeros((s, 3)); y[:, 0] = yv; y[:, 2] = spr.sensors_ // n_points
+        barrier(); t3 = time.perf_counter()
+        a, _ = spr.predict(y)
+        barrier(); t4 = time.perf_counter()
+        extra = dict(optimal_placement_ms=round(1e3 * (t2 - t1), 3), train_ms=round(1e3 * (t3 - t2), 3),
+                     predict_ms=round(1e3 * (t4 - t3), 3), min_pivot_gap=float(spr.pivot_gap_.min()))
+
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import spr_oracle as orc
+        cc = min(wl['cpu_cells'], cells_loc)
+        idx = torch.cat([torch.arange(f * n_points, f * n_points + cc, device=eng.device) for f in range(F)])
+        Xs = eng.to_host(Xd[idx])                   # first cc cells of every feature: a valid (cc*F) x m problem
+        t1 = time.perf_counter()
+        xr_cpu, st_cpu = orc.fit_reconstruct_timed(Xs, F, s)
+        t_cpu = time.perf_counter() - t1
+        try:
+            import threadpoolctl
+            cores = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+        except Exception:
+            cores = os.cpu_count()
+        cpu = dict(value=round(Xs.nbytes / t_cpu / 1e9, 4), unit='GB/s', cores=int(cores), kind='port',
+                   sample=f'{cc} cells x {F} features x {m} snapshots ({Xs.nbytes / 1e6:.0f} MB), s={s}: '
+                          f'oracle fit+reconstruct {t_cpu:.2f} s (same generator, first {cc} cells per feature)')
+        # parity on the same sample: GPU path vs oracle
+        sp2 = SPR(Xs, F, None, engine=eng)
+        sp2.fit(select_modes='number', n_modes=s)
+        xr_gpu = sp2.reconstruct(st_cpu['Ar'][0])   # same coefficients need the same sign convention:
+        sg = np.sign(np.sum(sp2.Ur * st_cpu['Ur'], axis=0))
+        xr_gpu = sp2.reconstruct(st_cpu['Ar'][0] * sg)
+        sp2.optimal_placement()
+        piv_cpu, _ = orc.qr_pivots(st_cpu['Ur'])
+        parity = dict(sensors_equal=bool(np.array_equal(sp2.sensors_, piv_cpu)),
+                      field_rel_fro=float(np.linalg.norm(xr_gpu - xr_cpu) / np.linalg.norm(xr_cpu)),
+                      sigma_rel=float(np.max(np.abs(sp2.Sigma_r - st_cpu['Sigma_r']) / st_cpu['Sigma_r'])),
+                      sigma1_over_sigmas=float(sp2.Sigma_r[0] / sp2.Sigma_r[-1]))
+
+    if rank == 0:
+        out = {
+            'metric': 'SPR fit+reconstruct throughput (GB/s snapshot matrix)', 'value': round(value, 2),
+            'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f"{args.workload}: {cells_loc} cells/GPU x {F} features x {m} snapshots, "
+                                   f"{s} modes/sensors, f64, rows sharded over {world} GPU(s)",
+                       'rows_per_gpu': n_loc, 'snapshot_GB_per_gpu': round(n_loc * m * 8 / 1e9, 3)},
+            'hbm_roofline_frac_step': round(hbm_frac, 4),
+            'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
+        }
+        if extra:
+            out['extra'] = extra
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -49,10 +49,13 @@ int spr_device_cus(int *out_cus);
 /* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
  * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised
  * X0 = (X - X_cnt)/X_scl (:169) and the X0^T X0 half of np.linalg.svd (:272).
- * One read of X.  For every local row i: d_rowmean[i] = mean_j X[i,j].  For every
- * feature f (0..n_features-1), over the LOCAL rows of f:
- *   d_fstats[3f..3f+2] = (count, mean, M2) of the row means (Welford/Chan form),
- *   d_gram[f*m*m ..]   = sum_i (x_i - mean_i)(x_i - mean_i)^T            (m x m, full).
+ * Two calls on the same stream and workspace:
+ *   spr_stats_gram_f64           the one read of X: d_rowmean[i] = mean_j X[i,j] for every
+ *                                local row, per-workgroup Gram / Welford partials -> workspace;
+ *   spr_stats_gram_finalize_f64  fixed-order reduction of the partials (bitwise reproducible,
+ *                                no float atomics).  For every feature f over its LOCAL rows:
+ *     d_fstats[3f..3f+2] = (count, mean, M2) of the row means (Welford/Chan form),
+ *     d_gram[f*m*m ..]   = sum_i (x_i - mean_i)(x_i - mean_i)^T          (m x m, full).
  * The caller combines: var_f = (trace(G_f) + m*M2_f) / (count_f*m) -> X_scl; G = sum_f G_f/var_f.
  * Across ranks d_gram is summed (all-reduce) and d_fstats Chan-merged.
  * center = 1: as above.  center = 0: rows are taken as they are (d_rowmean is written as
@@ -61,8 +64,10 @@ int spr_device_cus(int *out_cus);
 size_t spr_stats_gram_workspace(int32_t m, int32_t n_features);
 int spr_stats_gram_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx,
                        int64_t row0, int64_t n_points, int32_t n_features, int32_t center,
-                       double *d_rowmean, double *d_fstats, double *d_gram,
-                       void *d_workspace, size_t workspace_bytes, void *stream);
+                       double *d_rowmean, void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_stats_gram_finalize_f64(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points,
+                                int32_t n_features, const void *d_workspace, size_t workspace_bytes,
+                                double *d_fstats, double *d_gram, void *stream);
 
 /* ---- K4 : basis projection  Ur = X0 . W,  W = V_r Sigma_r^-1 (m x r) ----------------
  * Replaces the U factor of np.linalg.svd (:272) and the truncation U[:, :r] (:336).

@@ -219,9 +219,7 @@ size_t workspace_bytes(int32_t n_features) {
 
 template <int MT>
 int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
-           int32_t n_features, int center, double *rowmean, double *fstats, double *gram, void *ws, size_t ws_bytes,
-           hipStream_t st) {
-  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, NW>;
+           int32_t n_features, int center, double *rowmean, void *ws, size_t ws_bytes, hipStream_t st) {
   SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
               "spr_stats_gram_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
   SegPlan plan = make_plan<MT>(n_rows, row0, n_points, n_features);
@@ -234,6 +232,19 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   hipLaunchKernelGGL(stats_gram_kernel<MT>, dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, vec_ok, center, plan,
                      rowmean, stat_part, slab);
   SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+template <int MT>
+int launch_finalize(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points, int32_t n_features,
+                    double *fstats, double *gram, const void *ws, size_t ws_bytes, hipStream_t st) {
+  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, NW>;
+  SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
+              "spr_stats_gram_finalize_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
+  SegPlan plan = make_plan<MT>(n_rows, row0, n_points, n_features);
+  const int64_t max_grid = (int64_t)occupancy_wgs<MT>() + n_features;
+  const double *slab = static_cast<const double *>(ws);
+  const double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
   hipLaunchKernelGGL(gram_finalize_kernel<MT>, dim3(GramShape<MT>::T, n_features), dim3(256), 0, st, slab,
                      stat_part, (int)m, plan, (int)RT::ROWS_PER_IT, gram, fstats);
   SPR_LAUNCH_CHECK();
@@ -279,16 +290,30 @@ extern "C" size_t spr_stats_gram_workspace(int32_t m, int32_t n_features) {
 
 extern "C" int spr_stats_gram_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                                   int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
-                                  double *d_fstats, double *d_gram, void *d_workspace, size_t workspace_bytes_, void *stream) {
+                                  void *d_workspace, size_t workspace_bytes_, void *stream) {
   int rc = check_args("spr_stats_gram_f64", d_X, n_rows, m, ldx, row0, n_points, n_features);
   if (rc != SPR_OK) return rc;
-  SPR_REQUIRE(d_rowmean && d_fstats && d_gram && d_workspace, SPR_E_INVALID,
-              "spr_stats_gram_f64: NULL output/workspace");
+  SPR_REQUIRE(d_rowmean && d_workspace, SPR_E_INVALID, "spr_stats_gram_f64: NULL output/workspace");
   rc = SPR_E_UNSUPPORTED;
-#define RUN_CALL(MTV)                                                                                   \
-  rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_fstats, d_gram,       \
-                   d_workspace, workspace_bytes_, static_cast<hipStream_t>(stream))
+#define RUN_CALL(MTV)                                                                                \
+  rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_workspace, \
+                   workspace_bytes_, static_cast<hipStream_t>(stream))
   SPR_DISPATCH_MT(spr_round_mt(m), RUN_CALL)
 #undef RUN_CALL
+  return rc;
+}
+
+extern "C" int spr_stats_gram_finalize_f64(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points,
+                                           int32_t n_features, const void *d_workspace, size_t workspace_bytes_,
+                                           double *d_fstats, double *d_gram, void *stream) {
+  int rc = check_args("spr_stats_gram_finalize_f64", d_workspace, n_rows, m, m, row0, n_points, n_features);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_fstats && d_gram, SPR_E_INVALID, "spr_stats_gram_finalize_f64: NULL output");
+  rc = SPR_E_UNSUPPORTED;
+#define FIN_CALL(MTV)                                                                                 \
+  rc = launch_finalize<MTV>(n_rows, m, row0, n_points, n_features, d_fstats, d_gram, d_workspace,    \
+                            workspace_bytes_, static_cast<hipStream_t>(stream))
+  SPR_DISPATCH_MT(spr_round_mt(m), FIN_CALL)
+#undef FIN_CALL
   return rc;
 }

@@ -34,6 +34,7 @@ class HipEngine:
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         self._ws = {}
+        self._timing = {}
 
     # ---- plumbing ---------------------------------------------------------------------
     def _stream(self):
@@ -69,6 +70,21 @@ class HipEngine:
             raise TypeError('device snapshot matrix must be a 2-D float64 CUDA tensor with unit column stride')
         return X.shape[0], X.shape[1], X.stride(0)
 
+    def time_next(self, kernel):
+        """Bracket the next launch of `kernel` ('stats_gram' | 'project' | 'reconstruct') with a pair of
+        timing events on the launch stream; returns (start, stop) torch events to read after a sync."""
+        t = self.torch
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        self._timing[kernel] = (e0, e1)
+        return e0, e1
+
+    def _timed(self, kernel):
+        ev = self._timing.pop(kernel, None)
+        if ev is None:
+            return (lambda: None), (lambda: None)
+        st = self.torch.cuda.current_stream(self.device)
+        return (lambda: ev[0].record(st)), (lambda: ev[1].record(st))
+
     # ---- K1 + K3a ------------------------------------------------------------------------
     def stats_gram(self, X, row0, n_points, n_features, center=True):
         """-> rowmean (n,), fstats (F,3) = (count, mean, M2) of the local row means,
@@ -81,22 +97,36 @@ class HipEngine:
         if nbytes == 0:
             raise NotImplementedError(f'stats_gram: m={m} outside the built range (1..{_lib.SPR_MAX_M})')
         ws = self._workspace('gram', nbytes)
+        tic, toc = self._timed('stats_gram')
+        tic()
         _lib.check(self.lib.spr_stats_gram_f64(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
-                                               _ptr(rowmean), _ptr(fstats), _ptr(gram), _ptr(ws), ws.numel(),
-                                               self._stream()), 'spr_stats_gram_f64')
+                                               _ptr(rowmean), _ptr(ws), ws.numel(), self._stream()),
+                   'spr_stats_gram_f64')
+        toc()
+        _lib.check(self.lib.spr_stats_gram_finalize_f64(n, m, row0, n_points, n_features, _ptr(ws), ws.numel(),
+                                                        _ptr(fstats), _ptr(gram), self._stream()),
+                   'spr_stats_gram_finalize_f64')
         return rowmean, fstats, gram
 
     # ---- K4 --------------------------------------------------------------------------------
-    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True):
-        """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even."""
+    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None):
+        """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even.
+        ``out``: a previous result of the same shape to overwrite (keeps one basis buffer alive)."""
         n, m, ld = self._check_matrix(X)
         r = W.shape[1]
         ldu = r + (r & 1)
-        buf = self.empty((n, ldu))
+        if out is not None and tuple(out.shape) == (n, r) and out.stride(0) == ldu and out.stride(1) == 1:
+            buf = out
+        else:
+            del out
+            buf = self.empty((n, ldu))
+        tic, toc = self._timed('project')
+        tic()
         _lib.check(self.lib.spr_project_f64(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
                                             _ptr(inv_scale), _ptr(W.contiguous()), r, _ptr(buf), ldu,
                                             self._stream()), 'spr_project_f64')
-        return buf[:, :r]
+        toc()
+        return buf[:, :r] if buf.shape[1] != r else buf
 
     # ---- K2 / K11 stand-alone ---------------------------------------------------------------
     def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
@@ -121,9 +151,12 @@ class HipEngine:
         n_p = A.shape[0]
         if out is None:
             out = self.empty((n_p, n))
+        tic, toc = self._timed('reconstruct')
+        tic()
         _lib.check(self.lib.spr_reconstruct_f64(_ptr(Ur), n, r, ldu, row0, n_points, n_features, _ptr(rowmean),
                                                 _ptr(scale), _ptr(A.contiguous()), n_p, _ptr(out), out.stride(0),
                                                 self._stream()), 'spr_reconstruct_f64')
+        toc()
         return out
 
     # ---- K6 ----------------------------------------------------------------------------------

@@ -301,7 +301,7 @@ class ROM:
         S_safe = np.maximum(S[:r], floor if floor > 0 else 1.0)
         W = V[:, :r] / S_safe
         Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, eng.to_device(W),
-                           center=center)
+                           center=center, out=self._d.pop('Ur', None))
         Ar = V[:, :r] * S[:r]                                # A = (diag(S) Vt).T  (:273)
         return Ur_d, Ar, exp_variance[:r], S, r
 

@@ -108,7 +108,31 @@ __device__ inline bool seg_locate(const SegPlan &p, int b, int &f, int &wl, int 
 }
 
 // ---- small device utilities ------------------------------------------------------------
-__device__ inline double group_sum(double v, int width) {  // butterfly over `width` lanes
+// Butterfly sum over aligned groups of `width` lanes; every lane of a group ends with the
+// same bits (each step adds the same two partial sums in both partners).  The four steps
+// inside a 16-lane row are DPP moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror):
+// VALU speed, no LDS crossbar; only the 16<->32 and 32<->64 exchanges use ds_bpermute.
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  union { double d; int i[2]; } a, b;
+  a.d = v;
+  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
+  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
+  return b.d;
+}
+
+template <int WIDTH>
+__device__ inline double group_sum_t(double v) {
+  if (WIDTH >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (WIDTH >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (WIDTH >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+  if (WIDTH >= 16) v += dpp_f64<0x140>(v);  // row_mirror
+  if (WIDTH >= 32) v += __shfl_xor(v, 16, 64);
+  if (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__device__ inline double group_sum(double v, int width) {  // run-time width (cold paths)
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
     for (int j = 0; j < QR_UNR; ++j) {
       const int64_t row = rbase + j * RPW;
       double d = (MODE == 0) ? (u[j].x * u[j].x + u[j].y * u[j].y) : (u[j].x * q0 + u[j].y * q1);
-      d = group_sum(d, LPR);
+      d = group_sum_t<LPR>(d);
       if (lig == 0 && row < n_rows) {
         double v;
         if (MODE == 0) {

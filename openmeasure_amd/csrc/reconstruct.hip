@@ -64,7 +64,7 @@ __global__ __launch_bounds__(RC_THREADS) void reconstruct_kernel(
       for (int p = 0; p < RC_PB; ++p) {
         if (p < npb) {
           double d = u[j].x * a0[p] + u[j].y * a1[p];
-          d = group_sum(d, LPR);
+          d = group_sum_t<LPR>(d);
           if (lig == 0 && row < hi) out[(int64_t)(np0 + p) * ldo + row] = sc * d + mu;
         }
       }

@@ -12,14 +12,22 @@
 #pragma once
 #include "common.hpp"
 
-struct RowStats {  // Welford state of the row means seen by one lane group
-  double cnt, mean, m2;
-  __device__ inline void init() { cnt = 0.0; mean = 0.0; m2 = 0.0; }
+struct RowStats {  // running statistics of the row means seen by one lane group
+  // Shifted sums: d = x - ref with ref = the first row mean seen, so no division sits in the
+  // streaming loop; converted to the (count, mean, M2) form that Chan's merge wants at the end.
+  double cnt, ref, s1, s2;
+  __device__ inline void init() { cnt = 0.0; ref = 0.0; s1 = 0.0; s2 = 0.0; }
   __device__ inline void push(double x) {
+    ref = (cnt == 0.0) ? x : ref;
+    const double d = x - ref;
     cnt += 1.0;
-    double d = x - mean;
-    mean += d / cnt;
-    m2 += d * (x - mean);
+    s1 += d;
+    s2 += d * d;
+  }
+  __device__ inline double mean() const { return cnt > 0.0 ? ref + s1 / cnt : 0.0; }
+  __device__ inline double m2() const {
+    const double v = cnt > 0.0 ? s2 - s1 * s1 / cnt : 0.0;
+    return v > 0.0 ? v : 0.0;
   }
 };
 
@@ -67,7 +75,7 @@ struct RowTile {
                                       int wave, int lane, double *__restrict__ rowmean,
                                       RowStats *st) {
     const int grp = lane / LPR, lig = lane % LPR;
-    const double dm = (double)m;
+    const double inv_m = 1.0 / (double)m;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
@@ -76,8 +84,8 @@ struct RowTile {
       double s = 0.0;
 #pragma unroll
       for (int v = 0; v < VPL; ++v) s += pre[it][v].x + pre[it][v].y;
-      s = group_sum(s, LPR);
-      const double mean = center ? s / dm : 0.0;
+      s = group_sum_t<LPR>(s);
+      const double mean = center ? s * inv_m : 0.0;
       if (WRITE_MEAN && rv) {
         if (lig == 0) rowmean[lrow] = mean;
         st->push(mean);

@@ -17,75 +17,64 @@
 
 namespace {
 
-constexpr int NW = 8;  // waves per workgroup
-
 template <int MT>
 struct GramShape {
   static constexpr int MPAD = 16 * MT;
   static constexpr int MP = MPAD + ((MT % 2 == 0) ? 16 : 0);
   static constexpr int T = MT * (MT + 1) / 2;
+  static constexpr int NU = (MT + 1) / 2;  // wave "units": tile rows u and MT-1-u together
 };
 
-// tile-group x k-slice split of the 8 waves and the panel height, per padded width
+// waves per workgroup, k slices and panel height per padded width (NW = NU * KS)
 template <int MT> struct GramCfg;
-template <> struct GramCfg<1>  { static constexpr int R = 64, TG = 1, KS = 8; };
-template <> struct GramCfg<2>  { static constexpr int R = 64, TG = 1, KS = 8; };
-template <> struct GramCfg<3>  { static constexpr int R = 64, TG = 1, KS = 8; };
-template <> struct GramCfg<4>  { static constexpr int R = 64, TG = 2, KS = 4; };
-template <> struct GramCfg<6>  { static constexpr int R = 32, TG = 4, KS = 2; };
-template <> struct GramCfg<8>  { static constexpr int R = 32, TG = 4, KS = 2; };
-template <> struct GramCfg<12> { static constexpr int R = 32, TG = 8, KS = 1; };
-template <> struct GramCfg<16> { static constexpr int R = 32, TG = 8, KS = 1; };
+template <> struct GramCfg<1>  { static constexpr int NW = 8,  R = 64, KS = 8; static constexpr bool DBUF = true; };
+template <> struct GramCfg<2>  { static constexpr int NW = 8,  R = 32, KS = 8; static constexpr bool DBUF = true; };
+template <> struct GramCfg<3>  { static constexpr int NW = 8,  R = 64, KS = 4; static constexpr bool DBUF = true; };
+template <> struct GramCfg<4>  { static constexpr int NW = 8,  R = 32, KS = 4; static constexpr bool DBUF = true; };
+template <> struct GramCfg<6>  { static constexpr int NW = 12, R = 48, KS = 4; static constexpr bool DBUF = true; };
+template <> struct GramCfg<8>  { static constexpr int NW = 8,  R = 32, KS = 2; static constexpr bool DBUF = true; };
+template <> struct GramCfg<12> { static constexpr int NW = 12, R = 24, KS = 2; static constexpr bool DBUF = false; };
+template <> struct GramCfg<16> { static constexpr int NW = 8,  R = 32, KS = 1; static constexpr bool DBUF = true; };
 
-// linear index over the upper triangle (row-major) -> tile row / column
+// linear index over the upper triangle (row-major) <-> tile row / column
+constexpr int tri_index(int mt, int ti, int tj) { return ti * mt - ti * (ti - 1) / 2 + (tj - ti); }
+
 template <int MT>
 __device__ inline void tile_coords(int idx, int &ti, int &tj) {
   ti = 0;
   while (ti < MT - 1 && idx >= MT - ti) { idx -= MT - ti; ++ti; }
   tj = ti + idx;
-  if (tj > MT - 1) tj = MT - 1;  // surplus slots of the last wave: harmless duplicate
+  if (tj > MT - 1) tj = MT - 1;
 }
 
-template <int MT>
-__global__ __launch_bounds__(NW * 64) void stats_gram_kernel(
-    const double *__restrict__ X, int64_t ldx, int m, int vec_ok_i, int center_i, SegPlan plan,
-    double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab) {
+// The whole life of one wave: unit U owns tile rows RA = U (tiles (RA, RA..MT-1)) and, when
+// different, RB = MT-1-U (tiles (RB, RB..MT-1)) -- MT+1 tiles for every unit, so the eight
+// waves of the m = 256 case are perfectly balanced (17 tiles each).  Per k step the wave
+// reads the MT-RA operand fragments of column blocks RA..MT-1 once (every fragment is both
+// an A and a B operand) and issues its MFMAs from registers; the fragments of step k+1 are
+// requested before the MFMAs of step k so LDS latency hides behind the 64-cycle MFMAs.
+template <int MT, int U>
+__device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int m, bool vec_ok, bool center,
+                                 int64_t lo, int64_t hi, int wl, int wpf, int ks, int wave, int lane,
+                                 double *__restrict__ lds0, double *__restrict__ lds1,
+                                 double *__restrict__ rowmean, double *__restrict__ stat_part,
+                                 double *__restrict__ slab) {
   using S = GramShape<MT>;
   using C = GramCfg<MT>;
-  constexpr int R = C::R, TG = C::TG, KS = C::KS, MP = S::MP, T = S::T;
-  constexpr int TPW = (T + TG - 1) / TG;
-  constexpr int KROWS = R / KS;
-  static_assert(TG * KS == NW, "waves = tile groups x k slices");
+  constexpr int R = C::R, KS = C::KS, NW = C::NW, MP = S::MP, T = S::T;
+  constexpr int KROWS = R / KS, KSTEPS = KROWS / 4;
+  constexpr int RA = U, RB = MT - 1 - U;
+  constexpr int NA = MT - RA;                 // tiles in row RA == operand fragments per k step
+  constexpr int NB = (RB != RA) ? MT - RB : 0;
   static_assert(KROWS % 4 == 0, "k slice must be a multiple of the MFMA depth");
   using RT = RowTile<MT, R, MP, NW>;
 
-  __shared__ double lds[2][R * MP];
-
-  int f, wl, wpf, base;
-  int64_t lo, hi;
-  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tg = wave % TG, ks = wave / TG;
-  const bool vec_ok = vec_ok_i != 0;
-
-  // tiles of this wave: linear upper-triangle index -> (ti, tj)
-  int offA[TPW], offB[TPW];
-  int nt = T - tg * TPW;
-  if (nt > TPW) nt = TPW;
-  if (nt < 0) nt = 0;
+  f64x4 accA[NA];
+  f64x4 accB[NB > 0 ? NB : 1];
 #pragma unroll
-  for (int u = 0; u < TPW; ++u) {
-    int ti, tj;
-    tile_coords<MT>(tg * TPW + u, ti, tj);
-    offA[u] = ti * 16;
-    offB[u] = tj * 16;
-  }
-
-  f64x4 acc[TPW];
+  for (int j = 0; j < NA; ++j) accA[j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int u = 0; u < TPW; ++u) acc[u] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int j = 0; j < NB; ++j) accB[j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
   RowStats st;
   st.init();
@@ -95,22 +84,43 @@ __global__ __launch_bounds__(NW * 64) void stats_gram_kernel(
   int64_t c = wl;
   if (c < nchunks) tile.load(X, ldx, m, vec_ok, lo + c * R, hi, wave, lane);
   int buf = 0;
-  const int frag = (lane >> 4) * MP + (lane & 15);
+  const int frag = (lane >> 4) * MP + (lane & 15) + ks * KROWS * MP + RA * 16;
   while (c < nchunks) {
-    tile.template center_store<true>(lds[buf], m, center_i != 0, lo + c * R, hi, wave, lane, rowmean, &st);
+    double *cur = buf ? lds1 : lds0;
+    tile.template center_store<true>(cur, m, center, lo + c * R, hi, wave, lane, rowmean, &st);
     const int64_t cn = c + wpf;
     if (cn < nchunks) tile.load(X, ldx, m, vec_ok, lo + cn * R, hi, wave, lane);
     __syncthreads();
-    const double *p = lds[buf] + frag + ks * KROWS * MP;
-#pragma unroll 1
-    for (int k0 = 0; k0 < KROWS; k0 += 4) {
+    const double *p = cur + frag;
+    if constexpr (C::DBUF) {
+      double op[2][NA];
 #pragma unroll
-      for (int u = 0; u < TPW; ++u) {
-        if (u < nt) {
-          const double a = p[k0 * MP + offA[u]];
-          const double b = p[k0 * MP + offB[u]];
-          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+      for (int j = 0; j < NA; ++j) op[0][j] = p[16 * j];
+#pragma unroll
+      for (int k = 0; k < KSTEPS; ++k) {
+        if (k + 1 < KSTEPS) {
+#pragma unroll
+          for (int j = 0; j < NA; ++j) op[(k + 1) & 1][j] = p[(k + 1) * 4 * MP + 16 * j];
         }
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+          accA[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[k & 1][0], op[k & 1][j], accA[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          accB[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[k & 1][RB - RA], op[k & 1][RB - RA + j], accB[j], 0, 0, 0);
+      }
+    } else {  // register-tight shapes: one operand set, three waves per SIMD cover the LDS latency
+#pragma unroll 1
+      for (int k = 0; k < KSTEPS; ++k) {
+        double op[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) op[j] = p[k * 4 * MP + 16 * j];
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+          accA[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[0], op[j], accA[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          accB[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[RB - RA], op[RB - RA + j], accB[j], 0, 0, 0);
       }
     }
     buf ^= 1;
@@ -118,30 +128,74 @@ __global__ __launch_bounds__(NW * 64) void stats_gram_kernel(
   }
 
   // tiles -> slab[(block*KS + ks)][tile][reg][lane]
-  {
-    double *sp = slab + ((int64_t)blockIdx.x * KS + ks) * T * 256;
+  double *sp = slab + ((int64_t)blockIdx.x * KS + ks) * T * 256 + lane;
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-      if (u < nt) {
-        double *tp = sp + (int64_t)(tg * TPW + u) * 256 + lane;
-        tp[0] = acc[u].x; tp[64] = acc[u].y; tp[128] = acc[u].z; tp[192] = acc[u].w;
-      }
-    }
+  for (int j = 0; j < NA; ++j) {
+    double *tp = sp + (int64_t)tri_index(MT, RA, RA + j) * 256;
+    tp[0] = accA[j].x; tp[64] = accA[j].y; tp[128] = accA[j].z; tp[192] = accA[j].w;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double *tp = sp + (int64_t)tri_index(MT, RB, RB + j) * 256;
+    tp[0] = accB[j].x; tp[64] = accB[j].y; tp[128] = accB[j].z; tp[192] = accB[j].w;
   }
   // Welford partials: one slot per lane group
   if ((lane % RT::LPR) == 0) {
     double *q = stat_part + ((int64_t)blockIdx.x * RT::ROWS_PER_IT + wave * RT::RPW + lane / RT::LPR) * 3;
-    q[0] = st.cnt; q[1] = st.mean; q[2] = st.m2;
+    q[0] = st.cnt; q[1] = st.mean(); q[2] = st.m2();
   }
 }
 
-// grid (T, n_features), 256 threads: fixed-order sum of the slabs of feature f for one tile
 template <int MT>
-__global__ __launch_bounds__(256) void gram_finalize_kernel(
+__global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
+    const double *__restrict__ X, int64_t ldx, int m, int vec_ok_i, int center_i, SegPlan plan,
+    double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab) {
+  using S = GramShape<MT>;
+  using C = GramCfg<MT>;
+  constexpr int NU = S::NU;
+  static_assert(NU * C::KS == C::NW, "waves = units x k slices");
+  __shared__ double lds[2][C::R * S::MP];
+
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int unit = wave % NU, ks = wave / NU;
+#define GRAM_UNIT(UV)                                                                                        \
+  case UV:                                                                                                   \
+    if constexpr (UV < NU)                                                                                   \
+      gram_wave<MT, UV>(X, ldx, m, vec_ok_i != 0, center_i != 0, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
+                        lds[1], rowmean, stat_part, slab);                                                   \
+    break;
+  switch (unit) {
+    GRAM_UNIT(0) GRAM_UNIT(1) GRAM_UNIT(2) GRAM_UNIT(3) GRAM_UNIT(4) GRAM_UNIT(5) GRAM_UNIT(6) GRAM_UNIT(7)
+    default: break;
+  }
+#undef GRAM_UNIT
+}
+
+__device__ inline void chan_merge(double &n, double &mu, double &m2, double nb, double mb, double sb) {
+  if (nb > 0.0) {
+    const double tot = n + nb, d = mb - mu;
+    mu += d * nb / tot;
+    m2 += sb + d * d * n * nb / tot;
+    n = tot;
+  }
+}
+
+// grid (T, n_features), 1024 threads: fixed-order sum of the slabs of feature f for one tile.
+// Thread (g, e) adds the partials p = g, g+4, ... of tile element e (four independent load
+// streams per thread); the four group sums are then added in group order through LDS, so
+// the result does not depend on scheduling.
+template <int MT>
+__global__ __launch_bounds__(1024) void gram_finalize_kernel(
     const double *__restrict__ slab, const double *__restrict__ stat_part, int m, SegPlan plan,
     int slots_per_wg, double *__restrict__ gram, double *__restrict__ fstats) {
   constexpr int T = GramShape<MT>::T;
   constexpr int KS = GramCfg<MT>::KS;
+  __shared__ double red[4][256];
   const int f = blockIdx.y;
   const int tile = blockIdx.x;
   // blocks of feature f
@@ -159,30 +213,50 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(
   }
   int ti, tj;
   tile_coords<MT>(tile, ti, tj);
-  const int e = threadIdx.x;
-  double sum = 0.0;
+  const int e = threadIdx.x & 255, g = threadIdx.x >> 8;
+  const int np = wpf * KS;
   const double *sp = slab + ((int64_t)base * KS * T + tile) * 256 + e;
-  for (int p = 0; p < wpf * KS; ++p) sum += sp[(int64_t)p * T * 256];
-  const int l = e & 63, reg = e >> 6;
-  const int gi = ti * 16 + (l >> 4) + 4 * reg, gj = tj * 16 + (l & 15);
-  if (gi < m && gj < m) {
-    double *G = gram + (int64_t)f * m * m;
-    G[(int64_t)gi * m + gj] = sum;
-    if (ti != tj) G[(int64_t)gj * m + gi] = sum;
+  const int64_t stride = (int64_t)T * 256;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int p = g;
+  for (; p + 12 < np; p += 16) {
+    s0 += sp[p * stride];
+    s1 += sp[(p + 4) * stride];
+    s2 += sp[(p + 8) * stride];
+    s3 += sp[(p + 12) * stride];
   }
-  if (tile == 0 && e == 0) {
+  for (; p < np; p += 4) s0 += sp[p * stride];
+  red[g][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0) {
+    const double sum = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const int l = e & 63, reg = e >> 6;
+    const int gi = ti * 16 + (l >> 4) + 4 * reg, gj = tj * 16 + (l & 15);
+    if (gi < m && gj < m) {
+      double *G = gram + (int64_t)f * m * m;
+      G[(int64_t)gi * m + gj] = sum;
+      if (ti != tj) G[(int64_t)gj * m + gi] = sum;
+    }
+  }
+  if (tile == 0) {  // Chan merge of the Welford partials: strided per thread, then a fixed binary tree
+    __syncthreads();
     double n = 0.0, mu = 0.0, m2 = 0.0;
     const double *q = stat_part + (int64_t)base * slots_per_wg * 3;
-    for (int p = 0; p < wpf * slots_per_wg; ++p) {
-      const double nb = q[3 * p], mb = q[3 * p + 1], sb = q[3 * p + 2];
-      if (nb > 0.0) {
-        const double tot = n + nb, d = mb - mu;
-        mu += d * nb / tot;
-        m2 += sb + d * d * n * nb / tot;
-        n = tot;
-      }
+    const int tot_slots = wpf * slots_per_wg;
+    for (int pp = threadIdx.x; pp < tot_slots; pp += 1024) chan_merge(n, mu, m2, q[3 * pp], q[3 * pp + 1], q[3 * pp + 2]);
+    double *sn = &red[0][0], *smu = &red[1][0], *sm2 = &red[2][0];  // 1024 doubles each would not fit: fold to 256 first
+    for (int o = 32; o > 0; o >>= 1) {                               // wave tree (lane i <- lane i+o)
+      const double on = __shfl_down(n, o, 64), om = __shfl_down(mu, o, 64), os = __shfl_down(m2, o, 64);
+      chan_merge(n, mu, m2, on, om, os);
     }
-    fstats[3 * f] = n; fstats[3 * f + 1] = mu; fstats[3 * f + 2] = m2;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sn[w] = n; smu[w] = mu; sm2[w] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      n = 0.0; mu = 0.0; m2 = 0.0;
+      for (int ww = 0; ww < 16; ++ww) chan_merge(n, mu, m2, sn[ww], smu[ww], sm2[ww]);
+      fstats[3 * f] = n; fstats[3 * f + 1] = mu; fstats[3 * f + 2] = m2;
+    }
   }
 }
 
@@ -191,7 +265,7 @@ int occupancy_wgs() {
   static int cached = 0;
   if (cached) return cached;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT>, NW * 64, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT>, GramCfg<MT>::NW * 64, 0) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -211,7 +285,7 @@ SegPlan make_plan(int64_t n_rows, int64_t row0, int64_t n_points, int32_t n_feat
 
 template <int MT>
 size_t workspace_bytes(int32_t n_features) {
-  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, NW>;
+  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW>;
   const int64_t max_grid = (int64_t)occupancy_wgs<MT>() + n_features;
   return (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256 * sizeof(double) +
          (size_t)max_grid * RT::ROWS_PER_IT * 3 * sizeof(double);
@@ -229,7 +303,7 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   double *slab = static_cast<double *>(ws);
   double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  hipLaunchKernelGGL(stats_gram_kernel<MT>, dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, vec_ok, center, plan,
+  hipLaunchKernelGGL(stats_gram_kernel<MT>, dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m, vec_ok, center, plan,
                      rowmean, stat_part, slab);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
@@ -238,14 +312,14 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
 template <int MT>
 int launch_finalize(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points, int32_t n_features,
                     double *fstats, double *gram, const void *ws, size_t ws_bytes, hipStream_t st) {
-  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, NW>;
+  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW>;
   SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
               "spr_stats_gram_finalize_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
   SegPlan plan = make_plan<MT>(n_rows, row0, n_points, n_features);
   const int64_t max_grid = (int64_t)occupancy_wgs<MT>() + n_features;
   const double *slab = static_cast<const double *>(ws);
   const double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
-  hipLaunchKernelGGL(gram_finalize_kernel<MT>, dim3(GramShape<MT>::T, n_features), dim3(256), 0, st, slab,
+  hipLaunchKernelGGL(gram_finalize_kernel<MT>, dim3(GramShape<MT>::T, n_features), dim3(1024), 0, st, slab,
                      stat_part, (int)m, plan, (int)RT::ROWS_PER_IT, gram, fstats);
   SPR_LAUNCH_CHECK();
   return SPR_OK;

@@ -42,7 +42,7 @@ import numpy as np
 
 __all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix']
 
-_DENSE_C_LIMIT = 1 << 30   # optimal_placement returns a dense ndarray below this many bytes
+_DENSE_C_LIMIT = 1 << 26   # optimal_placement returns a dense ndarray below this many bytes (64 MiB)
 
 
 class RowShard:
@@ -80,6 +80,49 @@ class DeviceMatrix:
     @property
     def shape(self):
         return tuple(self.tensor.shape)
+
+
+class _Trace:
+    """Optional per-phase wall-clock trace of fit() (SPR_TRACE=1): synchronises at every mark."""
+
+    def __init__(self, eng):
+        import os
+        self.on = os.environ.get('SPR_TRACE', '0') == '1'
+        self.eng = eng
+        self.marks = []
+        if self.on:
+            self.mark('start')
+
+    def mark(self, label):
+        if not self.on:
+            return
+        import time
+        if hasattr(self.eng, 'device') and self.eng.device.type == 'cuda':
+            self.eng.torch.cuda.synchronize()
+        self.marks.append((label, time.perf_counter()))
+
+    def report(self):
+        if not self.on:
+            return
+        import sys
+        t0 = self.marks[0][1]
+        prev = t0
+        parts = []
+        for label, t in self.marks[1:]:
+            parts.append(f'{label}={1e3 * (t - prev):.2f}')
+            prev = t
+        print('[spr trace] ' + ' '.join(parts) + f' total={1e3 * (prev - t0):.2f} ms', file=sys.stderr)
+
+
+def _eigh_small(G):
+    """LAPACK dsyevd on the (m, m) Gram matrix with the BLAS pool capped: the problem is far too
+    small for a many-core pool (128 threads made it 10x slower on the GPU host)."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                   # pragma: no cover
+        return np.linalg.eigh(G)
+    with threadpool_limits(limits=4, user_api='blas'):
+        return np.linalg.eigh(G)
 
 
 def _sign_fix(V):
@@ -205,10 +248,13 @@ class ROM:
         Xd = self._Xd()
         m = Xd.shape[1]
         F = self.n_features
+        tr_ = self._trace = _Trace(eng)
         rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+        tr_.mark('stats_gram')
         gram = self._all_reduce(gram)
         fs = eng.to_host(self._all_gather(fstats))          # (world, F, 3)
         G_f = eng.to_host(gram)                              # (F, m, m)
+        tr_.mark('collect')
         cnt = np.zeros(F); mu = np.zeros(F); m2 = np.zeros(F)
         for w in range(fs.shape[0]):                         # Chan merge in rank order
             nb, mb, sb = fs[w, :, 0], fs[w, :, 1], fs[w, :, 2]
@@ -231,6 +277,7 @@ class ROM:
             self._d['inv_scale'] = eng.to_device(1.0 / self._scl_f)
         for k in ('X_cnt', 'X_scl', 'X0'):
             self._host.pop(k, None)
+        tr_.mark('merge')
 
     def scale_data(self, scale_type='std', axis_cnt=1):
         """Reference :83-171.  Sets X_cnt / X_scl and returns the scaled matrix X0."""
@@ -281,7 +328,7 @@ class ROM:
     # ------------------------------------------------------------------ a3 decomposition
     def _spectrum(self, G):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
-        lam, V = np.linalg.eigh(G)
+        lam, V = _eigh_small(G)
         lam = lam[::-1]
         V = _sign_fix(V[:, ::-1])
         lam_pos = np.maximum(lam, 0.0)
@@ -294,6 +341,7 @@ class ROM:
         Xd = self._Xd()
         m = Xd.shape[1]
         S, V, exp_variance = self._spectrum(G)
+        self._trace.mark('eigh')
         r = self._select_rank(exp_variance, m, select_modes, n_modes)
         # modes below sqrt(m eps) sigma_1 carry no information on the Gram route; keep the
         # projection finite for them (their reference counterparts are LAPACK rounding noise)
@@ -302,6 +350,7 @@ class ROM:
         W = V[:, :r] / S_safe
         Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, eng.to_device(W),
                            center=center, out=self._d.pop('Ur', None))
+        self._trace.mark('project')
         Ar = V[:, :r] * S[:r]                                # A = (diag(S) Vt).T  (:273)
         return Ur_d, Ar, exp_variance[:r], S, r
 
@@ -349,6 +398,7 @@ class ROM:
         self.Vr = Ar / Sigma_r
         for k in ('C', 'Theta'):
             self.__dict__.pop(k, None)
+        self._trace.report()
 
     # ------------------------------------------------------------------ a10 reconstruct
     def reconstruct(self, Ar, sampling=None, to_host=True):
@@ -391,7 +441,7 @@ class SPR(ROM):
     # ------------------------------------------------------------------ a6 optimal_placement
     def optimal_placement(self, calc_type='qr', n_sensors=10, mask=None, d_min=0., verbose=False):
         """Reference :700-756.  Returns the one-hot measurement matrix C of shape (s, n):
-        a dense ndarray when it is small (< 1 GiB), a scipy.sparse CSR matrix otherwise.
+        a dense ndarray when it is small (< 64 MiB), a scipy.sparse CSR matrix otherwise.
         The ordered global sensor rows are also kept in ``self.sensors_``."""
         if calc_type == 'gem':
             raise NotImplementedError("calc_type='gem' has no device implementation yet (no CPU fallback).")

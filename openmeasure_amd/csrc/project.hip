@@ -7,9 +7,21 @@
 // the 16-row blocks rg, rg+RG, ... of each panel.
 //
 // v_mfma_f64_16x16x4_f64 operands: A[i = l&15][k = l>>4] = panel[16 rb + i][k0 + k] -- a
-// strided LDS read, conflict-free because the row stride MP is 2 (mod 4) doubles;
+// strided LDS read.  The row stride MP is 17 (mod 32) doubles: conflict-free both for
+// ds_read_b64 (32-lane groups, 64 banks) and for the ds_read2_b64 / ds_read2st64_b64 forms
+// hipcc fuses neighbouring reads into (16-lane groups, 32 banks); rows are then only 8-byte
+// aligned, so the panel is written with ds_write_b64;
 // B[k = l>>4][j = l&15] = W[k0 + k][16 cg + j].  Result: col = l&15, row = (l>>4) + 4 reg.
 #include "rowtile.hpp"
+
+#ifndef PROJ_ABLATE
+#define PROJ_ABLATE 0   // diagnostic builds: 1 = no MFMAs, 2 = no centring/loads in the loop, 3 = no Ur stores
+#endif
+#if PROJ_ABLATE == 1
+#define PROJ_MFMA(a, b, c) ({ asm volatile("" ::"v"(a), "v"(b)); (c); })
+#else
+#define PROJ_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#endif
 
 namespace {
 
@@ -17,13 +29,13 @@ constexpr int NW = 8;
 
 template <int MT> struct ProjRows { static constexpr int R = (MT >= 12) ? 32 : 64; };
 
-template <int MT, int RTILES>
+template <int MT, int RTILES, bool VEC>
 __global__ __launch_bounds__(NW * 64) void project_kernel(
-    const double *__restrict__ X, int64_t ldx, int m, int vec_ok_i, int center_i, SegPlan plan,
+    const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     const double *__restrict__ inv_scale, const double *__restrict__ W, int r,
     double *__restrict__ Ur, int64_t ldu) {
   constexpr int R = ProjRows<MT>::R;
-  constexpr int MPAD = 16 * MT, MP = MPAD + 2;
+  constexpr int MPAD = 16 * MT, MP = MPAD + ((MT % 2) ? 1 : 17);   // == 17 (mod 32)
   constexpr int KSTEPS = MPAD / 4;
   constexpr int CG = RTILES, RG = NW / CG, RB = R / 16;
   using RT = RowTile<MT, R, MP, NW>;
@@ -37,7 +49,6 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cg = wave % CG, rg = wave / CG;
-  const bool vec_ok = vec_ok_i != 0;
   const double isc = inv_scale[f];
 
   // B fragments of this wave's 16 output columns, all k
@@ -49,36 +60,66 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
       const int k = 4 * ks + (lane >> 4);
       bfrag[ks] = (k < m && col < r) ? W[(int64_t)k * r + col] : 0.0;
     }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(bfrag[ks]));  // pin: never re-load W inside the loop
   }
 
+  // Same one-barrier software pipeline as the Gram kernel: the MFMAs of panel c run from one
+  // LDS buffer while this wave centres panel c+1 into the other buffer (one row pass per slice
+  // of the k loop) and re-issues the HBM loads of panel c+2 into the registers just freed.
   RT tile;
   const int64_t nchunks = (hi - lo + R - 1) / R;
   int64_t c = wl;
-  if (c < nchunks) tile.load(X, ldx, m, vec_ok, lo + c * R, hi, wave, lane);
+  tile.template load<VEC>(X, ldx, m, lo + c * R, hi, wave, lane);
+  tile.template center_store<false>(lds[0], m, center_i != 0, lo + c * R, hi, wave, lane, nullptr, nullptr);
+  int64_t cn = c + wpf;
+  int64_t nrow0 = (cn < nchunks) ? lo + cn * R : hi;
+  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane);
   int buf = 0;
   const int afrag = (lane & 15) * MP + (lane >> 4);
+  const int col = cg * 16 + (lane & 15);
+  constexpr int NRB = (RB + RG - 1) / RG;           // row blocks per wave and panel (upper bound)
+  constexpr int SLOTS = NRB * KSTEPS;               // MFMAs per wave and panel
   while (c < nchunks) {
-    tile.template center_store<false>(lds[buf], m, center_i != 0, lo + c * R, hi, wave, lane, nullptr, nullptr);
-    const int64_t cn = c + wpf;
-    if (cn < nchunks) tile.load(X, ldx, m, vec_ok, lo + cn * R, hi, wave, lane);
+    double *cur = lds[buf];
+    double *nxt = lds[buf ^ 1];
+    const int64_t c2 = cn + wpf;
+    const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * R : hi;
     __syncthreads();
-    for (int rb = rg; rb < RB; rb += RG) {
-      const double *p = lds[buf] + rb * 16 * MP + afrag;
-      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[4 * ks], bfrag[ks], acc, 0, 0, 0);
-      const int col = cg * 16 + (lane & 15);
-      const int64_t row = lo + c * R + rb * 16 + (lane >> 4);
-      if (col < r) {
-        if (row < hi) Ur[row * ldu + col] = acc.x * isc;
-        if (row + 4 < hi) Ur[(row + 4) * ldu + col] = acc.y * isc;
-        if (row + 8 < hi) Ur[(row + 8) * ldu + col] = acc.z * isc;
-        if (row + 12 < hi) Ur[(row + 12) * ldu + col] = acc.w * isc;
+#pragma clang loop unroll(full)
+    for (int b = 0; b < NRB; ++b) {
+      const int rb = rg + b * RG;
+      const bool live = rb < RB;                    // wave-uniform
+      const double *p = cur + (live ? rb : 0) * 16 * MP + afrag;
+      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma clang loop unroll(full)
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (live) {
+          if (ks & 1) acc1 = PROJ_MFMA(p[4 * ks], bfrag[ks], acc1);
+          else acc0 = PROJ_MFMA(p[4 * ks], bfrag[ks], acc0);
+        }
+#pragma clang loop unroll(full)
+        for (int it = 0; it < RT::IT; ++it)
+          if (PROJ_ABLATE != 2 && (it * SLOTS) / RT::IT == b * KSTEPS + ks) {
+            tile.template center_store_pass<false>(it, nxt, m, center_i != 0, nrow0, hi, wave, lane, nullptr, nullptr);
+            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane);
+          }
+      }
+      if (live) {
+        const int64_t row = lo + c * R + rb * 16 + (lane >> 4);
+        if (PROJ_ABLATE == 3) asm volatile("" ::"v"(acc0.x + acc1.x), "v"(acc0.y + acc1.y), "v"(acc0.z + acc1.z), "v"(acc0.w + acc1.w));
+        if (PROJ_ABLATE != 3 && col < r) {
+          if (row < hi) Ur[row * ldu + col] = (acc0.x + acc1.x) * isc;
+          if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (acc0.y + acc1.y) * isc;
+          if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (acc0.z + acc1.z) * isc;
+          if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (acc0.w + acc1.w) * isc;
+        }
       }
     }
     buf ^= 1;
     c = cn;
+    cn = c2;
+    nrow0 = n2row0;
   }
 }
 
@@ -89,7 +130,7 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   static int total_wg = 0;
   if (!total_wg) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES>, NW * 64, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES, true>, NW * 64, 0) !=
             hipSuccess || per_cu < 1)
       per_cu = 1;
     if (per_cu > 4) per_cu = 4;
@@ -101,8 +142,12 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   plan.total_wg = total_wg; plan.chunk_rows = ProjRows<MT>::R;
   const int grid = seg_total_wgs(plan);
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  hipLaunchKernelGGL((project_kernel<MT, RTILES>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, vec_ok,
-                     center, plan, inv_scale, W, (int)r, Ur, ldu);
+  if (vec_ok)
+    hipLaunchKernelGGL((project_kernel<MT, RTILES, true>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center,
+                       plan, inv_scale, W, (int)r, Ur, ldu);
+  else
+    hipLaunchKernelGGL((project_kernel<MT, RTILES, false>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center,
+                       plan, inv_scale, W, (int)r, Ur, ldu);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }

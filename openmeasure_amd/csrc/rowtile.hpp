@@ -9,6 +9,11 @@
 // pattern), and the next panel's loads are issued before the consumer starts on the
 // current one.  Columns >= m and rows past the segment end are written as zeros, so
 // the consumers never need a bounds test.
+//
+// Everything here is branch-free on purpose: loads always go to a clamped, valid address
+// and validity is applied with selects.  Predicated loads split the basic block, and
+// hipcc's s_waitcnt insertion then falls back to vmcnt(0) right behind the loads it has
+// just issued, which serialises the HBM latency into the MFMA loop.
 #pragma once
 #include "common.hpp"
 
@@ -17,10 +22,10 @@ struct RowStats {  // running statistics of the row means seen by one lane group
   // streaming loop; converted to the (count, mean, M2) form that Chan's merge wants at the end.
   double cnt, ref, s1, s2;
   __device__ inline void init() { cnt = 0.0; ref = 0.0; s1 = 0.0; s2 = 0.0; }
-  __device__ inline void push(double x) {
+  __device__ inline void push(double x, bool valid) {
     ref = (cnt == 0.0) ? x : ref;
-    const double d = x - ref;
-    cnt += 1.0;
+    const double d = valid ? x - ref : 0.0;
+    cnt += valid ? 1.0 : 0.0;
     s1 += d;
     s2 += d * d;
   }
@@ -31,73 +36,126 @@ struct RowStats {  // running statistics of the row means seen by one lane group
   }
 };
 
-template <int MT, int R, int MP, int NWAVES>
+// LPRMAX caps the lanes that share a row.  Fewer lanes per row means more of the row sum is
+// formed by plain per-lane adds and less by cross-lane steps: at 16 lanes the butterfly is
+// four DPP steps (no ds_bpermute) and one wave instruction handles four rows at once.  This
+// matters because VALU work does not hide behind v_mfma_f64_16x16x4_f64 on gfx950 (measured:
+// kernel time = MFMA time + VALU time), so the centring pass is kept as short as possible.
+template <int MT, int R, int MP, int NWAVES, int LPRMAX = 16>
 struct RowTile {
   static constexpr int MPAD = 16 * MT;
   static constexpr int NV = MPAD / 2;                       // 16-byte pieces per padded row
-  static constexpr int LPR = spr_pow2_divisor_le64(NV);     // lanes per row
+  static constexpr int LPR0 = spr_pow2_divisor_le64(NV);
+  static constexpr int LPR = LPR0 < LPRMAX ? LPR0 : LPRMAX; // lanes per row
   static constexpr int VPL = NV / LPR;                      // pieces per lane
   static constexpr int RPW = 64 / LPR;                      // rows per wave instruction
   static constexpr int ROWS_PER_IT = NWAVES * RPW;
   static constexpr int IT = R / ROWS_PER_IT;
   static_assert(R % ROWS_PER_IT == 0, "panel rows must be a multiple of rows per pass");
-  static_assert(MP % 2 == 0, "LDS row stride must keep rows 16-byte aligned");
+  static constexpr bool WIDE_STORE = (MP % 2 == 0);   // odd stride: rows are only 8-byte aligned in LDS
 
   f64x2 pre[IT][VPL];
 
-  // issue the loads of the panel whose first local row is crow0 (rows >= seg_hi read as 0)
-  __device__ inline void load(const double *__restrict__ X, int64_t ldx, int m, bool vec_ok,
-                              int64_t crow0, int64_t seg_hi, int wave, int lane) {
+  // Pass `it` (a constant after unrolling) of the panel whose first local row is crow0.
+  // VEC: rows are 16-byte aligned and m is even.  Rows >= seg_hi re-read the last valid row
+  // and columns >= m re-read column 0; center_store_pass discards both.
+  template <bool VEC>
+  __device__ inline void load_pass(int it, const double *__restrict__ X, int64_t ldx, int m, int64_t crow0,
+                                   int64_t seg_hi, int wave, int lane) {
     const int grp = lane / LPR, lig = lane % LPR;
+    int64_t lrow = crow0 + it * ROWS_PER_IT + wave * RPW + grp;
+    lrow = lrow < seg_hi ? lrow : seg_hi - 1;
+    const double *rp = X + lrow * ldx;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int64_t lrow = crow0 + it * ROWS_PER_IT + wave * RPW + grp;
-      const bool rv = lrow < seg_hi;
-      const double *rp = X + lrow * ldx;
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const int col = 2 * (lig + v * LPR);
-        f64x2 t = {0.0, 0.0};
-        if (vec_ok) {
-          if (rv && col < m) t = *reinterpret_cast<const f64x2 *>(rp + col);
-        } else {
-          if (rv && col < m) t.x = rp[col];
-          if (rv && col + 1 < m) t.y = rp[col + 1];
-        }
-        pre[it][v] = t;
+    for (int v = 0; v < VPL; ++v) {
+      const int col = 2 * (lig + v * LPR);
+      f64x2 t;
+      if (VEC) {
+        t = *reinterpret_cast<const f64x2 *>(rp + (col < m ? col : 0));
+      } else {
+        t.x = rp[col < m ? col : 0];
+        t.y = rp[col + 1 < m ? col + 1 : 0];
       }
+      pre[it][v] = t;
     }
   }
 
-  // mean -> centre -> LDS; optionally store the row means and feed the Welford state
+  template <bool VEC>
+  __device__ inline void load(const double *__restrict__ X, int64_t ldx, int m, int64_t crow0, int64_t seg_hi,
+                              int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) load_pass<VEC>(it, X, ldx, m, crow0, seg_hi, wave, lane);
+  }
+
+  // one pass of mean -> centre -> LDS; optionally stores the row means and feeds the running
+  // statistics.  Split per pass so that a caller can slot the passes between the MFMA steps of
+  // the previous panel.
   template <bool WRITE_MEAN>
-  __device__ inline void center_store(double *__restrict__ lds, int m, bool center, int64_t crow0, int64_t seg_hi,
-                                      int wave, int lane, double *__restrict__ rowmean,
-                                      RowStats *st) {
+  __device__ inline void center_store_pass(int it, double *__restrict__ lds, int m, bool center, int64_t crow0,
+                                           int64_t seg_hi, int wave, int lane, double *__restrict__ rowmean,
+                                           RowStats *st) {
     const int grp = lane / LPR, lig = lane % LPR;
     const double inv_m = 1.0 / (double)m;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
-      const int64_t lrow = crow0 + rloc;
-      const bool rv = lrow < seg_hi;
+    const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
+    const int64_t lrow = crow0 + rloc;
+    const bool rv = lrow < seg_hi;
+    // wave-uniform fast path: whole pass inside the segment and no padded columns -> no selects
+    const bool fast = (crow0 + (it + 1) * ROWS_PER_IT <= seg_hi) && (m == MPAD);
+    if (fast) {
       double s = 0.0;
 #pragma unroll
       for (int v = 0; v < VPL; ++v) s += pre[it][v].x + pre[it][v].y;
       s = group_sum_t<LPR>(s);
       const double mean = center ? s * inv_m : 0.0;
-      if (WRITE_MEAN && rv) {
+      if (WRITE_MEAN) {
         if (lig == 0) rowmean[lrow] = mean;
-        st->push(mean);
+        st->push(mean, true);
       }
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int col = 2 * (lig + v * LPR);
-        f64x2 c;
-        c.x = (rv && col < m) ? pre[it][v].x - mean : 0.0;
-        c.y = (rv && col + 1 < m) ? pre[it][v].y - mean : 0.0;
+        f64x2 c = {pre[it][v].x - mean, pre[it][v].y - mean};
+        if constexpr (WIDE_STORE) {
+          *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
+        } else {
+          lds[rloc * MP + col] = c.x;
+          lds[rloc * MP + col + 1] = c.y;
+        }
+      }
+      return;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int col = 2 * (lig + v * LPR);
+      s += (col < m ? pre[it][v].x : 0.0) + (col + 1 < m ? pre[it][v].y : 0.0);
+    }
+    s = group_sum_t<LPR>(s);
+    const double mean = center ? s * inv_m : 0.0;
+    if (WRITE_MEAN) {
+      if (rv && lig == 0) rowmean[lrow] = mean;
+      st->push(mean, rv);
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int col = 2 * (lig + v * LPR);
+      f64x2 c;
+      c.x = (rv && col < m) ? pre[it][v].x - mean : 0.0;
+      c.y = (rv && col + 1 < m) ? pre[it][v].y - mean : 0.0;
+      if constexpr (WIDE_STORE) {
         *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
+      } else {
+        lds[rloc * MP + col] = c.x;
+        lds[rloc * MP + col + 1] = c.y;
       }
     }
+  }
+
+  template <bool WRITE_MEAN>
+  __device__ inline void center_store(double *__restrict__ lds, int m, bool center, int64_t crow0, int64_t seg_hi,
+                                      int wave, int lane, double *__restrict__ rowmean, RowStats *st) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+      center_store_pass<WRITE_MEAN>(it, lds, m, center, crow0, seg_hi, wave, lane, rowmean, st);
   }
 };

@@ -15,6 +15,15 @@
 // The result lane map is col = l&15, row = (l>>4) + 4*reg.
 #include "rowtile.hpp"
 
+#ifndef GRAM_ABLATE
+#define GRAM_ABLATE 0   // diagnostic builds: 1 = no MFMAs, 2 = no centring/loads in the loop
+#endif
+#if GRAM_ABLATE == 1
+#define GRAM_MFMA(a, b, c) ({ asm volatile("" ::"v"(a), "v"(b)); (c); })
+#else
+#define GRAM_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#endif
+
 namespace {
 
 template <int MT>
@@ -27,14 +36,17 @@ struct GramShape {
 
 // waves per workgroup, k slices and panel height per padded width (NW = NU * KS)
 template <int MT> struct GramCfg;
-template <> struct GramCfg<1>  { static constexpr int NW = 8,  R = 64, KS = 8; static constexpr bool DBUF = true; };
-template <> struct GramCfg<2>  { static constexpr int NW = 8,  R = 32, KS = 8; static constexpr bool DBUF = true; };
-template <> struct GramCfg<3>  { static constexpr int NW = 8,  R = 64, KS = 4; static constexpr bool DBUF = true; };
-template <> struct GramCfg<4>  { static constexpr int NW = 8,  R = 32, KS = 4; static constexpr bool DBUF = true; };
-template <> struct GramCfg<6>  { static constexpr int NW = 12, R = 48, KS = 4; static constexpr bool DBUF = true; };
-template <> struct GramCfg<8>  { static constexpr int NW = 8,  R = 32, KS = 2; static constexpr bool DBUF = true; };
-template <> struct GramCfg<12> { static constexpr int NW = 12, R = 24, KS = 2; static constexpr bool DBUF = false; };
-template <> struct GramCfg<16> { static constexpr int NW = 8,  R = 32, KS = 1; static constexpr bool DBUF = true; };
+template <> struct GramCfg<1>  { static constexpr int NW = 8,  R = 64, KS = 8; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
+template <> struct GramCfg<2>  { static constexpr int NW = 8,  R = 32, KS = 8; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
+template <> struct GramCfg<3>  { static constexpr int NW = 8,  R = 64, KS = 4; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
+template <> struct GramCfg<4>  { static constexpr int NW = 8,  R = 32, KS = 4; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
+template <> struct GramCfg<6>  { static constexpr int NW = 12, R = 48, KS = 4; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
+template <> struct GramCfg<8>  { static constexpr int NW = 8,  R = 32, KS = 2; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
+template <> struct GramCfg<12> { static constexpr int NW = 12, R = 24, KS = 2; static constexpr bool DBUF = false; static constexpr int LPRMAX = 32; };
+#ifndef GRAM_DBUF16
+#define GRAM_DBUF16 false
+#endif
+template <> struct GramCfg<16> { static constexpr int NW = 8,  R = 32, KS = 1; static constexpr bool DBUF = GRAM_DBUF16; static constexpr int LPRMAX = 16; };
 
 // linear index over the upper triangle (row-major) <-> tile row / column
 constexpr int tri_index(int mt, int ti, int tj) { return ti * mt - ti * (ti - 1) / 2 + (tj - ti); }
@@ -53,8 +65,8 @@ __device__ inline void tile_coords(int idx, int &ti, int &tj) {
 // reads the MT-RA operand fragments of column blocks RA..MT-1 once (every fragment is both
 // an A and a B operand) and issues its MFMAs from registers; the fragments of step k+1 are
 // requested before the MFMAs of step k so LDS latency hides behind the 64-cycle MFMAs.
-template <int MT, int U>
-__device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int m, bool vec_ok, bool center,
+template <int MT, int U, bool VEC>
+__device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int m, bool center,
                                  int64_t lo, int64_t hi, int wl, int wpf, int ks, int wave, int lane,
                                  double *__restrict__ lds0, double *__restrict__ lds1,
                                  double *__restrict__ rowmean, double *__restrict__ stat_part,
@@ -67,7 +79,7 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
   constexpr int NA = MT - RA;                 // tiles in row RA == operand fragments per k step
   constexpr int NB = (RB != RA) ? MT - RB : 0;
   static_assert(KROWS % 4 == 0, "k slice must be a multiple of the MFMA depth");
-  using RT = RowTile<MT, R, MP, NW>;
+  using RT = RowTile<MT, R, MP, NW, C::LPRMAX>;
 
   f64x4 accA[NA];
   f64x4 accB[NB > 0 ? NB : 1];
@@ -80,16 +92,23 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
   st.init();
   RT tile;
 
+  // Software pipeline, one barrier per panel: while the MFMAs of panel c run from one LDS
+  // buffer, the same wave centres panel c+1 (already in registers) into the other buffer,
+  // one row pass between k steps, and then requests panel c+2 from HBM.
   const int64_t nchunks = (hi - lo + R - 1) / R;
   int64_t c = wl;
-  if (c < nchunks) tile.load(X, ldx, m, vec_ok, lo + c * R, hi, wave, lane);
+  tile.template load<VEC>(X, ldx, m, lo + c * R, hi, wave, lane);
+  tile.template center_store<true>(lds0, m, center, lo + c * R, hi, wave, lane, rowmean, &st);
+  int64_t cn = c + wpf;
+  int64_t nrow0 = (cn < nchunks) ? lo + cn * R : hi;      // past-the-end panel: every row invalid
+  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane);
   int buf = 0;
   const int frag = (lane >> 4) * MP + (lane & 15) + ks * KROWS * MP + RA * 16;
   while (c < nchunks) {
     double *cur = buf ? lds1 : lds0;
-    tile.template center_store<true>(cur, m, center, lo + c * R, hi, wave, lane, rowmean, &st);
-    const int64_t cn = c + wpf;
-    if (cn < nchunks) tile.load(X, ldx, m, vec_ok, lo + cn * R, hi, wave, lane);
+    double *nxt = buf ? lds0 : lds1;
+    const int64_t c2 = cn + wpf;
+    const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * R : hi;
     __syncthreads();
     const double *p = cur + frag;
     if constexpr (C::DBUF) {
@@ -104,27 +123,41 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
         }
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-          accA[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[k & 1][0], op[k & 1][j], accA[j], 0, 0, 0);
+          accA[j] = GRAM_MFMA(op[k & 1][0], op[k & 1][j], accA[j]);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-          accB[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[k & 1][RB - RA], op[k & 1][RB - RA + j], accB[j], 0, 0, 0);
+          accB[j] = GRAM_MFMA(op[k & 1][RB - RA], op[k & 1][RB - RA + j], accB[j]);
+#pragma unroll
+        for (int it = 0; it < RT::IT; ++it)
+          if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
+            tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
+            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane);   // panel c+2 into the freed registers
+          }
       }
     } else {  // register-tight shapes: one operand set, three waves per SIMD cover the LDS latency
-#pragma unroll 1
+#pragma unroll
       for (int k = 0; k < KSTEPS; ++k) {
         double op[NA];
 #pragma unroll
         for (int j = 0; j < NA; ++j) op[j] = p[k * 4 * MP + 16 * j];
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-          accA[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[0], op[j], accA[j], 0, 0, 0);
+          accA[j] = GRAM_MFMA(op[0], op[j], accA[j]);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-          accB[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[RB - RA], op[RB - RA + j], accB[j], 0, 0, 0);
+          accB[j] = GRAM_MFMA(op[RB - RA], op[RB - RA + j], accB[j]);
+#pragma unroll
+        for (int it = 0; it < RT::IT; ++it)
+          if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
+            tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
+            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane);   // panel c+2 into the freed registers
+          }
       }
     }
     buf ^= 1;
     c = cn;
+    cn = c2;
+    nrow0 = n2row0;
   }
 
   // tiles -> slab[(block*KS + ks)][tile][reg][lane]
@@ -146,9 +179,9 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
   }
 }
 
-template <int MT>
+template <int MT, bool VEC>
 __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
-    const double *__restrict__ X, int64_t ldx, int m, int vec_ok_i, int center_i, SegPlan plan,
+    const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab) {
   using S = GramShape<MT>;
   using C = GramCfg<MT>;
@@ -166,7 +199,7 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
 #define GRAM_UNIT(UV)                                                                                        \
   case UV:                                                                                                   \
     if constexpr (UV < NU)                                                                                   \
-      gram_wave<MT, UV>(X, ldx, m, vec_ok_i != 0, center_i != 0, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
+      gram_wave<MT, UV, VEC>(X, ldx, m, center_i != 0, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
                         lds[1], rowmean, stat_part, slab);                                                   \
     break;
   switch (unit) {
@@ -265,7 +298,7 @@ int occupancy_wgs() {
   static int cached = 0;
   if (cached) return cached;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT>, GramCfg<MT>::NW * 64, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT, true>, GramCfg<MT>::NW * 64, 0) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -285,7 +318,7 @@ SegPlan make_plan(int64_t n_rows, int64_t row0, int64_t n_points, int32_t n_feat
 
 template <int MT>
 size_t workspace_bytes(int32_t n_features) {
-  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW>;
+  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW, GramCfg<MT>::LPRMAX>;
   const int64_t max_grid = (int64_t)occupancy_wgs<MT>() + n_features;
   return (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256 * sizeof(double) +
          (size_t)max_grid * RT::ROWS_PER_IT * 3 * sizeof(double);
@@ -303,8 +336,12 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   double *slab = static_cast<double *>(ws);
   double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  hipLaunchKernelGGL(stats_gram_kernel<MT>, dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m, vec_ok, center, plan,
-                     rowmean, stat_part, slab);
+  if (vec_ok)
+    hipLaunchKernelGGL((stats_gram_kernel<MT, true>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m,
+                       center, plan, rowmean, stat_part, slab);
+  else
+    hipLaunchKernelGGL((stats_gram_kernel<MT, false>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m,
+                       center, plan, rowmean, stat_part, slab);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
@@ -312,7 +349,7 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
 template <int MT>
 int launch_finalize(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points, int32_t n_features,
                     double *fstats, double *gram, const void *ws, size_t ws_bytes, hipStream_t st) {
-  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW>;
+  using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW, GramCfg<MT>::LPRMAX>;
   SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
               "spr_stats_gram_finalize_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
   SegPlan plan = make_plan<MT>(n_rows, row0, n_points, n_features);

@@ -20,9 +20,9 @@ for line in p.stderr.splitlines():
         rows.append(cur)
     elif cur is not None:
         cur[k] = v
-print(f"{'kernel':70s} {'VGPR':>5} {'AGPR':>5} {'vspill':>6} {'SGPR':>5} {'sspill':>6} {'LDS':>7} {'occ':>4}")
+print(f"{'kernel':70s} {'VGPR':>5} {'AGPR':>5} {'vspill':>6} {'SGPR':>5} {'sspill':>6} {'LDS':>7} {'occ':>4} {'scratch':>7}")
 for r in rows:
     print(f"{r['name']:70s} {r.get('VGPRs','?'):>5} {r.get('AGPRs','?'):>5} {r.get('VGPRs Spill','?'):>6} "
           f"{r.get('TotalSGPRs','?'):>5} {r.get('SGPRs Spill','?'):>6} {r.get('LDS Size [bytes/block]','?'):>7} "
-          f"{r.get('Occupancy [waves/SIMD]','?'):>4}")
+          f"{r.get('Occupancy [waves/SIMD]','?'):>4} {r.get('ScratchSize [bytes/lane]','?'):>7}")
 sys.exit(p.returncode)

@@ -33,9 +33,9 @@ if ROOT not in sys.path:
 # CPU-sized case, c2/c3 the single-GPU cases, c3 the one the north_star target is quoted on.
 WORKLOADS = {
     'c1': dict(cells=18_362, features=9, m=41, s=14, cpu_cells=18_362),
-    'c2': dict(cells=1_000_000, features=4, m=64, s=32, cpu_cells=250_000),
-    'c3': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=12_000),
-    'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=12_000),   # c3 at 1/10 of the rows
+    'c2': dict(cells=1_000_000, features=4, m=64, s=32, cpu_cells=1_000_000),
+    'c3': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=100_000),
+    'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000),   # c3 at 1/10 of the rows
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F64_PEAK_TF = 78.6     # AMD public spec for MI355X FP64 matrix; tools/mfma_probe measures 73.6 on the box
@@ -50,7 +50,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default=os.environ.get('SPR_BENCH_WORKLOAD', 'c2'), choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default=os.environ.get('SPR_BENCH_WORKLOAD', 'c3'), choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline / parity leg')
     ap.add_argument('--extra', action='store_true', help='also time placement/train/predict')
     args = ap.parse_args()

@@ -192,9 +192,10 @@ class ROM:
         if self._world() == 1:
             return t[None]
         import torch.distributed as dist
-        out = t.new_empty((self._world(),) + tuple(t.shape))
-        dist.all_gather_into_tensor(out, t.contiguous(), group=self._shard.group)
-        return out
+        flat = t.contiguous().view(-1)                       # concatenated layout: accepted by RCCL and gloo alike
+        out = flat.new_empty((self._world() * flat.numel(),))
+        dist.all_gather_into_tensor(out, flat, group=self._shard.group)
+        return out.view((self._world(),) + tuple(t.shape))
 
     def _lazy(self, key, make):
         if key not in self._host:
@@ -329,6 +330,16 @@ class ROM:
     def _spectrum(self, G):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
         lam, V = _eigh_small(G)
+        if self._world() > 1:
+            # every rank must project with bit-identical factors: rank 0's decomposition wins
+            import torch.distributed as dist
+            eng = self._engine()
+            pack = eng.to_device(np.concatenate([lam, V.ravel()]))
+            dist.broadcast(pack, src=dist.get_global_rank(self._shard.group, 0) if self._shard.group is not None else 0,
+                           group=self._shard.group)
+            pack = eng.to_host(pack)
+            m_ = lam.shape[0]
+            lam, V = pack[:m_].copy(), pack[m_:].reshape(m_, m_).copy()
         lam = lam[::-1]
         V = _sign_fix(V[:, ::-1])
         lam_pos = np.maximum(lam, 0.0)

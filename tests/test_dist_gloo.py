@@ -1,0 +1,89 @@
+"""World-size-2 (and 3) tests of the row-sharded path over the gloo backend on CPU.
+
+The HIP kernels cannot run here, so the local per-shard arithmetic is supplied by the NumPy
+test double (tests/numpy_engine.py); what is under test is the product's own host logic:
+RowShard bookkeeping with features that straddle ranks, the Chan merge of per-rank feature
+statistics, the Gram all-reduce, the per-step pivot candidate all-gather with global
+indices, the Theta/cnt all-reduce and the field all-gather -- against the single-process
+run and the reference's golden fixture."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fixture, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden
+        from tests.numpy_engine import NumpyEngine
+        g = load_golden(fixture)
+        X = g['X']
+        n = X.shape[0]
+        n_loc = n // world
+        assert n_loc * world == n
+        row0 = rank * n_loc
+        spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None,
+                  shard=RowShard(row0, n), engine=NumpyEngine())
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        mask = g.get('mask')
+        C = spr.optimal_placement(mask=None if mask is None else mask[row0:row0 + n_loc])
+        spr.train(C)
+        A3, S3 = spr.predict(list(g['ys']))
+        X3 = spr.reconstruct(A3)
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, Sigma=spr.Sigma_r, X3=X3, A3=A3,
+                 S3=S3, Theta=spr.Theta, X_cnt=spr.X_cnt, X_scl=spr.X_scl, Ur=spr.Ur, Ar=spr.Ar, C_shape=C.shape,
+                 gap=spr.pivot_gap_)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fixture,world', [('g2_num4', 2), ('g2_num4', 3), ('g3_num8', 2), ('g2_num4_mask', 2), ('g4_num5', 3)])
+def test_sharded_path_matches_reference(tmp_path, fixture, world):
+    from tests.conftest import load_golden
+    from tests.parity import REL_FRO, align_signs, rel_fro
+    g = load_golden(fixture)
+    n = g['X'].shape[0]
+    if n % world:
+        pytest.skip('rows do not divide')
+    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+    n_loc = n // world
+    for r, o in enumerate(outs):
+        # replicated results identical on every rank
+        np.testing.assert_array_equal(o['piv'], outs[0]['piv'])
+        np.testing.assert_array_equal(o['X3'], outs[0]['X3'])
+        np.testing.assert_array_equal(o['Theta'], outs[0]['Theta'])
+        # sharded attributes are the local rows
+        sl = slice(r * n_loc, (r + 1) * n_loc)
+        np.testing.assert_allclose(o['X_cnt'], g['X_cnt'][sl], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(o['X_scl'], g['X_scl'][sl], rtol=1e-12)
+        sg = align_signs(o['Ar'], g['Ar'])
+        np.testing.assert_allclose(o['Ur'] * sg, g['Ur_after_placement' if 'mask' in g else 'Ur'][sl], atol=1e-8)
+    o = outs[0]
+    assert tuple(o['C_shape']) == tuple(g['C_shape'])
+    np.testing.assert_array_equal(o['piv'], g['piv'])                       # global indices, exact, ordered
+    np.testing.assert_allclose(o['Sigma'], g['Sigma_r'], rtol=1e-9)
+    assert o['X3'].shape == (n, 3)
+    assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO
+    sg = align_signs(o['Ar'], g['Ar'])
+    np.testing.assert_allclose(o['A3'] * sg, g['Ar_pred3'], atol=1e-7 * np.abs(g['Ar_pred3']).max())
+    np.testing.assert_allclose(o['S3'], g['Ar_sigma3'], rtol=1e-6, atol=1e-9 * np.abs(g['Ar_sigma3']).max())
+    assert o['gap'].min() > 1e-9

@@ -142,7 +142,15 @@ def main():
         roof = dict(kernel=dom, bound='hbm', achieved=round(alg[dom]['bytes'] / k_ms[dom] / 1e6, 1),
                     peak=HBM_PEAK_GBS, unit='GB/s')
     roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
-    roof['traffic'] = None                           # PMC pass: profiles/ (separate rocprofv3 --pmc runs)
+    roof['traffic'] = None                           # HBM bytes/launch from separate rocprofv3 --pmc passes
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            pm = json.load(f).get(args.workload)
+        if pm and dom == 'stats_gram' and world == 1:
+            roof['traffic'] = pm['hbm_bytes']
+            roof['algorithmic_bytes'] = int(alg[dom]['bytes'])
+    except (OSError, ValueError):
+        pass
     roof['ms'] = round(k_ms[dom], 4)
     # whole-step algorithmic bytes: (2m + 2r + 1) n B + 16 n
     step_bytes = (2 * m + 2 * r + 1) * float(n_glob) * 8 + 16.0 * n_glob

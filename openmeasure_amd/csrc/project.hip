@@ -7,13 +7,14 @@
 // the 16-row blocks rg, rg+RG, ... of each panel.
 //
 // v_mfma_f64_16x16x4_f64 operands: A[i = l&15][k = l>>4] = panel[16 rb + i][k0 + k] -- a
-// strided LDS read.  The row stride MP is 17 (mod 32) doubles: conflict-free both for
-// ds_read_b64 (32-lane groups, 64 banks) and for the ds_read2_b64 / ds_read2st64_b64 forms
-// hipcc fuses neighbouring reads into (16-lane groups, 32 banks); rows are then only 8-byte
-// aligned, so the panel is written with ds_write_b64;
-// B[k = l>>4][j = l&15] = W[k0 + k][16 cg + j].  Result: col = l&15, row = (l>>4) + 4 reg.
+// strided ds_read_b64; with the row stride MP = MPAD + 2 (2 mod 4 doubles) the 32 lanes of a
+// group fall on 32 distinct bank pairs.  B[k = l>>4][j = l&15] = W[k0 + k][16 cg + j].
+// Result: col = l&15, row = (l>>4) + 4 reg.
 #include "rowtile.hpp"
 
+#ifndef PROJ_PAD
+#define PROJ_PAD 2   // row stride MPAD+2: ds_read_b64 A fragments conflict-free, rows 16-byte aligned (a sweep over 1..18 changed the kernel time by < 3 %)
+#endif
 #ifndef PROJ_ABLATE
 #define PROJ_ABLATE 0   // diagnostic builds: 1 = no MFMAs, 2 = no centring/loads in the loop, 3 = no Ur stores
 #endif
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
     const double *__restrict__ inv_scale, const double *__restrict__ W, int r,
     double *__restrict__ Ur, int64_t ldu) {
   constexpr int R = ProjRows<MT>::R;
-  constexpr int MPAD = 16 * MT, MP = MPAD + ((MT % 2) ? 1 : 17);   // == 17 (mod 32)
+  constexpr int MPAD = 16 * MT, MP = MPAD + PROJ_PAD;
   constexpr int KSTEPS = MPAD / 4;
   constexpr int CG = RTILES, RG = NW / CG, RB = R / 16;
   using RT = RowTile<MT, R, MP, NW>;

@@ -102,30 +102,41 @@ int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t l
  * Replaces scipy.linalg.qr(Ur.T, pivoting=True) (:739) -- only the first s pivots are
  * used by the reference (:740-743).  Greedy max-residual-norm selection with norm
  * down-dating, identical in exact arithmetic to dgeqp3's choice; ties go to the lowest
- * global row index (LAPACK idamax).
+ * global row index (LAPACK idamax).  Candidate-set form (csrc/qr_pivot.hip): a full sweep
+ * over Ur leaves exact residual norms, a candidate set (the largest rows of every sweep
+ * block) and tau = the largest norm a non-candidate can have; steps run on the candidates
+ * and are certified while the winner's residual is strictly above tau.
  *
- * spr_mask_rows      Ur[~mask,:] = 0 in place (:737-738); d_mask is n_rows bytes.
- * spr_qr_init        d_nrm[i] = |Ur[i,:]|^2 and this rank's best candidate
- *                    d_cand[0..r+1] = (value, global row as double, that row of Ur).
- * spr_qr_step        given n_cand candidates (one per rank, d_cands[n_cand][r+2]) picks
- *                    the winner, writes d_piv[step] (int64 global row) and the new
- *                    orthonormal direction d_Q[step][r], then down-dates d_nrm with it
- *                    and leaves this rank's next candidate in d_cand.
- * Single GPU: d_cands == d_cand, n_cand = 1.  Multi GPU: all-gather d_cand between steps.
- * d_gap (optional, may be NULL): d_gap[step] = relative gap between the local best and
- * second-best residual at selection time (diagnostic for pivot uniqueness).
- * Workspace: spr_qr_workspace(n_rows) bytes. */
-#define SPR_QR_CAND_LEN(r) ((r) + 3)
+ * spr_mask_rows     Ur[~mask,:] = 0 in place (:737-738); d_mask is n_rows bytes.
+ * spr_qr_init       d_nrm[i] = |Ur[i,:]|^2, candidate set, this rank's best record
+ *                   d_rec[0..r+2] = (value, global row as double, runner-up, row of Ur) and
+ *                   d_tau[0].
+ * spr_qr_step       given the ranks' records d_recs[n_rec][r+3] and taus d_taus[n_tau]: picks
+ *                   the winner, writes d_piv[step], the direction d_Q[step][r], d_gap[step]
+ *                   (relative gap to the best rival candidate) and d_ok[step] (1 = certified:
+ *                   first step after a sweep, or winner > tau), down-dates the candidate
+ *                   residuals and leaves this rank's next record in d_rec.
+ * spr_qr_refresh    applies the nq <= spr_qr_batch() accepted directions Q[j0..j0+nq) to all
+ *                   rows in one sweep (pivots marked), then new candidates / d_rec / d_tau.
+ * Driver loop (host): up to spr_qr_batch() steps, read d_ok once, keep the certified prefix
+ * (always >= 1 step), refresh, repeat.  Single GPU: d_recs == d_rec, d_taus == d_tau.
+ * Workspace: spr_qr_workspace(n_rows) bytes, the same buffer for all calls of one run. */
+#define SPR_QR_REC_LEN(r) ((r) + 3)
 size_t spr_qr_workspace(int64_t n_rows);
+int32_t spr_qr_batch(void);
 int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
                       const uint8_t *d_mask, void *stream);
 int spr_qr_init_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
-                    int64_t row0, double *d_nrm, double *d_cand,
+                    int64_t row0, double *d_nrm, double *d_rec, double *d_tau,
                     void *d_workspace, size_t workspace_bytes, void *stream);
-int spr_qr_step_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
-                    int64_t row0, int32_t step, const double *d_cands, int32_t n_cand,
-                    double *d_Q, int64_t *d_piv, double *d_nrm, double *d_cand,
-                    double *d_gap, void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_recs, int32_t n_rec,
+                    const double *d_taus, int32_t n_tau, int32_t first, double *d_Q,
+                    int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                       const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq,
+                       double *d_nrm, double *d_rec, double *d_tau,
+                       void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- K7 + K8 : Theta = C . Ur and cnt = C . X_cnt for a CSR measurement matrix ------
  * Replaces C.dot(self.Ur) (:797) and self.C.dot(self.X_cnt[:,0]) (:573).  The one-hot C

@@ -1,24 +1,35 @@
-// K6: QR column pivoting of Ur^T -- greedy max-residual-norm row selection.
+// K6: QR column pivoting of Ur^T -- greedy max-residual-norm row selection, candidate-set form.
 //
-// dgeqp3 on the r x n matrix Ur^T (sparse_sensing.py:739) picks, at step j, the column
-// with the largest residual norm after projecting out the j columns already chosen.
-// Only the pivot ORDER is used by the reference (:740-743), so no Householder vectors or
-// R factor are formed: per step the rank owning the winner contributes its row u_p, the
-// residual direction q_j = (I - Q Q^T) u_p / |..| is built in the r-dimensional
-// coefficient space (classical Gram-Schmidt, applied twice), and every row's squared
-// residual norm is down-dated by (u_i . q_j)^2 in one streaming pass over Ur.  Ties go to
-// the lowest global row index, as LAPACK's idamax does.
+// dgeqp3 on the r x n matrix Ur^T (sparse_sensing.py:739) picks, at step j, the column with
+// the largest residual norm after projecting out the j columns already chosen; only the
+// pivot ORDER is used by the reference (:740-743).  Per step the winning row u_p gives the
+// residual direction q_j = (I - Q Q^T) u_p / |..| in the r-dimensional coefficient space
+// (classical Gram-Schmidt applied twice), and every row's squared residual norm drops by
+// (u_i . q_j)^2.  Ties go to the lowest global row index, as LAPACK's idamax does.
+//
+// Sweeping all of Ur once per step costs r passes over n*r*8 bytes.  Residual norms only
+// decrease, so a stale norm is an upper bound: a full sweep ("refresh") leaves exact norms
+// and, per sweep block, its QR_TOPT largest rows; their union is the candidate set (a few
+// thousand rows, L2-resident) and tau = the largest norm any NON-candidate can have.  Steps
+// are then taken on the candidates alone -- exact arithmetic on exact copies of their rows --
+// and a step is certified only while its winner's residual is strictly above tau (the first
+// step after a refresh is always exact: every block's maximum is a candidate).  After at most
+// QR_BATCH steps, or at the first uncertified step, the accepted directions are applied to
+// all rows in ONE multi-direction sweep and a new candidate set is drawn.  Same pivots as the
+// step-per-sweep algorithm, r/QR_BATCH-ish passes over Ur instead of r.
 //
 // Candidate record (one per rank, all-gathered between steps when sharded), r+3 doubles:
 //   [0] best residual norm^2   [1] its global row (as double, exact below 2^53)
-//   [2] runner-up norm^2 on this rank   [3..3+r) the row of Ur
+//   [2] runner-up norm^2 among this rank's candidates   [3..3+r) the row of Ur
 #include "common.hpp"
 
 namespace {
 
 constexpr int QR_THREADS = 256;
 constexpr int QR_UNR = 4;
-constexpr int QR_MAX_PART = 4096;
+constexpr int QR_TOPT = 8;          // rows kept per sweep block
+constexpr int QR_MAX_BLOCKS = 1024; // sweep grid cap -> at most 8192 candidates
+constexpr int QR_BATCH = 8;         // directions applied per refresh sweep
 
 struct Best {
   double v1; int64_t i1; double v2;
@@ -36,46 +47,61 @@ struct Best {
   }
 };
 
-__device__ inline void block_best(Best &b, double *sv1, long long *si1, double *sv2, double *part) {
-  // wave butterfly, then across waves through LDS; thread 0 writes (v1, i1, v2) to part[0..2]
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov1 = __shfl_xor(b.v1, o, 64);
-    const long long oi1 = __shfl_xor((long long)b.i1, o, 64);
-    const double ov2 = __shfl_xor(b.v2, o, 64);
-    b.merge(ov1, oi1, ov2);
+// dot product of a row (read by LPR lanes, two doubles each) with up to NQ directions held in
+// registers, then v <- max(v - d^2, 0) per direction, in direction order
+template <int LPR, int NQ>
+__device__ inline double downdate(double v, f64x2 u, const double (&q0)[NQ], const double (&q1)[NQ], int nq) {
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) {
+    if (t < nq) {
+      double d = u.x * q0[t] + u.y * q1[t];
+      d = group_sum_t<LPR>(d);
+      v -= d * d;
+      v = v < 0.0 ? 0.0 : v;
+    }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { sv1[wave] = b.v1; si1[wave] = b.i1; sv2[wave] = b.v2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    Best t; t.init();
-    for (int w = 0; w < QR_THREADS / 64; ++w) t.merge(sv1[w], si1[w], sv2[w]);
-    part[0] = t.v1; part[1] = (double)t.i1; part[2] = t.v2;
-  }
+  return v;
 }
 
-// MODE 0: nrm = |u|^2.  MODE 1: nrm -= (u.q)^2, pivot row -> -1.  Both: per-block best.
+__device__ inline f64x2 load_row_piece(const double *__restrict__ rp, int k0, int r, bool vec_ok, bool valid) {
+  f64x2 t = {0.0, 0.0};
+  if (valid) {
+    if (vec_ok) {
+      if (k0 < r) t = *reinterpret_cast<const f64x2 *>(rp + k0);
+    } else {
+      if (k0 < r) t.x = rp[k0];
+      if (k0 + 1 < r) t.y = rp[k0 + 1];
+    }
+  }
+  return t;
+}
+
+// Full sweep over the rank's rows.  MODE 0: nrm = |u|^2.  MODE 2: nrm <- nrm down-dated by nq
+// directions (rows already chosen keep -1).  Both: the block's QR_TOPT largest (value, global
+// row) pairs, sorted, to tops[block][QR_TOPT][2].
 template <int LPR, int MODE>
 __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
     const double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int vec_ok_i, int64_t row0,
-    const double *__restrict__ q, const int64_t *__restrict__ piv_ptr, double *__restrict__ nrm,
-    double *__restrict__ part) {
+    const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
   constexpr int RPW = 64 / LPR;
   constexpr int ROWS_IT = (QR_THREADS / 64) * RPW * QR_UNR;
-  __shared__ double sv1[QR_THREADS / 64], sv2[QR_THREADS / 64];
-  __shared__ long long si1[QR_THREADS / 64];
+  __shared__ double sval[QR_THREADS * QR_TOPT];
+  __shared__ long long sidx[QR_THREADS * QR_TOPT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / LPR, lig = lane % LPR;
   const bool vec_ok = vec_ok_i != 0;
   const int k0 = 2 * lig;
-  double q0 = 0.0, q1 = 0.0;
-  int64_t piv = -1;
-  if (MODE == 1) {
-    if (k0 < r) q0 = q[k0];
-    if (k0 + 1 < r) q1 = q[k0 + 1];
-    piv = *piv_ptr;
+  double q0[QR_BATCH], q1[QR_BATCH];
+#pragma unroll
+  for (int t = 0; t < QR_BATCH; ++t) {
+    q0[t] = (MODE == 2 && t < nq && k0 < r) ? Q[(int64_t)t * r + k0] : 0.0;
+    q1[t] = (MODE == 2 && t < nq && k0 + 1 < r) ? Q[(int64_t)t * r + k0 + 1] : 0.0;
   }
-  Best best; best.init();
+  double tv[QR_TOPT];
+  long long ti[QR_TOPT];
+#pragma unroll
+  for (int k = 0; k < QR_TOPT; ++k) { tv[k] = -2.0; ti[k] = -1; }
+
   const int64_t nsteps = (n_rows + ROWS_IT - 1) / ROWS_IT;
   for (int64_t s = blockIdx.x; s < nsteps; s += gridDim.x) {
     const int64_t rbase = s * ROWS_IT + (wave * QR_UNR) * RPW + grp;
@@ -83,64 +109,147 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
 #pragma unroll
     for (int j = 0; j < QR_UNR; ++j) {
       const int64_t row = rbase + j * RPW;
-      f64x2 t = {0.0, 0.0};
-      if (row < n_rows) {
-        const double *rp = Ur + row * ldu;
-        if (vec_ok) {
-          if (k0 < r) t = *reinterpret_cast<const f64x2 *>(rp + k0);
-        } else {
-          if (k0 < r) t.x = rp[k0];
-          if (k0 + 1 < r) t.y = rp[k0 + 1];
-        }
-      }
-      u[j] = t;
+      u[j] = load_row_piece(Ur + row * ldu, k0, r, vec_ok, row < n_rows);
     }
 #pragma unroll
     for (int j = 0; j < QR_UNR; ++j) {
       const int64_t row = rbase + j * RPW;
-      double d = (MODE == 0) ? (u[j].x * u[j].x + u[j].y * u[j].y) : (u[j].x * q0 + u[j].y * q1);
-      d = group_sum_t<LPR>(d);
-      if (lig == 0 && row < n_rows) {
-        double v;
-        if (MODE == 0) {
-          v = d;
-        } else {
-          const double old = nrm[row];
-          v = old - d * d;
-          if (v < 0.0) v = 0.0;
-          if (old < 0.0 || row0 + row == piv) v = -1.0;  // chosen rows leave the race
+      const bool mine = (lig == 0) && (row < n_rows);
+      double v;
+      if (MODE == 0) {
+        v = group_sum_t<LPR>(u[j].x * u[j].x + u[j].y * u[j].y);
+      } else {
+        const double old = mine ? nrm[row] : 0.0;
+        v = downdate<LPR, QR_BATCH>(old, u[j], q0, q1, nq);
+        v = old < 0.0 ? -1.0 : v;
+      }
+      if (mine) nrm[row] = v;
+      // per-lane sorted top list; rows arrive in increasing index order, so "strictly greater"
+      // keeps the lowest index among equal values
+      const bool ins = mine && (v > tv[QR_TOPT - 1]);
+      if (__any(ins)) {
+        const long long gi = row0 + row;
+#pragma unroll
+        for (int k = QR_TOPT - 1; k >= 0; --k) {
+          const bool here = ins && (v > tv[k]);
+          const bool above = (k > 0) ? (v > tv[k > 0 ? k - 1 : 0]) : false;
+          const double nv = above ? tv[k > 0 ? k - 1 : 0] : v;
+          const long long ni = above ? ti[k > 0 ? k - 1 : 0] : gi;
+          tv[k] = here ? nv : tv[k];
+          ti[k] = here ? ni : ti[k];
         }
-        nrm[row] = v;
-        best.push(v, row0 + row);
       }
     }
   }
-  block_best(best, sv1, si1, sv2, part + 3 * (int64_t)blockIdx.x);
-}
-
-// one workgroup: reduce the per-block bests, emit this rank's candidate record
-__global__ __launch_bounds__(QR_THREADS) void qr_candidate_kernel(
-    const double *__restrict__ part, int n_part, const double *__restrict__ Ur, int r, int64_t ldu,
-    int64_t row0, int64_t n_rows, double *__restrict__ cand) {
-  __shared__ double sv1[QR_THREADS / 64], sv2[QR_THREADS / 64];
-  __shared__ long long si1[QR_THREADS / 64];
-  __shared__ double res[3];
-  Best b; b.init();
-  for (int p = threadIdx.x; p < n_part; p += QR_THREADS)
-    b.merge(part[3 * p], (int64_t)part[3 * p + 1], part[3 * p + 2]);
-  block_best(b, sv1, si1, sv2, res);
+  // block merge: QR_TOPT rounds of arg-max over the 256 x QR_TOPT list entries (one wave)
+#pragma unroll
+  for (int k = 0; k < QR_TOPT; ++k) {
+    sval[threadIdx.x * QR_TOPT + k] = tv[k];
+    sidx[threadIdx.x * QR_TOPT + k] = ti[k];
+  }
   __syncthreads();
-  const int64_t gi = (int64_t)res[1];
-  if (threadIdx.x == 0) { cand[0] = res[0]; cand[1] = res[1]; cand[2] = res[2]; }
-  const int64_t li = gi - row0;
-  for (int k = threadIdx.x; k < r; k += QR_THREADS)
-    cand[3 + k] = (li >= 0 && li < n_rows) ? Ur[li * ldu + k] : 0.0;
+  if (wave == 0) {
+    double *out = tops + (int64_t)blockIdx.x * QR_TOPT * 2;
+    for (int round = 0; round < QR_TOPT; ++round) {
+      double bv = -3.0; long long bi = INT64_MAX; int bp = -1;
+      for (int e = lane; e < QR_THREADS * QR_TOPT; e += 64) {
+        const double v = sval[e]; const long long i = sidx[e];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bp = e; }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o, 64);
+        const long long oi = __shfl_xor(bi, o, 64);
+        const int op = __shfl_xor(bp, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = op; }
+      }
+      if (lane == 0) {
+        out[2 * round] = bv > -2.5 ? bv : -2.0;
+        out[2 * round + 1] = (double)(bv > -2.5 ? bi : -1);
+        if (bp >= 0) sval[bp] = -3.0;
+      }
+      __builtin_amdgcn_wave_barrier();   // one wave only: LDS accesses of a wave are issued and serviced in order
+    }
+  }
 }
 
-// one workgroup: pick the winner among the ranks' candidates, orthogonalise, store q / pivot
+// grid = sweep blocks: copy each block's top rows into the compact candidate arrays
+__global__ __launch_bounds__(QR_THREADS) void qr_gather_kernel(
+    const double *__restrict__ tops, const double *__restrict__ Ur, int r, int64_t ldu, int64_t row0,
+    int64_t n_rows, int ldc, int64_t *__restrict__ cand_idx, double *__restrict__ cand_res,
+    double *__restrict__ cand_U) {
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < QR_TOPT * ldc; e += QR_THREADS) {
+    const int k = e / ldc, c = e - k * ldc;
+    const double v = tops[((int64_t)b * QR_TOPT + k) * 2];
+    const int64_t gi = (int64_t)tops[((int64_t)b * QR_TOPT + k) * 2 + 1];
+    const int64_t li = gi - row0;
+    const bool ok = v >= 0.0 && li >= 0 && li < n_rows;     // -1 (already chosen) and -2 (empty) stay out
+    const int64_t slot = (int64_t)b * QR_TOPT + k;
+    cand_U[slot * ldc + c] = (ok && c < r) ? Ur[li * ldu + c] : 0.0;
+    if (c == 0) { cand_idx[slot] = ok ? gi : -1; cand_res[slot] = ok ? v : -2.0; }
+  }
+}
+
+// one workgroup: tau = largest QR_TOPT-th value over the blocks; best / runner-up candidate -> record
+__global__ __launch_bounds__(1024) void qr_cand_best_kernel(
+    const double *__restrict__ tops, int n_blocks, const int64_t *__restrict__ cand_idx,
+    const double *__restrict__ cand_res, const double *__restrict__ cand_U, int n_cand, int r, int ldc,
+    double *__restrict__ tau, double *__restrict__ rec) {
+  __shared__ double sv1[16], sv2[16], stau[16];
+  __shared__ long long si1[16];
+  __shared__ int spos[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Best b; b.init();
+  int pos = -1;
+  for (int c = threadIdx.x; c < n_cand; c += 1024) {
+    const double v = cand_res[c]; const int64_t gi = cand_idx[c];
+    if (gi >= 0) {
+      const bool better = v > b.v1 || (v == b.v1 && gi < b.i1);
+      b.push(v, gi);
+      pos = better ? c : pos;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {  // wave reduce carrying the winner's slot
+    const double ov1 = __shfl_xor(b.v1, o, 64);
+    const long long oi1 = __shfl_xor((long long)b.i1, o, 64);
+    const double ov2 = __shfl_xor(b.v2, o, 64);
+    const int op = __shfl_xor(pos, o, 64);
+    const bool take = ov1 > b.v1 || (ov1 == b.v1 && oi1 < b.i1);
+    b.merge(ov1, oi1, ov2);
+    pos = take ? op : pos;
+  }
+  double t = -2.0;
+  if (tops)
+    for (int k = threadIdx.x; k < n_blocks; k += 1024) {
+      const double v = tops[((int64_t)k * QR_TOPT + QR_TOPT - 1) * 2];
+      t = v > t ? v : t;
+    }
+  for (int o = 32; o > 0; o >>= 1) { const double ot = __shfl_xor(t, o, 64); t = ot > t ? ot : t; }
+  if (lane == 0) { sv1[wave] = b.v1; si1[wave] = b.i1; sv2[wave] = b.v2; spos[wave] = pos; stau[wave] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Best g; g.init(); int gp = -1; double gt = -2.0;
+    for (int w = 0; w < 16; ++w) {
+      const bool take = sv1[w] > g.v1 || (sv1[w] == g.v1 && si1[w] < g.i1);
+      g.merge(sv1[w], si1[w], sv2[w]);
+      gp = take ? spos[w] : gp;
+      gt = stau[w] > gt ? stau[w] : gt;
+    }
+    rec[0] = g.v1; rec[1] = (double)g.i1; rec[2] = g.v2;
+    spos[0] = gp;
+    if (tau) *tau = gt;
+  }
+  __syncthreads();
+  const int gp = spos[0];
+  for (int k = threadIdx.x; k < r; k += 1024) rec[3 + k] = (gp >= 0) ? cand_U[(int64_t)gp * ldc + k] : 0.0;
+}
+
+// one workgroup: pick the winner among the ranks' records, certify it against tau, orthogonalise,
+// store q / pivot / flags
 __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
-    const double *__restrict__ cands, int n_cand, int r, int step, double *__restrict__ Q,
-    int64_t *__restrict__ piv, double *__restrict__ gap) {
+    const double *__restrict__ recs, int n_rec, const double *__restrict__ taus, int n_tau, int first, int r,
+    int step, double *__restrict__ Q, int64_t *__restrict__ piv, double *__restrict__ gap,
+    double *__restrict__ okflag) {
   __shared__ double v[SPR_MAX_R], c[SPR_MAX_R];
   __shared__ double red[QR_THREADS / 64];
   __shared__ int win;
@@ -148,20 +257,23 @@ __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
   const int stride = r + 3;
   if (threadIdx.x == 0) {
     int w = 0;
-    for (int i = 1; i < n_cand; ++i) {
-      const double vi = cands[(int64_t)i * stride], vw = cands[(int64_t)w * stride];
-      if (vi > vw || (vi == vw && cands[(int64_t)i * stride + 1] < cands[(int64_t)w * stride + 1])) w = i;
+    for (int i = 1; i < n_rec; ++i) {
+      const double vi = recs[(int64_t)i * stride], vw = recs[(int64_t)w * stride];
+      if (vi > vw || (vi == vw && recs[(int64_t)i * stride + 1] < recs[(int64_t)w * stride + 1])) w = i;
     }
     win = w;
-    const double bestv = cands[(int64_t)w * stride];
-    double second = cands[(int64_t)w * stride + 2];
-    for (int i = 0; i < n_cand; ++i)
-      if (i != w && cands[(int64_t)i * stride] > second) second = cands[(int64_t)i * stride];
-    piv[step] = (int64_t)cands[(int64_t)w * stride + 1];
-    if (gap) gap[step] = (bestv > 0.0) ? (bestv - second) / bestv : 0.0;
+    const double bestv = recs[(int64_t)w * stride];
+    double second = recs[(int64_t)w * stride + 2];
+    for (int i = 0; i < n_rec; ++i)
+      if (i != w && recs[(int64_t)i * stride] > second) second = recs[(int64_t)i * stride];
+    double tau = -2.0;
+    for (int i = 0; i < n_tau; ++i) tau = taus[i] > tau ? taus[i] : tau;
+    piv[step] = (int64_t)recs[(int64_t)w * stride + 1];
+    if (gap) gap[step] = (bestv > 0.0) ? (bestv - second) / bestv : 0.0;   // candidates only: a lower bound on rivals
+    okflag[step] = (first || bestv > tau) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const double *row = cands + (int64_t)win * stride + 3;
+  const double *row = recs + (int64_t)win * stride + 3;
   for (int k = threadIdx.x; k < r; k += QR_THREADS) v[k] = row[k];
   __syncthreads();
   for (int pass = 0; pass < 2; ++pass) {
@@ -190,6 +302,43 @@ __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
   for (int k = threadIdx.x; k < r; k += QR_THREADS) Q[(int64_t)step * r + k] = v[k] * inv;
 }
 
+// candidate residuals <- down-dated by direction q; the pivot's own slot leaves the race
+template <int LPR>
+__global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
+    const double *__restrict__ cand_U, int n_cand, int r, int ldc, const int64_t *__restrict__ cand_idx,
+    const double *__restrict__ q, const int64_t *__restrict__ piv_ptr, double *__restrict__ cand_res) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / LPR, lig = lane % LPR;
+  const int k0 = 2 * lig;
+  double q0[1], q1[1];
+  q0[0] = (k0 < r) ? q[k0] : 0.0;
+  q1[0] = (k0 + 1 < r) ? q[k0 + 1] : 0.0;
+  const int64_t piv = *piv_ptr;
+  const int stride = gridDim.x * (QR_THREADS / 64) * RPW;
+  for (int c0 = (blockIdx.x * (QR_THREADS / 64) + wave) * RPW; c0 < n_cand; c0 += stride) {
+    const int c = c0 + grp;
+    const bool valid = c < n_cand;
+    const f64x2 u = load_row_piece(cand_U + (int64_t)(valid ? c : 0) * ldc, k0, r, true, valid);
+    const double old = (valid && lig == 0) ? cand_res[c] : 0.0;
+    double v = downdate<LPR, 1>(old, u, q0, q1, 1);
+    if (valid && lig == 0) {
+      if (old < 0.0) v = old;
+      if (cand_idx[c] == piv) v = -1.0;
+      cand_res[c] = v;
+    }
+  }
+}
+
+__global__ void qr_mark_kernel(const int64_t *__restrict__ piv, int n, int64_t row0, int64_t n_rows,
+                               double *__restrict__ nrm) {
+  const int t = threadIdx.x;
+  if (t < n) {
+    const int64_t li = piv[t] - row0;
+    if (li >= 0 && li < n_rows) nrm[li] = -1.0;
+  }
+}
+
 __global__ void mask_rows_kernel(double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu,
                                  const uint8_t *__restrict__ mask) {
   const int64_t total = n_rows * r;
@@ -200,15 +349,6 @@ __global__ void mask_rows_kernel(double *__restrict__ Ur, int64_t n_rows, int r,
   }
 }
 
-int sweep_grid(int64_t n_rows, int lpr) {
-  const int rows_it = (QR_THREADS / 64) * (64 / lpr) * QR_UNR;
-  int64_t steps = (n_rows + rows_it - 1) / rows_it;
-  const int cus = spr_cached_cus();
-  int64_t cap = 8LL * (cus > 0 ? cus : 256);
-  if (cap > QR_MAX_PART) cap = QR_MAX_PART;
-  return (int)(steps < cap ? steps : cap);
-}
-
 int pick_lpr(int r) {
   const int half = (r + 1) / 2;
   int l = 1;
@@ -216,10 +356,38 @@ int pick_lpr(int r) {
   return l;
 }
 
+int sweep_grid(int64_t n_rows, int lpr) {
+  const int rows_it = (QR_THREADS / 64) * (64 / lpr) * QR_UNR;
+  int64_t steps = (n_rows + rows_it - 1) / rows_it;
+  const int cus = spr_cached_cus();
+  int64_t cap = 4LL * (cus > 0 ? cus : 256);
+  if (cap > QR_MAX_BLOCKS) cap = QR_MAX_BLOCKS;
+  return (int)(steps < cap ? steps : cap);
+}
+
+// workspace carve-up
+struct QrWs {
+  double *tops;       // [QR_MAX_BLOCKS][QR_TOPT][2]
+  int64_t *cand_idx;  // [NC]
+  double *cand_res;   // [NC]
+  double *cand_U;     // [NC][<= SPR_MAX_R]
+  double *tau;        // [1]
+  static constexpr int64_t NC = (int64_t)QR_MAX_BLOCKS * QR_TOPT;
+  static size_t bytes() { return sizeof(double) * ((size_t)NC * 2 + NC * 2 + NC * SPR_MAX_R + 8); }
+  explicit QrWs(void *p) {
+    double *d = static_cast<double *>(p);
+    tops = d; d += NC * 2;
+    cand_idx = reinterpret_cast<int64_t *>(d); d += NC;
+    cand_res = d; d += NC;
+    cand_U = d; d += NC * SPR_MAX_R;
+    tau = d;
+  }
+};
+
 template <int MODE>
 int launch_sweep(int lpr, int grid, hipStream_t st, const double *Ur, int64_t n_rows, int r, int64_t ldu,
-                 int vec_ok, int64_t row0, const double *q, const int64_t *piv, double *nrm, double *part) {
-#define SW(L) hipLaunchKernelGGL((qr_sweep_kernel<L, MODE>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, vec_ok, row0, q, piv, nrm, part); break
+                 int vec_ok, int64_t row0, const double *Q, int nq, double *nrm, double *tops) {
+#define SW(L) hipLaunchKernelGGL((qr_sweep_kernel<L, MODE>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, vec_ok, row0, Q, nq, nrm, tops); break
   switch (lpr) {
     case 1: SW(1);
     case 2: SW(2);
@@ -242,12 +410,27 @@ int check_ur(const char *who, const double *Ur, int64_t n_rows, int32_t r, int64
   return SPR_OK;
 }
 
+// candidates from the last sweep's block tops + this rank's record and tau
+int build_candidates(const QrWs &w, int grid, const double *Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
+                     double *rec, double *tau_out, hipStream_t st) {
+  const int ldc = r + (r & 1);
+  hipLaunchKernelGGL(qr_gather_kernel, dim3(grid), dim3(QR_THREADS), 0, st, w.tops, Ur, r, ldu, row0, n_rows, ldc,
+                     w.cand_idx, w.cand_res, w.cand_U);
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, w.tops, grid, w.cand_idx, w.cand_res,
+                     w.cand_U, grid * QR_TOPT, r, ldc, tau_out, rec);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
 }  // namespace
 
 extern "C" size_t spr_qr_workspace(int64_t n_rows) {
   (void)n_rows;
-  return (size_t)QR_MAX_PART * 3 * sizeof(double);
+  return QrWs::bytes();
 }
+
+extern "C" int32_t spr_qr_batch(void) { return QR_BATCH; }
 
 extern "C" int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, const uint8_t *d_mask,
                                  void *stream) {
@@ -264,47 +447,75 @@ extern "C" int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_
 }
 
 extern "C" int spr_qr_init_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
-                               double *d_nrm, double *d_cand, void *d_workspace, size_t workspace_bytes,
-                               void *stream) {
+                               double *d_nrm, double *d_rec, double *d_tau, void *d_workspace,
+                               size_t workspace_bytes, void *stream) {
   int rc = check_ur("spr_qr_init_f64", d_Ur, n_rows, r, ldu);
   if (rc != SPR_OK) return rc;
-  SPR_REQUIRE(d_nrm && d_cand && d_workspace, SPR_E_INVALID, "spr_qr_init_f64: NULL pointer");
-  SPR_REQUIRE(workspace_bytes >= spr_qr_workspace(n_rows), SPR_E_WORKSPACE, "spr_qr_init_f64: workspace too small");
+  SPR_REQUIRE(d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "spr_qr_init_f64: NULL pointer");
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "spr_qr_init_f64: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & 15) == 0);
-  double *part = static_cast<double *>(d_workspace);
-  rc = launch_sweep<0>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, nullptr, d_nrm, part);
+  QrWs w(d_workspace);
+  rc = launch_sweep<0>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, 0, d_nrm, w.tops);
   if (rc != SPR_OK) return rc;
-  hipLaunchKernelGGL(qr_candidate_kernel, dim3(1), dim3(QR_THREADS), 0, st, part, grid, d_Ur, (int)r, ldu, row0,
-                     n_rows, d_cand);
+  return build_candidates(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
+}
+
+extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_recs, int32_t n_rec,
+                               const double *d_taus, int32_t n_tau, int32_t first, double *d_Q, int64_t *d_piv,
+                               double *d_gap, double *d_ok, double *d_rec, void *d_workspace,
+                               size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_recs && d_taus && d_Q && d_piv && d_ok && d_rec && d_workspace, SPR_E_INVALID,
+              "spr_qr_step_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && r > 0 && r <= SPR_MAX_R && step >= 0 && step < r && n_rec >= 1 && n_tau >= 1,
+              SPR_E_INVALID, "spr_qr_step_f64: bad r=%d step=%d n_rec=%d", r, step, n_rec);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "spr_qr_step_f64: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  QrWs w(d_workspace);
+  const int lpr = pick_lpr(r);
+  const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows, lpr) * QR_TOPT;
+  hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_recs, (int)n_rec, d_taus, (int)n_tau,
+                     (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok);
+  SPR_LAUNCH_CHECK();
+  const int rows_per_block = (QR_THREADS / 64) * (64 / lpr);
+  int grid = (n_cand + rows_per_block - 1) / rows_per_block;
+  if (grid > 256) grid = 256;
+#define CD(L) hipLaunchKernelGGL(qr_cand_downdate_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q + (int64_t)step * r, d_piv + step, w.cand_res); break
+  switch (lpr) {
+    case 1: CD(1);
+    case 2: CD(2);
+    case 4: CD(4);
+    case 8: CD(8);
+    case 16: CD(16);
+    case 32: CD(32);
+    default: CD(64);
+  }
+#undef CD
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, (const double *)nullptr, 0, w.cand_idx,
+                     w.cand_res, w.cand_U, n_cand, (int)r, ldc, (double *)nullptr, d_rec);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
 
-extern "C" int spr_qr_step_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
-                               int32_t step, const double *d_cands, int32_t n_cand, double *d_Q, int64_t *d_piv,
-                               double *d_nrm, double *d_cand, double *d_gap, void *d_workspace,
-                               size_t workspace_bytes, void *stream) {
-  int rc = check_ur("spr_qr_step_f64", d_Ur, n_rows, r, ldu);
+extern "C" int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                  const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq, double *d_nrm,
+                                  double *d_rec, double *d_tau, void *d_workspace, size_t workspace_bytes,
+                                  void *stream) {
+  int rc = check_ur("spr_qr_refresh_f64", d_Ur, n_rows, r, ldu);
   if (rc != SPR_OK) return rc;
-  SPR_REQUIRE(d_cands && d_Q && d_piv && d_nrm && d_cand && d_workspace, SPR_E_INVALID,
-              "spr_qr_step_f64: NULL pointer");
-  SPR_REQUIRE(step >= 0 && step < r && n_cand >= 1, SPR_E_INVALID, "spr_qr_step_f64: bad step=%d n_cand=%d", step,
-              n_cand);
-  SPR_REQUIRE(workspace_bytes >= spr_qr_workspace(n_rows), SPR_E_WORKSPACE, "spr_qr_step_f64: workspace too small");
+  SPR_REQUIRE(d_Q && d_piv && d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "spr_qr_refresh_f64: NULL pointer");
+  SPR_REQUIRE(j0 >= 0 && nq >= 1 && nq <= QR_BATCH && j0 + nq <= r, SPR_E_INVALID,
+              "spr_qr_refresh_f64: bad j0=%d nq=%d", j0, nq);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "spr_qr_refresh_f64: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & 15) == 0);
-  double *part = static_cast<double *>(d_workspace);
-  hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_cands, (int)n_cand, (int)r, (int)step,
-                     d_Q, d_piv, d_gap);
+  QrWs w(d_workspace);
+  hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + j0, (int)nq, row0, n_rows, d_nrm);
   SPR_LAUNCH_CHECK();
-  rc = launch_sweep<1>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, d_Q + (int64_t)step * r, d_piv + step,
-                       d_nrm, part);
+  rc = launch_sweep<2>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, d_Q + (int64_t)j0 * r, nq, d_nrm, w.tops);
   if (rc != SPR_OK) return rc;
-  hipLaunchKernelGGL(qr_candidate_kernel, dim3(1), dim3(QR_THREADS), 0, st, part, grid, d_Ur, (int)r, ldu, row0,
-                     n_rows, d_cand);
-  SPR_LAUNCH_CHECK();
-  return SPR_OK;
+  return build_candidates(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
 }

@@ -165,24 +165,37 @@ class HipEngine:
         _lib.check(self.lib.spr_mask_rows_f64(_ptr(Ur), n, r, ldu, _ptr(mask_u8), self._stream()),
                    'spr_mask_rows_f64')
 
+    @property
+    def qr_batch(self):
+        return int(self.lib.spr_qr_batch())
+
     def qr_begin(self, Ur, row0, n_steps):
-        """Allocate the pivoting state and compute the initial norms / local candidate."""
+        """Allocate the pivoting state; initial norms, candidate set, local record and tau."""
         n, r, ldu = self._check_matrix(Ur)
         t = self.torch
         st = dict(Ur=Ur, n=n, r=r, ldu=ldu, row0=row0,
-                  nrm=self.empty((n,)), cand=self.empty((r + 3,)), Q=self.zeros((n_steps, r)),
-                  piv=self.zeros((n_steps,), dtype=t.int64), gap=self.zeros((n_steps,)),
+                  nrm=self.empty((n,)), rec=self.empty((r + 3,)), tau=self.empty((1,)),
+                  Q=self.zeros((n_steps, r)), piv=self.zeros((n_steps,), dtype=t.int64),
+                  gap=self.zeros((n_steps,)), ok=self.zeros((n_steps,)),
                   ws=self._workspace('qr', self.lib.spr_qr_workspace(n)))
-        _lib.check(self.lib.spr_qr_init_f64(_ptr(Ur), n, r, ldu, row0, _ptr(st['nrm']), _ptr(st['cand']),
-                                            _ptr(st['ws']), st['ws'].numel(), self._stream()), 'spr_qr_init_f64')
+        _lib.check(self.lib.spr_qr_init_f64(_ptr(Ur), n, r, ldu, row0, _ptr(st['nrm']), _ptr(st['rec']),
+                                            _ptr(st['tau']), _ptr(st['ws']), st['ws'].numel(), self._stream()),
+                   'spr_qr_init_f64')
         return st
 
-    def qr_step(self, st, step, cands):
-        """cands: (n_cand, r+3) tensor of the ranks' candidate records (st['cand'][None] on one GPU)."""
-        _lib.check(self.lib.spr_qr_step_f64(_ptr(st['Ur']), st['n'], st['r'], st['ldu'], st['row0'], step,
-                                            _ptr(cands), cands.shape[0], _ptr(st['Q']), _ptr(st['piv']),
-                                            _ptr(st['nrm']), _ptr(st['cand']), _ptr(st['gap']), _ptr(st['ws']),
+    def qr_step(self, st, step, recs, taus, first):
+        """recs: (n_rank, r+3) records, taus: (n_rank, 1); one candidate-set step (see spr_hip.h)."""
+        _lib.check(self.lib.spr_qr_step_f64(st['n'], st['r'], step, _ptr(recs), recs.shape[0], _ptr(taus),
+                                            taus.numel(), int(bool(first)), _ptr(st['Q']), _ptr(st['piv']),
+                                            _ptr(st['gap']), _ptr(st['ok']), _ptr(st['rec']), _ptr(st['ws']),
                                             st['ws'].numel(), self._stream()), 'spr_qr_step_f64')
+
+    def qr_refresh(self, st, j0, nq):
+        """Apply the accepted directions Q[j0:j0+nq] to every row, redraw candidates / record / tau."""
+        _lib.check(self.lib.spr_qr_refresh_f64(_ptr(st['Ur']), st['n'], st['r'], st['ldu'], st['row0'],
+                                               _ptr(st['Q']), _ptr(st['piv']), j0, nq, _ptr(st['nrm']),
+                                               _ptr(st['rec']), _ptr(st['tau']), _ptr(st['ws']),
+                                               st['ws'].numel(), self._stream()), 'spr_qr_refresh_f64')
 
     # ---- K7 + K8 -------------------------------------------------------------------------------
     def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean):

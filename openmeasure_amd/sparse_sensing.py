@@ -125,6 +125,26 @@ def _eigh_small(G):
         return np.linalg.eigh(G)
 
 
+def pivot_loop(eng, st, s, all_gather=lambda t: t[None]):
+    """Host driver of the candidate-set pivoting (include/spr_hip.h, K6): batches of certified
+    steps on the candidate set, one full sweep per batch.  Returns the number of sweeps over Ur."""
+    j, sweeps = 0, 1
+    while j < s:
+        nb = min(eng.qr_batch, s - j)
+        taus = all_gather(st['tau'])
+        for t in range(nb):                                   # steps on the candidate set, no host sync
+            eng.qr_step(st, j + t, all_gather(st['rec']), taus, first=(t == 0))
+        ok = eng.to_host(st['ok'][j:j + nb])                   # one sync per batch
+        k = nb if ok.all() else int(np.argmin(ok))             # certified prefix (>= 1 by construction)
+        if k < 1:
+            raise RuntimeError('optimal_placement: first step after a sweep was not certified')
+        j += k
+        if j < s:
+            eng.qr_refresh(st, j - k, k)
+            sweeps += 1
+    return sweeps
+
+
 def _sign_fix(V):
     """Deterministic eigenvector signs: the entry of largest magnitude is positive."""
     idx = np.argmax(np.abs(V), axis=0)
@@ -469,8 +489,8 @@ class SPR(ROM):
             self._host.pop('Ur', None)
         s = self.r
         st = eng.qr_begin(Ur_d, self._row0, s)
-        for j in range(s):
-            eng.qr_step(st, j, self._all_gather(st['cand']))
+        sweeps = pivot_loop(eng, st, s, self._all_gather)
+        self.pivot_sweeps_ = sweeps
         piv = eng.to_host(st['piv']).astype(np.int64)
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])

@@ -79,30 +79,34 @@ class NumpyEngine:
     def mask_rows(self, Ur, mask_u8):
         Ur[mask_u8 == 0, :] = 0.0
 
-    def _candidate(self, st):
+    qr_batch = 8
+
+    def _record(self, st):
         nrm = st['nrm'].numpy()
         i = int(np.argmax(nrm))                      # first index on ties
         second = np.partition(nrm, -2)[-2] if nrm.size > 1 else -2.0
-        cand = np.concatenate([[nrm[i], st['row0'] + i, second], st['Ur'].numpy()[i]])
-        st['cand'] = torch.from_numpy(cand)
+        st['rec'] = torch.from_numpy(np.concatenate([[nrm[i], st['row0'] + i, second], st['Ur'].numpy()[i]]))
 
     def qr_begin(self, Ur, row0, n_steps):
         n, r = Ur.shape
         st = dict(Ur=Ur, n=n, r=r, row0=row0, nrm=torch.from_numpy((Ur.numpy() ** 2).sum(axis=1)),
                   Q=torch.zeros((n_steps, r), dtype=torch.float64),
                   piv=torch.zeros((n_steps,), dtype=torch.int64),
-                  gap=torch.zeros((n_steps,), dtype=torch.float64))
-        self._candidate(st)
+                  gap=torch.zeros((n_steps,), dtype=torch.float64),
+                  ok=torch.zeros((n_steps,), dtype=torch.float64),
+                  tau=torch.full((1,), -2.0, dtype=torch.float64))   # every row is a candidate here
+        self._record(st)
         return st
 
-    def qr_step(self, st, step, cands):
-        c = cands.numpy()
+    def qr_step(self, st, step, recs, taus, first):
+        c = recs.numpy()
         order = np.lexsort((c[:, 1], -c[:, 0]))      # max value, then lowest index
         w = order[0]
         piv = int(c[w, 1])
         st['piv'][step] = piv
         others = [c[w, 2]] + [c[i, 0] for i in range(c.shape[0]) if i != w]
         st['gap'][step] = (c[w, 0] - max(others)) / c[w, 0] if c[w, 0] > 0 else 0.0
+        st['ok'][step] = 1.0 if (first or c[w, 0] > float(taus.max())) else 0.0
         v = c[w, 3:].copy()
         Q = st['Q'].numpy()
         for _ in range(2):
@@ -118,7 +122,10 @@ class NumpyEngine:
         if 0 <= li < st['n']:
             new[li] = -1.0
         nrm[:] = new
-        self._candidate(st)
+        self._record(st)
+
+    def qr_refresh(self, st, j0, nq):
+        pass                                         # the model down-dates every row at every step
 
     # K7 + K8
     def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean):

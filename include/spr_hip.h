@@ -71,11 +71,13 @@ int spr_stats_gram_finalize_f64(int64_t n_rows, int32_t m, int64_t row0, int64_t
 
 /* ---- K4 : basis projection  Ur = X0 . W,  W = V_r Sigma_r^-1 (m x r) ----------------
  * Replaces the U factor of np.linalg.svd (:272) and the truncation U[:, :r] (:336).
- * Second read of X; centring is recomputed from the row itself and the per-feature
- * 1/X_scl (d_inv_scale[n_features]) is applied in the epilogue, so X0 never exists. */
+ * Second read of X.  center = 1: d_rowmean (the row means written by spr_stats_gram_f64)
+ * is removed in the epilogue as x.W - mean*(1^T W); the per-feature 1/X_scl
+ * (d_inv_scale[n_features]) is applied there too, so X0 never exists.  center = 0:
+ * rows are used as they are (d_rowmean may be NULL). */
 int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx,
                     int64_t row0, int64_t n_points, int32_t n_features, int32_t center,
-                    const double *d_inv_scale, const double *d_W, int32_t r,
+                    const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
                     double *d_Ur, int64_t ldu, void *stream);
 
 /* ---- K2 / K11 as stand-alone calls (ROM.scale_data's return value, ROM.unscale_data) --

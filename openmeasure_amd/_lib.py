@@ -33,7 +33,7 @@ PROTOTYPES = {
     'spr_stats_gram_workspace': (_sz, [_i32, _i32]),
     'spr_stats_gram_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),
     'spr_stats_gram_finalize_f64': (C.c_int, [_i64, _i32, _i64, _i64, _i32, _p, _sz, _p, _p, _p]),
-    'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _i32, _p, _i64, _p]),
+    'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
     'spr_scale_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
     'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
     'spr_reconstruct_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),

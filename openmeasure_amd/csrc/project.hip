@@ -1,8 +1,15 @@
 // K4: basis projection  Ur = ((X - rowmean) . W) * (1/X_scl),  W = V_r Sigma_r^-1  (m x r).
 //
 // Second (and last) read of the snapshot shard.  Same persistent-workgroup / row-panel
-// staging as the Gram kernel (rowtile.hpp); the centred panel goes to LDS, W lives in
-// registers for the whole kernel: wave (cg, rg) keeps the MFMA B fragments of output
+// staging as the Gram kernel (rowtile.hpp), but the panel goes to LDS RAW: VALU work does
+// not overlap with v_mfma_f64 on gfx950 (tools/coexec_probe.hip: time = MFMA + VALU), so the
+// centring is folded into the epilogue instead,
+//     (x_i - mu_i 1) . W = x_i . W - mu_i * (1^T W),
+// with mu_i read back from the row-mean array of the Gram pass (8 bytes per row) and the
+// column sums of W formed once per wave.  The products x_i . W carry the row mean through the
+// MFMA, so the result is accurate to eps * |mu|/|x - mu| * sqrt(m) relative -- the same order
+// as the reference's own X0 = X - mean (whose mean is only known to eps * |mu|).
+// W lives in registers for the whole kernel: wave (cg, rg) keeps the MFMA B fragments of output
 // columns [16 cg, 16 cg + 16) for every k (m/4 doubles per lane) and multiplies them with
 // the 16-row blocks rg, rg+RG, ... of each panel.
 //
@@ -33,7 +40,7 @@ template <int MT> struct ProjRows { static constexpr int R = (MT >= 12) ? 32 : 6
 template <int MT, int RTILES, bool VEC>
 __global__ __launch_bounds__(NW * 64) void project_kernel(
     const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
-    const double *__restrict__ inv_scale, const double *__restrict__ W, int r,
+    const double *__restrict__ inv_scale, const double *__restrict__ rowmean, const double *__restrict__ W, int r,
     double *__restrict__ Ur, int64_t ldu) {
   constexpr int R = ProjRows<MT>::R;
   constexpr int MPAD = 16 * MT, MP = MPAD + PROJ_PAD;
@@ -64,6 +71,14 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(bfrag[ks]));  // pin: never re-load W inside the loop
   }
+  // column sum of W for this lane's output column (centring term), 0 when the rows are used as they are
+  double wbar = 0.0;
+  if (center_i != 0) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) wbar += bfrag[ks];
+    wbar += __shfl_xor(wbar, 16, 64);
+    wbar += __shfl_xor(wbar, 32, 64);
+  }
 
   // Same one-barrier software pipeline as the Gram kernel: the MFMAs of panel c run from one
   // LDS buffer while this wave centres panel c+1 into the other buffer (one row pass per slice
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
   const int64_t nchunks = (hi - lo + R - 1) / R;
   int64_t c = wl;
   tile.template load<VEC>(X, ldx, m, lo + c * R, hi, wave, lane);
-  tile.template center_store<false>(lds[0], m, center_i != 0, lo + c * R, hi, wave, lane, nullptr, nullptr);
+  tile.raw_store(lds[0], m, lo + c * R, hi, wave, lane);
   int64_t cn = c + wpf;
   int64_t nrow0 = (cn < nchunks) ? lo + cn * R : hi;
   tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane);
@@ -81,6 +96,7 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
   const int col = cg * 16 + (lane & 15);
   constexpr int NRB = (RB + RG - 1) / RG;           // row blocks per wave and panel (upper bound)
   constexpr int SLOTS = NRB * KSTEPS;               // MFMAs per wave and panel
+  constexpr int NPIECE = RT::IT * RT::VPL;          // 16-byte pieces per lane and panel
   while (c < nchunks) {
     double *cur = lds[buf];
     double *nxt = lds[buf ^ 1];
@@ -100,20 +116,21 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
           else acc0 = PROJ_MFMA(p[4 * ks], bfrag[ks], acc0);
         }
 #pragma clang loop unroll(full)
-        for (int it = 0; it < RT::IT; ++it)
-          if (PROJ_ABLATE != 2 && (it * SLOTS) / RT::IT == b * KSTEPS + ks) {
-            tile.template center_store_pass<false>(it, nxt, m, center_i != 0, nrow0, hi, wave, lane, nullptr, nullptr);
-            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane);
+        for (int pc = 0; pc < NPIECE; ++pc)        // piece pc = (pass, 16-byte piece): LDS store, then reload
+          if (PROJ_ABLATE != 2 && (pc * SLOTS) / NPIECE == b * KSTEPS + ks) {
+            tile.raw_store_piece(pc / RT::VPL, pc % RT::VPL, nxt, m, nrow0, hi, wave, lane);
+            tile.template load_piece<VEC>(pc / RT::VPL, pc % RT::VPL, X, ldx, m, n2row0, hi, wave, lane);
           }
       }
       if (live) {
         const int64_t row = lo + c * R + rb * 16 + (lane >> 4);
         if (PROJ_ABLATE == 3) asm volatile("" ::"v"(acc0.x + acc1.x), "v"(acc0.y + acc1.y), "v"(acc0.z + acc1.z), "v"(acc0.w + acc1.w));
         if (PROJ_ABLATE != 3 && col < r) {
-          if (row < hi) Ur[row * ldu + col] = (acc0.x + acc1.x) * isc;
-          if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (acc0.y + acc1.y) * isc;
-          if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (acc0.z + acc1.z) * isc;
-          if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (acc0.w + acc1.w) * isc;
+          const double s0 = acc0.x + acc1.x, s1 = acc0.y + acc1.y, s2 = acc0.z + acc1.z, s3 = acc0.w + acc1.w;
+          if (row < hi) Ur[row * ldu + col] = (s0 - rowmean[row] * wbar) * isc;
+          if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (s1 - rowmean[row + 4] * wbar) * isc;
+          if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (s2 - rowmean[row + 8] * wbar) * isc;
+          if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (s3 - rowmean[row + 12] * wbar) * isc;
         }
       }
     }
@@ -126,8 +143,8 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
 
 template <int MT, int RTILES>
 int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
-           int32_t n_features, int center, const double *inv_scale, const double *W, int32_t r, double *Ur, int64_t ldu,
-           hipStream_t st) {
+           int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
+           double *Ur, int64_t ldu, hipStream_t st) {
   static int total_wg = 0;
   if (!total_wg) {
     int per_cu = 0;
@@ -145,23 +162,23 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   if (vec_ok)
     hipLaunchKernelGGL((project_kernel<MT, RTILES, true>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center,
-                       plan, inv_scale, W, (int)r, Ur, ldu);
+                       plan, inv_scale, rowmean, W, (int)r, Ur, ldu);
   else
     hipLaunchKernelGGL((project_kernel<MT, RTILES, false>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center,
-                       plan, inv_scale, W, (int)r, Ur, ldu);
+                       plan, inv_scale, rowmean, W, (int)r, Ur, ldu);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
 
 template <int MT>
 int launch_rt(int rt, const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
-              int32_t n_features, int center, const double *inv_scale, const double *W, int32_t r, double *Ur, int64_t ldu,
-              hipStream_t st) {
+              int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
+              double *Ur, int64_t ldu, hipStream_t st) {
   switch (rt) {
-    case 1: return launch<MT, 1>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, W, r, Ur, ldu, st);
-    case 2: return launch<MT, 2>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, W, r, Ur, ldu, st);
-    case 4: return launch<MT, 4>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, W, r, Ur, ldu, st);
-    case 8: return launch<MT, 8>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, W, r, Ur, ldu, st);
+    case 1: return launch<MT, 1>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
+    case 2: return launch<MT, 2>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
+    case 4: return launch<MT, 4>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
+    case 8: return launch<MT, 8>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
   }
   spr_set_error("spr_project_f64: r tile count %d not built", rt);
   return SPR_E_UNSUPPORTED;
@@ -171,8 +188,10 @@ int launch_rt(int rt, const double *X, int64_t n_rows, int32_t m, int64_t ldx, i
 
 extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                                int64_t n_points, int32_t n_features, int32_t center,
-                               const double *d_inv_scale, const double *d_W, int32_t r, double *d_Ur, int64_t ldu, void *stream) {
-  SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur, SPR_E_INVALID, "spr_project_f64: NULL pointer");
+                               const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
+                               double *d_Ur, int64_t ldu, void *stream) {
+  SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && (d_rowmean || !center), SPR_E_INVALID,
+              "spr_project_f64: NULL pointer");
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "spr_project_f64: bad shape");
   SPR_REQUIRE(r > 0 && r <= m && ldu >= r, SPR_E_INVALID, "spr_project_f64: bad r=%d (m=%d ldu=%lld)", r, m,
               (long long)ldu);
@@ -183,7 +202,7 @@ extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int
   const int need = (r + 15) / 16;
   const int rt = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define PJ(MTV) return launch_rt<MTV>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_W, r, d_Ur, ldu, st)
+#define PJ(MTV) return launch_rt<MTV>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, st)
   switch (spr_round_mt(m)) {
     case 1: PJ(1);
     case 2: PJ(2);

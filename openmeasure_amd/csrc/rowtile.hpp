@@ -80,6 +80,43 @@ struct RowTile {
     }
   }
 
+  // one 16-byte piece (it, v) of a pass: lets a consumer spread the HBM requests of the next
+  // panel over its whole MFMA phase instead of issuing them in one burst
+  template <bool VEC>
+  __device__ inline void load_piece(int it, int v, const double *__restrict__ X, int64_t ldx, int m, int64_t crow0,
+                                    int64_t seg_hi, int wave, int lane) {
+    const int grp = lane / LPR, lig = lane % LPR;
+    int64_t lrow = crow0 + it * ROWS_PER_IT + wave * RPW + grp;
+    lrow = lrow < seg_hi ? lrow : seg_hi - 1;
+    const double *rp = X + lrow * ldx;
+    const int col = 2 * (lig + v * LPR);
+    f64x2 t;
+    if (VEC) {
+      t = *reinterpret_cast<const f64x2 *>(rp + (col < m ? col : 0));
+    } else {
+      t.x = rp[col < m ? col : 0];
+      t.y = rp[col + 1 < m ? col + 1 : 0];
+    }
+    pre[it][v] = t;
+  }
+
+  __device__ inline void raw_store_piece(int it, int v, double *__restrict__ lds, int m, int64_t crow0,
+                                         int64_t seg_hi, int wave, int lane) {
+    const int grp = lane / LPR, lig = lane % LPR;
+    const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
+    const bool rv = crow0 + rloc < seg_hi;
+    const int col = 2 * (lig + v * LPR);
+    f64x2 c = pre[it][v];
+    c.x = (rv && col < m) ? c.x : 0.0;
+    c.y = (rv && col + 1 < m) ? c.y : 0.0;
+    if constexpr (WIDE_STORE) {
+      *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
+    } else {
+      lds[rloc * MP + col] = c.x;
+      lds[rloc * MP + col + 1] = c.y;
+    }
+  }
+
   template <bool VEC>
   __device__ inline void load(const double *__restrict__ X, int64_t ldx, int m, int64_t crow0, int64_t seg_hi,
                               int wave, int lane) {
@@ -149,6 +186,37 @@ struct RowTile {
         lds[rloc * MP + col + 1] = c.y;
       }
     }
+  }
+
+  // one pass of registers -> LDS without centring (the consumer removes the row mean
+  // algebraically); invalid rows / padded columns are written as zeros
+  __device__ inline void raw_store_pass(int it, double *__restrict__ lds, int m, int64_t crow0, int64_t seg_hi,
+                                        int wave, int lane) {
+    const int grp = lane / LPR, lig = lane % LPR;
+    const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
+    const bool rv = crow0 + rloc < seg_hi;
+    const bool fast = (crow0 + (it + 1) * ROWS_PER_IT <= seg_hi) && (m == MPAD);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int col = 2 * (lig + v * LPR);
+      f64x2 c = pre[it][v];
+      if (!fast) {
+        c.x = (rv && col < m) ? c.x : 0.0;
+        c.y = (rv && col + 1 < m) ? c.y : 0.0;
+      }
+      if constexpr (WIDE_STORE) {
+        *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
+      } else {
+        lds[rloc * MP + col] = c.x;
+        lds[rloc * MP + col + 1] = c.y;
+      }
+    }
+  }
+
+  __device__ inline void raw_store(double *__restrict__ lds, int m, int64_t crow0, int64_t seg_hi, int wave,
+                                   int lane) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) raw_store_pass(it, lds, m, crow0, seg_hi, wave, lane);
   }
 
   template <bool WRITE_MEAN>

@@ -109,9 +109,12 @@ class HipEngine:
         return rowmean, fstats, gram
 
     # ---- K4 --------------------------------------------------------------------------------
-    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None):
+    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
         """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even.
-        ``out``: a previous result of the same shape to overwrite (keeps one basis buffer alive)."""
+        ``out``: a previous result of the same shape to overwrite (keeps one basis buffer alive).
+        ``rowmean``: the row means from stats_gram (required when center=True)."""
+        if center and rowmean is None:
+            raise ValueError('project(center=True) needs the row means of the Gram pass')
         n, m, ld = self._check_matrix(X)
         r = W.shape[1]
         ldu = r + (r & 1)
@@ -123,7 +126,8 @@ class HipEngine:
         tic, toc = self._timed('project')
         tic()
         _lib.check(self.lib.spr_project_f64(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
-                                            _ptr(inv_scale), _ptr(W.contiguous()), r, _ptr(buf), ldu,
+                                            _ptr(inv_scale), _ptr(rowmean) if center else None, _ptr(W.contiguous()), r,
+                                            _ptr(buf), ldu,
                                             self._stream()), 'spr_project_f64')
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf

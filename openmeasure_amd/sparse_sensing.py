@@ -380,10 +380,10 @@ class ROM:
         S_safe = np.maximum(S[:r], floor if floor > 0 else 1.0)
         W = V[:, :r] / S_safe
         Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, eng.to_device(W),
-                           center=center, out=self._d.pop('Ur', None))
+                           center=center, out=self._d.pop('Ur', None), rowmean=self._d.get('rowmean'))
         self._trace.mark('project')
         Ar = V[:, :r] * S[:r]                                # A = (diag(S) Vt).T  (:273)
-        return Ur_d, Ar, exp_variance[:r], S, r
+        return Ur_d, Ar, exp_variance[:r], S, r, V[:, :r]
 
     def decomposition(self, X0, select_modes='variance', n_modes=99):
         """Reference :242-279 on a caller-supplied scaled matrix X0 (host ndarray, local rows).
@@ -415,18 +415,22 @@ class ROM:
         if basis is None:
             with np.errstate(invalid='ignore', divide='ignore'):
                 G = np.sum(self._G_f / self._var_f[:, None, None], axis=0)
-            Ur_d, Ar, expv, S, r = self._basis_from_gram(G, select_modes, n_modes, True, self._d['inv_scale'])
+            Ur_d, Ar, expv, S, r, V_r = self._basis_from_gram(G, select_modes, n_modes, True, self._d['inv_scale'])
             self.exp_variance_ = expv
             self.S_ = S
         else:
             Ur_d = eng.to_device(basis[0])
             Ar = np.asarray(basis[1])
+            V_r = None
         self._d['Ur'] = Ur_d
         self.Ar = Ar
         self.r = Ar.shape[1]
         Sigma_r = np.linalg.norm(Ar, axis=0)                  # :504-508
         self.Sigma_r = Sigma_r
-        self.Vr = Ar / Sigma_r
+        if V_r is not None:
+            self.Vr = V_r * (np.linalg.norm(V_r, axis=0) ** -1)   # = Ar / Sigma_r, also when a sigma underflowed to 0
+        else:
+            self.Vr = Ar / Sigma_r
         for k in ('C', 'Theta'):
             self.__dict__.pop(k, None)
         self._trace.report()

@@ -53,7 +53,7 @@ class NumpyEngine:
         return torch.from_numpy(mean.copy()), torch.from_numpy(fstats), torch.from_numpy(gram)
 
     # K4
-    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None):
+    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
         x = X.numpy()
         n = x.shape[0]
         mean = x.mean(axis=1) if center else np.zeros(n)

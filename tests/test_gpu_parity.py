@@ -71,7 +71,8 @@ def test_project_vs_oracle(eng, n_points, F, m, r):
     rng = np.random.default_rng(1)
     W = rng.standard_normal((m, r))
     inv = eng.to_device(1.0 / X_scl[::n_points, 0])
-    U = eng.to_host(eng.project(eng.to_device(X), 0, n_points, F, inv, eng.to_device(W)))
+    U = eng.to_host(eng.project(eng.to_device(X), 0, n_points, F, inv, eng.to_device(W),
+                                rowmean=eng.to_device(X_cnt[:, 0])))
     ref = X0 @ W
     assert np.abs(U - ref).max() <= 1e-12 * np.abs(ref).max()
 
@@ -216,6 +217,71 @@ def test_general_csr_measurement_matrix(eng):
                               eng.to_device(C.data), eng.to_device(U), 0, eng.to_device(mu))
     np.testing.assert_allclose(eng.to_host(Th), C @ U, atol=1e-12)
     np.testing.assert_allclose(eng.to_host(cnt), C @ mu, atol=1e-12)
+
+
+# ---- row shards: the kernels see rows [row0, row0+n_loc) of a global feature-major matrix ----
+@pytest.mark.parametrize('n_points,F,m,r,world', [(1000, 3, 24, 8, 2), (777, 4, 64, 16, 3), (500, 9, 40, 14, 4), (64, 2, 256, 32, 2)])
+def test_kernels_on_row_shards(eng, n_points, F, m, r, world):
+    """Every shard kernel with row0 != 0 and features that straddle the shard boundaries; the
+    per-shard results must add up / concatenate to the single-shard ones and to the oracle."""
+    from tests.numpy_engine import NumpyEngine
+    X = synth_host(n_points, F, m, min(m, 2 * r), 0.85, 1e-3, 900 + m)
+    n = n_points * F
+    if n % world:
+        pytest.skip('rows do not divide')
+    n_loc = n // world
+    X_cnt, X_scl, X0 = orc.scale_data_std(X, F)
+    ref = NumpyEngine()
+    W = np.random.default_rng(2).standard_normal((m, r))
+    inv = 1.0 / X_scl[::n_points, 0]
+    gram_sum = np.zeros((F, m, m)); cnt = np.zeros(F); Us = []; recs = []; means = []
+    for k in range(world):
+        row0 = k * n_loc
+        Xs = eng.to_device(X[row0:row0 + n_loc])
+        rowmean, fstats, gram = eng.stats_gram(Xs, row0, n_points, F)
+        rm_ref, fs_ref, g_ref = ref.stats_gram(ref.to_device(X[row0:row0 + n_loc]), row0, n_points, F)
+        np.testing.assert_allclose(eng.to_host(rowmean), rm_ref.numpy(), rtol=1e-13, atol=1e-13)
+        fs = eng.to_host(fstats)
+        np.testing.assert_array_equal(fs[:, 0], fs_ref.numpy()[:, 0])
+        np.testing.assert_allclose(fs[:, 1:], fs_ref.numpy()[:, 1:], rtol=1e-9, atol=1e-9 * np.abs(fs_ref.numpy()).max())
+        g = eng.to_host(gram)
+        assert np.abs(g - g_ref.numpy()).max() <= 1e-12 * max(np.abs(g_ref.numpy()).max(), 1e-300)
+        gram_sum += g; cnt += fs[:, 0]
+        U = eng.project(Xs, row0, n_points, F, eng.to_device(inv), eng.to_device(W), rowmean=rowmean)
+        Us.append(eng.to_host(U)); means.append(eng.to_host(rowmean))
+        A = np.random.default_rng(3).standard_normal((2, r))
+        xr = eng.to_host(eng.reconstruct(U, row0, n_points, F, rowmean, eng.to_device(X_scl[::n_points, 0]), eng.to_device(A))).T
+        assert rel_fro(xr, orc.reconstruct(A, Us[-1], X_cnt[row0:row0 + n_loc], X_scl[row0:row0 + n_loc])) <= 1e-13
+        st = eng.qr_begin(U, row0, r)
+        recs.append(eng.to_host(st['rec']))
+    np.testing.assert_array_equal(cnt, n_points)
+    Ufull = np.vstack(Us)
+    assert np.abs(Ufull - X0 @ W).max() <= 1e-11 * np.abs(X0 @ W).max()
+    # the best record over the shards is the globally largest row, with its GLOBAL index
+    nrm = (Ufull ** 2).sum(axis=1)
+    best = max(recs, key=lambda c: (c[0], -c[1]))
+    assert int(best[1]) == int(np.argmax(nrm)) and abs(best[0] - nrm.max()) <= 1e-12 * nrm.max()
+
+
+@pytest.mark.parametrize('n_points,F,m,r', [(1, 1, 2, 1), (3, 2, 2, 2), (17, 1, 1, 1), (5, 3, 300, 2)])
+def test_tiny_and_out_of_range_shapes(eng, n_points, F, m, r):
+    """shapes far below one panel / one workgroup, and m beyond the built range (must fail loudly)"""
+    rng = np.random.default_rng(n_points + m)
+    X = rng.standard_normal((n_points * F, m)) + 3.0
+    Xd = eng.to_device(X)
+    if m > 256:
+        with pytest.raises(NotImplementedError):
+            eng.stats_gram(Xd, 0, n_points, F)
+        return
+    rowmean, fstats, gram = eng.stats_gram(Xd, 0, n_points, F)
+    np.testing.assert_allclose(eng.to_host(rowmean), X.mean(axis=1), rtol=1e-14)
+    c = X - X.mean(axis=1, keepdims=True)
+    for f in range(F):
+        blk = c[f * n_points:(f + 1) * n_points]
+        np.testing.assert_allclose(eng.to_host(gram)[f], blk.T @ blk, atol=1e-13 * max(1.0, np.abs(blk).max() ** 2))
+    W = rng.standard_normal((m, r))
+    U = eng.to_host(eng.project(Xd, 0, n_points, F, eng.to_device(np.ones(F)), eng.to_device(W), rowmean=rowmean))
+    np.testing.assert_allclose(U, c @ W, atol=1e-12)
 
 
 # ---- size-independent properties at a larger size (too big for the oracle's full path in seconds) ----

@@ -37,18 +37,22 @@ def main():
         t_f = timeit(lambda: lib.spr_stats_gram_finalize_f64(n, m, 0, cells, F, ws.data_ptr(), ws.numel(), fstats.data_ptr(), gram.data_ptr(), st))
         W = eng.to_device(np.random.default_rng(0).standard_normal((m, r)))
         inv = eng.to_device(np.ones(F))
-        Ur = eng.project(X, 0, cells, F, inv, W)
-        t_p = timeit(lambda: eng.project(X, 0, cells, F, inv, W, out=Ur))
+        Ur = eng.project(X, 0, cells, F, inv, W, rowmean=rowmean)
+        t_p = timeit(lambda: eng.project(X, 0, cells, F, inv, W, out=Ur, rowmean=rowmean))
         a = eng.to_device(np.ones((1, r))); out = eng.empty((1, n))
         t_r = timeit(lambda: eng.reconstruct(Ur, 0, cells, F, rowmean, inv, a, out=out))
-        qs = eng.qr_begin(Ur, 0, 2)
-        t_q = timeit(lambda: eng.qr_step(qs, 0, qs['cand'][None]))
+        qs = eng.qr_begin(Ur, 0, 8)
+        eng.qr_step(qs, 0, qs['rec'][None], qs['tau'][None], True)
+        t_q = timeit(lambda: eng.qr_refresh(qs, 0, 1))
+        for j in range(1, 8):
+            eng.qr_step(qs, j, qs['rec'][None], qs['tau'][None], True)
+        t_q8 = timeit(lambda: eng.qr_refresh(qs, 0, 8))
         xb = n * m * 8
         print(f'cells={cells} F={F} m={m} r={r}  X={xb / 1e9:.2f} GB')
         print(f'  stats_gram  {t_g:8.3f} ms  {xb / t_g / 1e6:8.1f} GB/s  {n * m * m / t_g / 1e9:7.2f} TF   (finalize {t_f:.3f} ms)')
         print(f'  project     {t_p:8.3f} ms  {(xb + n * r * 8) / t_p / 1e6:8.1f} GB/s  {2.0 * n * m * r / t_p / 1e9:7.2f} TF')
         print(f'  reconstruct {t_r:8.3f} ms  {(n * r * 8 + 16 * n) / t_r / 1e6:8.1f} GB/s')
-        print(f'  qr_step     {t_q:8.3f} ms  {(n * r * 8 + 16 * n) / t_q / 1e6:8.1f} GB/s')
+        print(f'  qr_sweep x1 {t_q:8.3f} ms  {(n * r * 8 + 16 * n) / t_q / 1e6:8.1f} GB/s   x8 directions {t_q8:8.3f} ms  {(n * r * 8 + 16 * n) / t_q8 / 1e6:8.1f} GB/s')
         del X, Ur, out, rowmean
         torch.cuda.empty_cache()
 

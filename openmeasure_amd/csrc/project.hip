@@ -37,7 +37,7 @@ constexpr int NW = 8;
 
 template <int MT> struct ProjRows { static constexpr int R = (MT >= 12) ? 32 : 64; };
 
-template <int MT, int RTILES, bool VEC>
+template <int MT, int RTILES, int VEC>
 __global__ __launch_bounds__(NW * 64) void project_kernel(
     const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     const double *__restrict__ inv_scale, const double *__restrict__ rowmean, const double *__restrict__ W, int r,
@@ -148,7 +148,7 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   static int total_wg = 0;
   if (!total_wg) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES, true>, NW * 64, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES, 2>, NW * 64, 0) !=
             hipSuccess || per_cu < 1)
       per_cu = 1;
     if (per_cu > 4) per_cu = 4;
@@ -160,12 +160,14 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   plan.total_wg = total_wg; plan.chunk_rows = ProjRows<MT>::R;
   const int grid = seg_total_wgs(plan);
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  if (vec_ok)
-    hipLaunchKernelGGL((project_kernel<MT, RTILES, true>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center,
-                       plan, inv_scale, rowmean, W, (int)r, Ur, ldu);
-  else
-    hipLaunchKernelGGL((project_kernel<MT, RTILES, false>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center,
-                       plan, inv_scale, rowmean, W, (int)r, Ur, ldu);
+  const int lm = vec_ok ? ((m == 16 * MT) ? 2 : 1) : 0;
+#define PJ_LAUNCH(LM)                                                                                         \
+  hipLaunchKernelGGL((project_kernel<MT, RTILES, LM>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center, \
+                     plan, inv_scale, rowmean, W, (int)r, Ur, ldu)
+  if (lm == 2) PJ_LAUNCH(2);
+  else if (lm == 1) PJ_LAUNCH(1);
+  else PJ_LAUNCH(0);
+#undef PJ_LAUNCH
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }

@@ -57,9 +57,10 @@ struct RowTile {
   f64x2 pre[IT][VPL];
 
   // Pass `it` (a constant after unrolling) of the panel whose first local row is crow0.
-  // VEC: rows are 16-byte aligned and m is even.  Rows >= seg_hi re-read the last valid row
+  // VEC 0: any layout (8-byte loads); 1: rows 16-byte aligned, m even; 2: additionally m == 16*MT
+  // (no column clamp, constant offsets).  Rows >= seg_hi re-read the last valid row
   // and columns >= m re-read column 0; center_store_pass discards both.
-  template <bool VEC>
+  template <int VEC>
   __device__ inline void load_pass(int it, const double *__restrict__ X, int64_t ldx, int m, int64_t crow0,
                                    int64_t seg_hi, int wave, int lane) {
     const int grp = lane / LPR, lig = lane % LPR;
@@ -70,7 +71,9 @@ struct RowTile {
     for (int v = 0; v < VPL; ++v) {
       const int col = 2 * (lig + v * LPR);
       f64x2 t;
-      if (VEC) {
+      if (VEC == 2) {
+        t = *reinterpret_cast<const f64x2 *>(rp + col);               // m == MPAD: constant offsets
+      } else if (VEC == 1) {
         t = *reinterpret_cast<const f64x2 *>(rp + (col < m ? col : 0));
       } else {
         t.x = rp[col < m ? col : 0];
@@ -82,7 +85,7 @@ struct RowTile {
 
   // one 16-byte piece (it, v) of a pass: lets a consumer spread the HBM requests of the next
   // panel over its whole MFMA phase instead of issuing them in one burst
-  template <bool VEC>
+  template <int VEC>
   __device__ inline void load_piece(int it, int v, const double *__restrict__ X, int64_t ldx, int m, int64_t crow0,
                                     int64_t seg_hi, int wave, int lane) {
     const int grp = lane / LPR, lig = lane % LPR;
@@ -91,7 +94,9 @@ struct RowTile {
     const double *rp = X + lrow * ldx;
     const int col = 2 * (lig + v * LPR);
     f64x2 t;
-    if (VEC) {
+    if (VEC == 2) {
+      t = *reinterpret_cast<const f64x2 *>(rp + col);
+    } else if (VEC == 1) {
       t = *reinterpret_cast<const f64x2 *>(rp + (col < m ? col : 0));
     } else {
       t.x = rp[col < m ? col : 0];
@@ -117,7 +122,7 @@ struct RowTile {
     }
   }
 
-  template <bool VEC>
+  template <int VEC>
   __device__ inline void load(const double *__restrict__ X, int64_t ldx, int m, int64_t crow0, int64_t seg_hi,
                               int wave, int lane) {
 #pragma unroll

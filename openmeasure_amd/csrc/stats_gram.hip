@@ -65,7 +65,7 @@ __device__ inline void tile_coords(int idx, int &ti, int &tj) {
 // reads the MT-RA operand fragments of column blocks RA..MT-1 once (every fragment is both
 // an A and a B operand) and issues its MFMAs from registers; the fragments of step k+1 are
 // requested before the MFMAs of step k so LDS latency hides behind the 64-cycle MFMAs.
-template <int MT, int U, bool VEC>
+template <int MT, int U, int VEC>
 __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int m, bool center,
                                  int64_t lo, int64_t hi, int wl, int wpf, int ks, int wave, int lane,
                                  double *__restrict__ lds0, double *__restrict__ lds1,
@@ -179,7 +179,7 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
   }
 }
 
-template <int MT, bool VEC>
+template <int MT, int VEC>
 __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
     const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab) {
@@ -298,7 +298,7 @@ int occupancy_wgs() {
   static int cached = 0;
   if (cached) return cached;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT, true>, GramCfg<MT>::NW * 64, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT, 2>, GramCfg<MT>::NW * 64, 0) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -336,12 +336,14 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   double *slab = static_cast<double *>(ws);
   double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  if (vec_ok)
-    hipLaunchKernelGGL((stats_gram_kernel<MT, true>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m,
-                       center, plan, rowmean, stat_part, slab);
-  else
-    hipLaunchKernelGGL((stats_gram_kernel<MT, false>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m,
-                       center, plan, rowmean, stat_part, slab);
+  const int lm = vec_ok ? ((m == 16 * MT) ? 2 : 1) : 0;
+#define SG_LAUNCH(LM)                                                                                         \
+  hipLaunchKernelGGL((stats_gram_kernel<MT, LM>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m, \
+                     center, plan, rowmean, stat_part, slab)
+  if (lm == 2) SG_LAUNCH(2);
+  else if (lm == 1) SG_LAUNCH(1);
+  else SG_LAUNCH(0);
+#undef SG_LAUNCH
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }

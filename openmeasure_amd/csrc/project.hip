@@ -17,6 +17,8 @@
 // strided ds_read_b64; with the row stride MP = MPAD + 2 (2 mod 4 doubles) the 32 lanes of a
 // group fall on 32 distinct bank pairs.  B[k = l>>4][j = l&15] = W[k0 + k][16 cg + j].
 // Result: col = l&15, row = (l>>4) + 4 reg.
+#include <type_traits>
+
 #include "rowtile.hpp"
 
 #ifndef PROJ_PAD
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
   constexpr int NRB = (RB + RG - 1) / RG;           // row blocks per wave and panel (upper bound)
   constexpr int SLOTS = NRB * KSTEPS;               // MFMAs per wave and panel
   constexpr int NPIECE = RT::IT * RT::VPL;          // 16-byte pieces per lane and panel
+  constexpr bool ALL_LIVE = (RB % RG == 0);         // every (wave, b) pair has a row block
   while (c < nchunks) {
     double *cur = lds[buf];
     double *nxt = lds[buf ^ 1];
@@ -106,32 +109,63 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
 #pragma clang loop unroll(full)
     for (int b = 0; b < NRB; ++b) {
       const int rb = rg + b * RG;
-      const bool live = rb < RB;                    // wave-uniform
-      const double *p = cur + (live ? rb : 0) * 16 * MP + afrag;
-      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma clang loop unroll(full)
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        if (live) {
-          if (ks & 1) acc1 = PROJ_MFMA(p[4 * ks], bfrag[ks], acc1);
-          else acc0 = PROJ_MFMA(p[4 * ks], bfrag[ks], acc0);
+      // One wave-uniform branch per row block, never one per MFMA: a conditional around each
+      // MFMA made hipcc wait (lgkmcnt(0)) for every operand right before its use.
+      auto body = [&](auto live_tag, auto full_tag) {
+        constexpr bool LIVE = decltype(live_tag)::value;
+        constexpr bool FULLP = decltype(full_tag)::value;   // whole panel inside the segment and r == 16*RTILES
+        const double *p = cur + (LIVE ? rb : 0) * 16 * MP + afrag;
+        f64x4 acc0 = {0.0, 0.0, 0.0, 0.0};
+        const f64x4 acc1 = {0.0, 0.0, 0.0, 0.0};
+        // row means of this block's four output rows per lane, requested before the MFMAs so their
+        // latency is covered.  Unconditional, clamped loads: a branch here splits the block and hipcc
+        // then waits vmcnt(0) -- i.e. for these very loads -- before the first staging store.
+        const int64_t mrow = lo + c * R + (LIVE ? rb : 0) * 16 + (lane >> 4);
+        double mu[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t rr = mrow + 4 * i;
+          mu[i] = rowmean[rr < hi ? rr : hi - 1];
         }
 #pragma clang loop unroll(full)
-        for (int pc = 0; pc < NPIECE; ++pc)        // piece pc = (pass, 16-byte piece): LDS store, then reload
-          if (PROJ_ABLATE != 2 && (pc * SLOTS) / NPIECE == b * KSTEPS + ks) {
-            tile.raw_store_piece(pc / RT::VPL, pc % RT::VPL, nxt, m, nrow0, hi, wave, lane);
-            tile.template load_piece<VEC>(pc / RT::VPL, pc % RT::VPL, X, ldx, m, n2row0, hi, wave, lane);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          if (LIVE) {
+            acc0 = PROJ_MFMA(p[4 * ks], bfrag[ks], acc0);   // one chain: a dependent f64 MFMA issues back to back
           }
-      }
-      if (live) {
-        const int64_t row = lo + c * R + rb * 16 + (lane >> 4);
-        if (PROJ_ABLATE == 3) asm volatile("" ::"v"(acc0.x + acc1.x), "v"(acc0.y + acc1.y), "v"(acc0.z + acc1.z), "v"(acc0.w + acc1.w));
-        if (PROJ_ABLATE != 3 && col < r) {
-          const double s0 = acc0.x + acc1.x, s1 = acc0.y + acc1.y, s2 = acc0.z + acc1.z, s3 = acc0.w + acc1.w;
-          if (row < hi) Ur[row * ldu + col] = (s0 - rowmean[row] * wbar) * isc;
-          if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (s1 - rowmean[row + 4] * wbar) * isc;
-          if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (s2 - rowmean[row + 8] * wbar) * isc;
-          if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (s3 - rowmean[row + 12] * wbar) * isc;
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound how far ahead operands are fetched (VGPRs)
+#pragma clang loop unroll(full)
+          for (int pc = 0; pc < NPIECE; ++pc)        // piece pc = (pass, 16-byte piece): LDS store, then reload
+            if (PROJ_ABLATE != 2 && (pc * SLOTS) / NPIECE == b * KSTEPS + ks) {
+              tile.raw_store_piece(pc / RT::VPL, pc % RT::VPL, nxt, m, nrow0, hi, wave, lane);
+              tile.template load_piece<VEC>(pc / RT::VPL, pc % RT::VPL, X, ldx, m, n2row0, hi, wave, lane);
+            }
         }
+        if (LIVE) {
+          const int64_t row = mrow;
+          const double s0 = (acc0.x + acc1.x - mu[0] * wbar) * isc, s1 = (acc0.y + acc1.y - mu[1] * wbar) * isc;
+          const double s2 = (acc0.z + acc1.z - mu[2] * wbar) * isc, s3 = (acc0.w + acc1.w - mu[3] * wbar) * isc;
+          if (PROJ_ABLATE == 3) asm volatile("" ::"v"(s0), "v"(s1), "v"(s2), "v"(s3));
+          if (PROJ_ABLATE != 3) {
+            if (FULLP) {                                       // no predicates: one basic block per panel
+              Ur[row * ldu + col] = s0;
+              Ur[(row + 4) * ldu + col] = s1;
+              Ur[(row + 8) * ldu + col] = s2;
+              Ur[(row + 12) * ldu + col] = s3;
+            } else if (col < r) {
+              if (row < hi) Ur[row * ldu + col] = s0;
+              if (row + 4 < hi) Ur[(row + 4) * ldu + col] = s1;
+              if (row + 8 < hi) Ur[(row + 8) * ldu + col] = s2;
+              if (row + 12 < hi) Ur[(row + 12) * ldu + col] = s3;
+            }
+          }
+        }
+      };
+      const bool fullp = (lo + (c + 1) * R <= hi) && (r == 16 * RTILES);
+      if (ALL_LIVE || rb < RB) {
+        if (fullp) body(std::true_type{}, std::true_type{});
+        else body(std::true_type{}, std::false_type{});
+      } else {
+        body(std::false_type{}, std::false_type{});
       }
     }
     buf ^= 1;
@@ -194,6 +228,7 @@ extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int
                                double *d_Ur, int64_t ldu, void *stream) {
   SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && (d_rowmean || !center), SPR_E_INVALID,
               "spr_project_f64: NULL pointer");
+  if (!center) d_rowmean = d_X;   // read (clamped, in range) but multiplied by a zero column sum
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "spr_project_f64: bad shape");
   SPR_REQUIRE(r > 0 && r <= m && ldu >= r, SPR_E_INVALID, "spr_project_f64: bad r=%d (m=%d ldu=%lld)", r, m,
               (long long)ldu);

@@ -90,6 +90,14 @@ int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0, int64_t n_
                     int32_t n_features, const double *d_rowmean, const double *d_scale,
                     double *d_x, void *stream);
 
+/* ---- per-feature min / max of the raw block: np.max(x), np.min(x) of scale_type 'range' (:128)
+ * and 'max' (:135).  d_minmax[2f] = min, [2f+1] = max over the LOCAL rows of feature f (+inf/-inf
+ * when a feature has no local rows; ranks combine with min / max).  One extra read of X. */
+size_t spr_feature_minmax_workspace(int32_t n_features);
+int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                           int64_t n_points, int32_t n_features, double *d_minmax,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- K10 + K11 : reconstruction  x = X_scl * (Ur a) + X_cnt -------------------------
  * Replaces Ur @ Ar.T (:371) and unscale_data (:235, :372-373) in one streaming pass.
  * d_A is n_p x r row-major (the Ar argument); output d_Xrec is COLUMN-major

@@ -67,3 +67,92 @@ extern "C" int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0,
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
+
+// ---- per-feature minimum / maximum of the raw block (scale_type 'range' :128, 'max' :135) -----
+// A separate streaming pass, only run for those two scalings, so the fused Gram pass stays lean.
+namespace {
+
+__global__ __launch_bounds__(256) void minmax_kernel(const double *__restrict__ X, int64_t ldx, int m, SegPlan plan,
+                                                     double *__restrict__ part) {
+  __shared__ double smin[4], smax[4];
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double mn = INFINITY, mx = -INFINITY;
+  for (int64_t row = lo + (int64_t)wl * 4 + wave; row < hi; row += (int64_t)wpf * 4) {
+    const double *rp = X + row * ldx;
+    for (int c = lane; c < m; c += 64) {
+      const double v = rp[c];
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if (lane == 0) { smin[wave] = mn; smax[wave] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { mn = smin[w] < mn ? smin[w] : mn; mx = smax[w] > mx ? smax[w] : mx; }
+    part[2 * (int64_t)blockIdx.x] = mn;
+    part[2 * (int64_t)blockIdx.x + 1] = mx;
+  }
+}
+
+__global__ void minmax_finalize_kernel(const double *__restrict__ part, SegPlan plan, double *__restrict__ out) {
+  const int f = blockIdx.x;
+  int base = 0, wpf = 0, acc = 0;
+  for (int ff = seg_first_feature(plan); ff <= seg_last_feature(plan); ++ff) {
+    int64_t lo, hi;
+    seg_range(plan, ff, lo, hi);
+    const int w = seg_wgs(plan, hi - lo);
+    if (ff == f) { base = acc; wpf = w; }
+    acc += w;
+  }
+  double mn = INFINITY, mx = -INFINITY;
+  for (int p = threadIdx.x; p < wpf; p += 64) {
+    const double a = part[2 * (int64_t)(base + p)], b = part[2 * (int64_t)(base + p) + 1];
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if (threadIdx.x == 0) { out[2 * f] = mn; out[2 * f + 1] = mx; }   // +inf / -inf for features with no local rows
+}
+
+}  // namespace
+
+extern "C" size_t spr_feature_minmax_workspace(int32_t n_features) {
+  const int cus = spr_cached_cus();
+  return sizeof(double) * 2 * ((size_t)8 * (cus > 0 ? cus : 256) + (size_t)n_features);
+}
+
+extern "C" int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                      int64_t n_points, int32_t n_features, double *d_minmax, void *d_workspace,
+                                      size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_minmax && d_workspace, SPR_E_INVALID, "spr_feature_minmax_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
+                  row0 + n_rows <= n_points * (int64_t)n_features,
+              SPR_E_INVALID, "spr_feature_minmax_f64: bad shape");
+  SPR_REQUIRE(workspace_bytes >= spr_feature_minmax_workspace(n_features), SPR_E_WORKSPACE,
+              "spr_feature_minmax_f64: workspace too small");
+  const int cus = spr_cached_cus();
+  SegPlan plan;
+  plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
+  plan.total_wg = 8 * (cus > 0 ? cus : 256); plan.chunk_rows = 4;
+  const int grid = seg_total_wgs(plan);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, plan,
+                     static_cast<double *>(d_workspace));
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(minmax_finalize_kernel, dim3(n_features), dim3(64), 0, st,
+                     static_cast<const double *>(d_workspace), plan, d_minmax);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}

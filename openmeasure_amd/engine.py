@@ -132,6 +132,15 @@ class HipEngine:
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf
 
+    def feature_minmax(self, X, row0, n_points, n_features):
+        """-> (F, 2) tensor: min and max of the raw block per feature over the local rows."""
+        n, m, ld = self._check_matrix(X)
+        out = self.empty((n_features, 2))
+        ws = self._workspace('minmax', self.lib.spr_feature_minmax_workspace(n_features))
+        _lib.check(self.lib.spr_feature_minmax_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(out), _ptr(ws),
+                                                   ws.numel(), self._stream()), 'spr_feature_minmax_f64')
+        return out
+
     # ---- K2 / K11 stand-alone ---------------------------------------------------------------
     def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
         n, m, ld = self._check_matrix(X)

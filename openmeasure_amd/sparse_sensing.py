@@ -29,7 +29,7 @@ What differs from the reference, by design:
   * fitted arrays live in HBM; ``X_cnt``, ``X_scl``, ``Ur``, ... are copied to NumPy on
     first access;
   * options that have no device implementation yet ('gem' placement, 'COLS', scalings
-    other than 'std', ``axis_cnt=None``, ``sampling=``) raise ``NotImplementedError`` --
+    'median' / 'vast_2..4', ``axis_cnt=None``, ``sampling=``) raise ``NotImplementedError`` --
     they never fall back to a CPU path.
 
 Row sharding: pass ``shard=RowShard(row0, n_global, group)`` and the local block of rows;
@@ -254,16 +254,48 @@ class ROM:
         return self._lazy('X0', make)
 
     # ------------------------------------------------------------------ a2 scale_data
+    _DEVICE_SCALINGS = ('std', 'none', 'pareto', 'vast', 'range', 'level', 'max', 'variance', 'poisson', 'l2-norm')
+
     def _check_scaling(self, scale_type, axis_cnt):
         known = ['std', 'none', 'pareto', 'vast', 'range', 'level', 'max', 'variance', 'median', 'poisson',
                  'vast_2', 'vast_3', 'vast_4', 'l2-norm']
         if scale_type not in known:
             raise NotImplementedError('The scaling method selected has not been implemented yet')   # :164
-        if scale_type != 'std' or axis_cnt != 1:
-            raise NotImplementedError(f"scale_type={scale_type!r}, axis_cnt={axis_cnt!r}: only 'std' with "
-                                      'axis_cnt=1 has a device implementation (no CPU fallback).')
+        if scale_type not in self._DEVICE_SCALINGS:
+            raise NotImplementedError(f"scale_type={scale_type!r} has no device implementation (needs a per-feature "
+                                      'median / kurtosis); no CPU fallback.')
+        if axis_cnt != 1:
+            raise NotImplementedError(f'axis_cnt={axis_cnt!r}: only row centring (axis_cnt=1) has a device '
+                                      'implementation (no CPU fallback).')
 
-    def _stats_pass(self):
+    def _feature_scale(self, scale_type, cnt, mu, var, m):
+        """Per-feature scaling factor (:114-161) from the merged block statistics: cnt rows, block mean mu,
+        population variance var of the raw block; 'range' / 'max' add one min/max pass over X."""
+        with np.errstate(invalid='ignore', divide='ignore'):
+            std = np.sqrt(var)
+            if scale_type == 'std':
+                return std
+            if scale_type == 'none':
+                return np.ones_like(std)
+            if scale_type == 'pareto':
+                return np.sqrt(std)
+            if scale_type == 'vast':
+                return var / mu
+            if scale_type == 'level':
+                return mu.copy()
+            if scale_type == 'variance':
+                return var.copy()
+            if scale_type == 'poisson':
+                return np.sqrt(mu)
+            if scale_type == 'l2-norm':
+                return np.sqrt(cnt * m * (var + mu * mu))
+            eng = self._engine()
+            mm = self._all_gather(eng.feature_minmax(self._Xd(), self._row0, self.n_points, self.n_features))
+            mm = eng.to_host(mm)                              # (world, F, 2)
+            fmin, fmax = mm[:, :, 0].min(axis=0), mm[:, :, 1].max(axis=0)
+            return fmax - fmin if scale_type == 'range' else fmax
+
+    def _stats_pass(self, scale_type='std'):
         """Fused K1+K3a pass, cross-rank merge, per-feature scale. Leaves rowmean/scale on the device."""
         eng = self._engine()
         Xd = self._Xd()
@@ -289,8 +321,8 @@ class ROM:
         tr = np.trace(G_f, axis1=1, axis2=2)
         with np.errstate(invalid='ignore', divide='ignore'):
             var_f = (tr + m * m2) / (cnt * m)                # population variance of the raw block (:115)
-        self._scl_f = np.sqrt(var_f)
-        self._var_f = var_f
+        self._scl_f = self._feature_scale(scale_type, cnt, mu, var_f, m)
+        self._var_f = self._scl_f ** 2                        # what the Gram blocks are divided by
         self._G_f = G_f
         self._d['rowmean'] = rowmean
         self._d['scale'] = eng.to_device(self._scl_f)
@@ -303,7 +335,7 @@ class ROM:
     def scale_data(self, scale_type='std', axis_cnt=1):
         """Reference :83-171.  Sets X_cnt / X_scl and returns the scaled matrix X0."""
         self._check_scaling(scale_type, axis_cnt)
-        self._stats_pass()
+        self._stats_pass(scale_type)
         return self.X0
 
     # ------------------------------------------------------------------ a11 unscale_data
@@ -410,7 +442,7 @@ class ROM:
             raise ValueError('The select_mode value is wrong.')
         eng = self._engine()
         self.scale_type = scale_type
-        self._stats_pass()
+        self._stats_pass(scale_type)
         self._host.clear()
         if basis is None:
             with np.errstate(invalid='ignore', divide='ignore'):

@@ -57,14 +57,15 @@ def synth(n_points, n_features, m, k, rho, eps, seed):
     return np.ascontiguousarray(X)
 
 
-def run_case(sps, name, X, n_features, select_modes, n_modes, seed, mask_frac=None, store_X0=False):
+def run_case(sps, name, X, n_features, select_modes, n_modes, seed, mask_frac=None, store_X0=False,
+             scale_type='std'):
     n, m = X.shape
     n_points = n // n_features
     rng = np.random.default_rng(seed + 7)
     xyz = rng.random((n_points, 3))
     spr = sps.SPR(X.copy(), n_features, xyz)
-    spr.fit(select_modes=select_modes, n_modes=n_modes)
-    out = dict(X=X, n_features=np.int64(n_features), select_modes=np.array(select_modes),
+    spr.fit(scale_type=scale_type, select_modes=select_modes, n_modes=n_modes)
+    out = dict(X=X, scale_type=np.array(scale_type), n_features=np.int64(n_features), select_modes=np.array(select_modes),
                n_modes=np.float64(n_modes), X_cnt=spr.X_cnt, X_scl=spr.X_scl,
                Ur=np.array(spr.Ur), Ar=np.array(spr.Ar), Vr=spr.Vr, Sigma_r=spr.Sigma_r,
                r=np.int64(spr.r))
@@ -142,6 +143,11 @@ def main():
     # odd m / odd r / ragged: 333 cells x 3 x 7 snapshots, r = 5
     X = synth(333, 3, 7, 7, 0.6, 1e-3, 404)
     run_case(sps, 'g4_num5', X, 3, 'number', 5, 405)
+    # the other per-feature scalings of ROM.scale_data (:117-161) on the G2 matrix (positive data so
+    # that 'level' / 'poisson' / 'vast' are well defined)
+    X = synth(500, 3, 12, 12, 0.7, 1e-3, 202) * 0.05 + 5.0
+    for k, st in enumerate(['none', 'pareto', 'vast', 'level', 'variance', 'poisson', 'l2-norm', 'range', 'max']):
+        run_case(sps, 'g5_' + st.replace('-', ''), X, 3, 'number', 4, 500 + k, scale_type=st)
 
 
 if __name__ == '__main__':

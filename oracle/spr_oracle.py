@@ -49,12 +49,41 @@ def check_inputs(X, n_features):
 # ----------------------------------------------------------------------------
 # a2  ROM.scale_data('std', axis_cnt=1)            sparse_sensing.py:106-171
 # ----------------------------------------------------------------------------
-def scale_data_std(X, n_features, axis_cnt=1):
-    """Row centring + one population std per feature block.
+def feature_scale(x, scale_type):
+    """The per-feature scaling factor of ``ROM.scale_data`` for one feature block x
+    (:114-161; the kurtosis-based 'vast_2/3/4' branches assign an m-vector to a column
+    slice in the reference and only run when n_points == m, they are not restated)."""
+    if scale_type == 'std':
+        return np.std(x)                                  # :115
+    if scale_type == 'none':
+        return 1.                                         # :118
+    if scale_type == 'pareto':
+        return np.sqrt(np.std(x))                         # :121
+    if scale_type == 'vast':
+        return np.std(x) ** 2 / np.average(x)             # :124
+    if scale_type == 'range':
+        return np.max(x) - np.min(x)                      # :128
+    if scale_type == 'level':
+        return np.average(x)                              # :132
+    if scale_type == 'max':
+        return np.max(x)                                  # :135
+    if scale_type == 'variance':
+        return np.var(x)                                  # :138
+    if scale_type == 'median':
+        return np.median(x)                               # :141
+    if scale_type == 'poisson':
+        return np.sqrt(np.average(x))                     # :144
+    if scale_type == 'l2-norm':
+        return np.linalg.norm(x)                          # :160
+    raise NotImplementedError('The scaling method selected has not been implemented yet')   # :164
+
+
+def scale_data(X, n_features, scale_type='std', axis_cnt=1):
+    """Row centring + one scaling factor per feature block.
 
     :112  X_cnt[block] = np.average(block, axis=axis_cnt)   (row mean, or the block's
           scalar mean when axis_cnt is None)
-    :115  X_scl[block] = np.std(block)                      (ONE scalar per feature)
+    :114-161  X_scl[block] = one scalar per feature (population std for 'std')
     :169  X0 = (X - X_cnt) / X_scl
     Returns (X_cnt (n,1), X_scl (n,1), X0 (n,m)), all float64 like the reference's
     ``np.zeros`` outputs (:106-107).
@@ -67,9 +96,14 @@ def scale_data_std(X, n_features, axis_cnt=1):
         blk = slice(f * n_points, (f + 1) * n_points)
         x = X[blk, :]
         X_cnt[blk, 0] = np.average(x, axis=axis_cnt)
-        X_scl[blk, 0] = np.std(x)
+        X_scl[blk, 0] = feature_scale(x, scale_type)
     X0 = (X - X_cnt) / X_scl
     return X_cnt, X_scl, X0
+
+
+def scale_data_std(X, n_features, axis_cnt=1):
+    """``scale_data('std', axis_cnt)`` -- the default branch (:115)."""
+    return scale_data(X, n_features, 'std', axis_cnt)
 
 
 # ----------------------------------------------------------------------------
@@ -121,12 +155,12 @@ def decomposition(X0, select_modes='variance', n_modes=99):
 # ----------------------------------------------------------------------------
 # a5  ROM.fit                                      sparse_sensing.py:491-511
 # ----------------------------------------------------------------------------
-def fit(X, n_features, select_modes='variance', n_modes=99, axis_cnt=1):
+def fit(X, n_features, select_modes='variance', n_modes=99, axis_cnt=1, scale_type='std'):
     """scale_data -> decomposition -> Sigma_r / Vr (:504-508).
 
     Returns a dict with the attributes the reference object carries afterwards.
     """
-    X_cnt, X_scl, X0 = scale_data_std(X, n_features, axis_cnt)
+    X_cnt, X_scl, X0 = scale_data(X, n_features, scale_type, axis_cnt)
     Ur, Ar, expv, S = decomposition(X0, select_modes, n_modes)
     r = Ar.shape[1]
     Sigma_r = np.zeros((r,))

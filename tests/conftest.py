@@ -27,6 +27,7 @@ def load_golden(name):
     nm = float(g['n_modes'])
     g['n_modes'] = int(nm) if g['select_modes'] == 'number' else nm
     g['name'] = name
+    g['scale_type'] = str(g['scale_type']) if 'scale_type' in g else 'std'
     return g
 
 

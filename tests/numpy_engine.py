@@ -61,6 +61,15 @@ class NumpyEngine:
         U = ((x - mean[:, None]) @ W.numpy()) * inv_scale.numpy()[feat][:, None]
         return torch.from_numpy(np.ascontiguousarray(U))
 
+    def feature_minmax(self, X, row0, n_points, n_features):
+        x = X.numpy()
+        feat = self._feat(x.shape[0], row0, n_points, n_features)
+        out = np.empty((n_features, 2))
+        for f in range(n_features):
+            sel = feat == f
+            out[f] = (x[sel].min(), x[sel].max()) if sel.any() else (np.inf, -np.inf)
+        return torch.from_numpy(out)
+
     def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
         feat = self._feat(X.shape[0], row0, n_points, n_features)
         return torch.from_numpy((X.numpy() - rowmean.numpy()[:, None]) * inv_scale.numpy()[feat][:, None])

@@ -53,7 +53,9 @@ def test_unsupported_options_raise_not_fallback(small):
     X, F, xyz = small
     spr = SPR(X, F, xyz, engine=NumpyEngine())
     with pytest.raises(NotImplementedError):
-        spr.fit(scale_type='pareto')
+        spr.fit(scale_type='median')
+    with pytest.raises(NotImplementedError):
+        spr.fit(scale_type='vast_2')
     with pytest.raises(NotImplementedError):
         spr.fit(scale_type='bogus')                    # :164
     with pytest.raises(NotImplementedError):

@@ -67,8 +67,12 @@ def main():
     if world != args.gpus:
         log(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get('SPR_FORCE_DIST', '0') == '1'      # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
 
     wl = WORKLOADS[args.workload]
@@ -87,11 +91,11 @@ def main():
     torch.cuda.synchronize()
     log(f'[rank {rank}] generated {n_loc} x {m} f64 shard ({n_loc * m * 8 / 1e9:.2f} GB) in {time.time() - t0:.2f}s')
 
-    shard = RowShard(row0, n_glob) if world > 1 else None
+    shard = RowShard(row0, n_glob, force_collectives=force_dist) if (world > 1 or force_dist) else None
     spr = SPR(DeviceMatrix(Xd), F, None, shard=shard, engine=eng)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -113,7 +117,7 @@ def main():
         field = step(timers)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -221,7 +225,7 @@ def main():
         if extra:
             out['extra'] = extra
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

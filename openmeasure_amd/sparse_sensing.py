@@ -55,10 +55,11 @@ class RowShard:
     Every rank must hold the same number of rows (the field all-gather needs it).
     """
 
-    def __init__(self, row0, n_global, group=None):
+    def __init__(self, row0, n_global, group=None, force_collectives=False):
         self.row0 = int(row0)
         self.n_global = int(n_global)
         self.group = group
+        self.force_collectives = bool(force_collectives)   # issue the collectives even in a 1-rank group (tests)
 
     @property
     def world(self):
@@ -190,6 +191,10 @@ class ROM:
     def _world(self):
         return self._shard.world if self._shard is not None else 1
 
+    def _dist(self):
+        """True when collectives have to be issued (more than one rank, or forced for testing)."""
+        return self._shard is not None and (self._shard.world > 1 or self._shard.force_collectives)
+
     def _Xd(self):
         if 'X' not in self._d:
             eng = self._engine()
@@ -202,14 +207,14 @@ class ROM:
         return self._d['X']
 
     def _all_reduce(self, t):
-        if self._world() > 1:
+        if self._dist():
             import torch.distributed as dist
             dist.all_reduce(t, group=self._shard.group)
         return t
 
     def _all_gather(self, t):
         """-> tensor (world, *t.shape)"""
-        if self._world() == 1:
+        if not self._dist():
             return t[None]
         import torch.distributed as dist
         flat = t.contiguous().view(-1)                       # concatenated layout: accepted by RCCL and gloo alike
@@ -382,7 +387,7 @@ class ROM:
     def _spectrum(self, G):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
         lam, V = _eigh_small(G)
-        if self._world() > 1:
+        if self._dist():
             # every rank must project with bit-identical factors: rank 0's decomposition wins
             import torch.distributed as dist
             eng = self._engine()
@@ -484,7 +489,7 @@ class ROM:
         n_loc = Ur_d.shape[0]
         n_p = A_d.shape[0]
         world = self._world()
-        if world == 1:
+        if not self._dist():
             out = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
                                   self._d['scale'], A_d)
         else:

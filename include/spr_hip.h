@@ -82,13 +82,14 @@ int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx,
 
 /* ---- K2 / K11 as stand-alone calls (ROM.scale_data's return value, ROM.unscale_data) --
  * spr_scale_rows:  X0 = (X - rowmean) * inv_scale[feature]   (:169), n_rows x m.
- * spr_unscale:     x  = scale[feature] * x0 + rowmean        (:235), n_rows. */
+ * spr_unscale:     x  = scale[feature] * x0 + rowmean        (:235), n_rows; with d_rowscale != NULL
+ *                  the per-row factor is used instead (the sampled form, :233). */
 int spr_scale_rows_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                        int64_t n_points, int32_t n_features, const double *d_rowmean,
                        const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream);
 int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0, int64_t n_points,
                     int32_t n_features, const double *d_rowmean, const double *d_scale,
-                    double *d_x, void *stream);
+                    const double *d_rowscale, double *d_x, void *stream);
 
 /* ---- per-feature min / max of the raw block: np.max(x), np.min(x) of scale_type 'range' (:128)
  * and 'max' (:135).  d_minmax[2f] = min, [2f+1] = max over the LOCAL rows of feature f (+inf/-inf
@@ -101,10 +102,12 @@ int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t
 /* ---- K10 + K11 : reconstruction  x = X_scl * (Ur a) + X_cnt -------------------------
  * Replaces Ur @ Ar.T (:371) and unscale_data (:235, :372-373) in one streaming pass.
  * d_A is n_p x r row-major (the Ar argument); output d_Xrec is COLUMN-major
- * (n_p columns of ldo >= n_rows doubles each). d_scale[n_features] = X_scl per feature. */
+ * (n_p columns of ldo >= n_rows doubles each). d_scale[n_features] = X_scl per feature;
+ * d_rowscale (optional) = one factor per row instead, for reconstruct(sampling=S) (:365-368)
+ * where the rows are S.Ur, the centre S.X_cnt and the factor S.X_scl. */
 int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
                         int64_t row0, int64_t n_points, int32_t n_features,
-                        const double *d_rowmean, const double *d_scale,
+                        const double *d_rowmean, const double *d_scale, const double *d_rowscale,
                         const double *d_A, int32_t n_p, double *d_Xrec, int64_t ldo,
                         void *stream);
 
@@ -152,11 +155,14 @@ int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ld
  * Replaces C.dot(self.Ur) (:797) and self.C.dot(self.X_cnt[:,0]) (:573).  The one-hot C
  * of optimal_placement is the 1-nnz-per-row case (a row gather).  Column indices are
  * GLOBAL rows; entries outside [row0,row0+n_rows) are skipped, so per-rank results are
- * partial sums to be all-reduced.  d_Theta is s x r row-major, d_cnt has s entries. */
+ * partial sums to be all-reduced.  d_Theta is s x r row-major, d_cnt has s entries.
+ * d_scl (optional, s entries) = C . X_scl[:,0] (sampling @ X_scl, :233) from the per-feature
+ * d_scale[n_features] and the global n_points. */
 int spr_measure_csr_f64(const int64_t *d_indptr, const int64_t *d_indices,
                         const double *d_vals, int32_t s, const double *d_Ur,
                         int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
-                        const double *d_rowmean, double *d_Theta, double *d_cnt,
+                        const double *d_rowmean, const double *d_scale, int64_t n_points,
+                        int32_t n_features, double *d_Theta, double *d_cnt, double *d_scl,
                         void *stream);
 
 /* ---- K8 + K9 : scale_vector + (weighted) least squares ------------------------------

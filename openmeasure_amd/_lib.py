@@ -35,17 +35,17 @@ PROTOTYPES = {
     'spr_stats_gram_finalize_f64': (C.c_int, [_i64, _i32, _i64, _i64, _i32, _p, _sz, _p, _p, _p]),
     'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
     'spr_scale_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
-    'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
+    'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     'spr_feature_minmax_workspace': (_sz, [_i32]),
     'spr_feature_minmax_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
-    'spr_reconstruct_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
+    'spr_reconstruct_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     'spr_qr_workspace': (_sz, [_i64]),
     'spr_qr_batch': (_i32, []),
     'spr_mask_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     'spr_qr_init_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     'spr_qr_step_f64': (C.c_int, [_i64, _i32, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'spr_qr_refresh_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
-    'spr_measure_csr_f64': (C.c_int, [_p, _p, _p, _i32, _p, _i64, _i32, _i64, _i64, _p, _p, _p, _p]),
+    'spr_measure_csr_f64': (C.c_int, [_p, _p, _p, _i32, _p, _i64, _i32, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     'spr_solve_ols_f64': (C.c_int, [_p, _i32, _i32, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     'spr_synth_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p]),
     'spr_synth_gather_f64': (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p, _p]),

@@ -1,4 +1,4 @@
-// K7 + K8: Theta = C . Ur and cnt = C . X_cnt for a CSR measurement matrix C (s x n).
+// K7 + K8: Theta = C . Ur, cnt = C . X_cnt (and optionally scl = C . X_scl) for a CSR matrix C (s x n).
 //
 // One 256-thread workgroup per row of C.  The one-hot C of optimal_placement
 // (sparse_sensing.py:741-743) has one entry per row, which makes this a row gather; a
@@ -16,12 +16,13 @@ constexpr int MS_WAVES = MS_THREADS / 64;
 __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
     const int64_t *__restrict__ indptr, const int64_t *__restrict__ indices, const double *__restrict__ vals,
     const double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
-    const double *__restrict__ rowmean, double *__restrict__ Theta, double *__restrict__ cnt) {
-  __shared__ double part[MS_WAVES][SPR_MAX_R + 1];
+    const double *__restrict__ rowmean, const double *__restrict__ scale, int64_t n_points, int n_features,
+    double *__restrict__ Theta, double *__restrict__ cnt, double *__restrict__ scl) {
+  __shared__ double part[MS_WAVES][SPR_MAX_R + 2];
   const int row = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t e0 = indptr[row], e1 = indptr[row + 1];
-  double a0 = 0.0, a1 = 0.0, ac = 0.0;
+  double a0 = 0.0, a1 = 0.0, ac = 0.0, as = 0.0;
   for (int64_t e = e0 + wave; e < e1; e += MS_WAVES) {
     const int64_t col = indices[e] - row0;
     if (col < 0 || col >= n_rows) continue;
@@ -29,17 +30,25 @@ __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
     const double *u = Ur + col * ldu;
     if (lane < r) a0 += v * u[lane];
     if (lane + 64 < r) a1 += v * u[lane + 64];
-    if (lane == 0) ac += v * rowmean[col];
+    if (lane == 0) {
+      ac += v * rowmean[col];
+      if (scl) {                                   // X_scl of that row = scale of its feature (:110, :115)
+        int64_t f = (row0 + col) / n_points;
+        if (f > n_features - 1) f = n_features - 1;
+        as += v * scale[f];
+      }
+    }
   }
   part[wave][lane] = a0;
   part[wave][lane + 64] = a1;
-  if (lane == 0) part[wave][SPR_MAX_R] = ac;
+  if (lane == 0) { part[wave][SPR_MAX_R] = ac; part[wave][SPR_MAX_R + 1] = as; }
   __syncthreads();
-  for (int k = threadIdx.x; k <= SPR_MAX_R; k += MS_THREADS) {
+  for (int k = threadIdx.x; k <= SPR_MAX_R + 1; k += MS_THREADS) {
     double s = 0.0;
     for (int w = 0; w < MS_WAVES; ++w) s += part[w][k];
     if (k < r) Theta[(int64_t)row * r + k] = s;
     if (k == SPR_MAX_R) cnt[row] = s;
+    if (k == SPR_MAX_R + 1 && scl) scl[row] = s;
   }
 }
 
@@ -47,15 +56,19 @@ __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
 
 extern "C" int spr_measure_csr_f64(const int64_t *d_indptr, const int64_t *d_indices, const double *d_vals,
                                    int32_t s, const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
-                                   int64_t row0, const double *d_rowmean, double *d_Theta, double *d_cnt,
+                                   int64_t row0, const double *d_rowmean, const double *d_scale, int64_t n_points,
+                                   int32_t n_features, double *d_Theta, double *d_cnt, double *d_scl,
                                    void *stream) {
   SPR_REQUIRE(d_indptr && d_indices && d_vals && d_Ur && d_rowmean && d_Theta && d_cnt, SPR_E_INVALID,
               "spr_measure_csr_f64: NULL pointer");
   SPR_REQUIRE(s > 0 && n_rows > 0 && r > 0 && ldu >= r && row0 >= 0, SPR_E_INVALID,
               "spr_measure_csr_f64: bad shape s=%d n_rows=%lld r=%d", s, (long long)n_rows, r);
   SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_measure_csr_f64: r=%d > %d not built", r, SPR_MAX_R);
+  SPR_REQUIRE(!d_scl || (d_scale && n_points > 0 && n_features > 0), SPR_E_INVALID,
+              "spr_measure_csr_f64: scl output needs the per-feature scale and layout");
   hipLaunchKernelGGL(measure_csr_kernel, dim3(s), dim3(MS_THREADS), 0, static_cast<hipStream_t>(stream), d_indptr,
-                     d_indices, d_vals, d_Ur, n_rows, (int)r, ldu, row0, d_rowmean, d_Theta, d_cnt);
+                     d_indices, d_vals, d_Ur, n_rows, (int)r, ldu, row0, d_rowmean, d_scale, n_points, (int)n_features,
+                     d_Theta, d_cnt, d_scl);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }

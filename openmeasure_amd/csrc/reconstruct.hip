@@ -17,7 +17,7 @@ constexpr int RC_PB = 4;  // coefficient vectors handled per pass over Ur
 template <int LPR>
 __global__ __launch_bounds__(RC_THREADS) void reconstruct_kernel(
     const double *__restrict__ Ur, int r, int64_t ldu, int vec_ok_i, SegPlan plan,
-    const double *__restrict__ rowmean, const double *__restrict__ scale,
+    const double *__restrict__ rowmean, const double *__restrict__ scale, const double *__restrict__ rowscale,
     const double *__restrict__ A, int np0, int npb, double *__restrict__ out, int64_t ldo) {
   constexpr int RPW = 64 / LPR;                        // rows per wave instruction
   constexpr int ROWS_IT = (RC_THREADS / 64) * RPW * RC_UNR;  // rows per workgroup step
@@ -60,12 +60,13 @@ __global__ __launch_bounds__(RC_THREADS) void reconstruct_kernel(
     for (int j = 0; j < RC_UNR; ++j) {
       const int64_t row = rbase + j * RPW;
       const double mu = (row < hi && lig == 0) ? rowmean[row] : 0.0;
+      const double rs = (rowscale && row < hi && lig == 0) ? rowscale[row] : sc;   // sampled rows carry their own scale
 #pragma unroll
       for (int p = 0; p < RC_PB; ++p) {
         if (p < npb) {
           double d = u[j].x * a0[p] + u[j].y * a1[p];
           d = group_sum_t<LPR>(d);
-          if (lig == 0 && row < hi) out[(int64_t)(np0 + p) * ldo + row] = sc * d + mu;
+          if (lig == 0 && row < hi) out[(int64_t)(np0 + p) * ldo + row] = rs * d + mu;
         }
       }
     }
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(RC_THREADS) void reconstruct_kernel(
 
 template <int LPR>
 int launch(const double *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0, int64_t n_points,
-           int32_t n_features, const double *rowmean, const double *scale, const double *A, int32_t n_p,
-           double *out, int64_t ldo, hipStream_t st) {
+           int32_t n_features, const double *rowmean, const double *scale, const double *rowscale, const double *A,
+           int32_t n_p, double *out, int64_t ldo, hipStream_t st) {
   constexpr int RPW = 64 / LPR;
   constexpr int ROWS_IT = (RC_THREADS / 64) * RPW * RC_UNR;
   const int cus = spr_cached_cus();
@@ -88,7 +89,7 @@ int launch(const double *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row
   for (int p0 = 0; p0 < n_p; p0 += RC_PB) {
     const int npb = (n_p - p0 < RC_PB) ? n_p - p0 : RC_PB;
     hipLaunchKernelGGL(reconstruct_kernel<LPR>, dim3(grid), dim3(RC_THREADS), 0, st, Ur, (int)r, ldu, vec_ok,
-                       plan, rowmean, scale, A, p0, npb, out, ldo);
+                       plan, rowmean, scale, rowscale, A, p0, npb, out, ldo);
     SPR_LAUNCH_CHECK();
   }
   return SPR_OK;
@@ -98,8 +99,8 @@ int launch(const double *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row
 
 extern "C" int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
                                    int64_t n_points, int32_t n_features, const double *d_rowmean,
-                                   const double *d_scale, const double *d_A, int32_t n_p, double *d_Xrec,
-                                   int64_t ldo, void *stream) {
+                                   const double *d_scale, const double *d_rowscale, const double *d_A, int32_t n_p,
+                                   double *d_Xrec, int64_t ldo, void *stream) {
   SPR_REQUIRE(d_Ur && d_rowmean && d_scale && d_A && d_Xrec, SPR_E_INVALID, "spr_reconstruct_f64: NULL pointer");
   SPR_REQUIRE(n_rows > 0 && r > 0 && ldu >= r && n_p > 0 && ldo >= n_rows, SPR_E_INVALID,
               "spr_reconstruct_f64: bad shape n_rows=%lld r=%d ldu=%lld n_p=%d ldo=%lld", (long long)n_rows, r,
@@ -110,7 +111,7 @@ extern "C" int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r
   SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_reconstruct_f64: r=%d > %d not built", r, SPR_MAX_R);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int half = (r + 1) / 2;
-#define RC(L) return launch<L>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_A, n_p, d_Xrec, ldo, st)
+#define RC(L) return launch<L>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
   if (half <= 1) RC(1);
   if (half <= 2) RC(2);
   if (half <= 4) RC(4);

@@ -24,12 +24,13 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(
 
 __global__ __launch_bounds__(256) void unscale_kernel(
     const double *__restrict__ x0, int64_t n_rows, int64_t row0, int64_t n_points, int n_features,
-    const double *__restrict__ rowmean, const double *__restrict__ scale, double *__restrict__ x) {
+    const double *__restrict__ rowmean, const double *__restrict__ scale, const double *__restrict__ rowscale,
+    double *__restrict__ x) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
        i += (int64_t)gridDim.x * blockDim.x) {
     int64_t f = (row0 + i) / n_points;
     if (f > n_features - 1) f = n_features - 1;
-    x[i] = scale[f] * x0[i] + rowmean[i];
+    x[i] = (rowscale ? rowscale[i] : scale[f]) * x0[i] + rowmean[i];
   }
 }
 
@@ -57,13 +58,13 @@ extern "C" int spr_scale_rows_f64(const double *d_X, int64_t n_rows, int32_t m, 
 }
 
 extern "C" int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0, int64_t n_points,
-                               int32_t n_features, const double *d_rowmean, const double *d_scale, double *d_x,
-                               void *stream) {
+                               int32_t n_features, const double *d_rowmean, const double *d_scale,
+                               const double *d_rowscale, double *d_x, void *stream) {
   SPR_REQUIRE(d_x0 && d_rowmean && d_scale && d_x, SPR_E_INVALID, "spr_unscale_f64: NULL pointer");
   SPR_REQUIRE(n_rows > 0 && row0 >= 0 && n_points > 0 && n_features > 0, SPR_E_INVALID,
               "spr_unscale_f64: bad shape");
   hipLaunchKernelGGL(unscale_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     d_x0, n_rows, row0, n_points, (int)n_features, d_rowmean, d_scale, d_x);
+                     d_x0, n_rows, row0, n_points, (int)n_features, d_rowmean, d_scale, d_rowscale, d_x);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }

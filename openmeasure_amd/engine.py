@@ -150,15 +150,16 @@ class HipEngine:
                    'spr_scale_rows_f64')
         return out
 
-    def unscale(self, x0, row0, n_points, n_features, rowmean, scale):
+    def unscale(self, x0, row0, n_points, n_features, rowmean, scale, rowscale=None):
         n = x0.shape[0]
         out = self.empty((n,))
         _lib.check(self.lib.spr_unscale_f64(_ptr(x0.contiguous()), n, row0, n_points, n_features, _ptr(rowmean),
-                                            _ptr(scale), _ptr(out), self._stream()), 'spr_unscale_f64')
+                                            _ptr(scale), _ptr(rowscale), _ptr(out), self._stream()),
+                   'spr_unscale_f64')
         return out
 
     # ---- K10 + K11 ---------------------------------------------------------------------------
-    def reconstruct(self, Ur, row0, n_points, n_features, rowmean, scale, A, out=None):
+    def reconstruct(self, Ur, row0, n_points, n_features, rowmean, scale, A, out=None, rowscale=None):
         """x = X_scl (Ur a) + X_cnt for the n_p rows of A. -> (n_p, n) tensor (column-major (n, n_p))."""
         n, r, ldu = self._check_matrix(Ur)
         n_p = A.shape[0]
@@ -167,7 +168,8 @@ class HipEngine:
         tic, toc = self._timed('reconstruct')
         tic()
         _lib.check(self.lib.spr_reconstruct_f64(_ptr(Ur), n, r, ldu, row0, n_points, n_features, _ptr(rowmean),
-                                                _ptr(scale), _ptr(A.contiguous()), n_p, _ptr(out), out.stride(0),
+                                                _ptr(scale), _ptr(rowscale), _ptr(A.contiguous()), n_p, _ptr(out),
+                                                out.stride(0),
                                                 self._stream()), 'spr_reconstruct_f64')
         toc()
         return out
@@ -211,15 +213,18 @@ class HipEngine:
                                                st['ws'].numel(), self._stream()), 'spr_qr_refresh_f64')
 
     # ---- K7 + K8 -------------------------------------------------------------------------------
-    def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean):
+    def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean, scale=None, n_points=0):
+        """-> Theta (s,r), cnt (s,) [, scl (s,) = C . X_scl when the per-feature scale is given]."""
         n, r, ldu = self._check_matrix(Ur)
         s = indptr.shape[0] - 1
         Theta = self.empty((s, r))
         cnt = self.empty((s,))
+        scl = self.empty((s,)) if scale is not None else None
         _lib.check(self.lib.spr_measure_csr_f64(_ptr(indptr), _ptr(indices), _ptr(vals), s, _ptr(Ur), n, r, ldu,
-                                                row0, _ptr(rowmean), _ptr(Theta), _ptr(cnt), self._stream()),
-                   'spr_measure_csr_f64')
-        return Theta, cnt
+                                                row0, _ptr(rowmean), _ptr(scale), n_points,
+                                                scale.shape[0] if scale is not None else 0, _ptr(Theta), _ptr(cnt),
+                                                _ptr(scl), self._stream()), 'spr_measure_csr_f64')
+        return (Theta, cnt) if scale is None else (Theta, cnt, scl)
 
     # ---- K8 + K9 -------------------------------------------------------------------------------
     def solve_ols(self, Theta, cnt, scale, y):

@@ -29,7 +29,7 @@ What differs from the reference, by design:
   * fitted arrays live in HBM; ``X_cnt``, ``X_scl``, ``Ur``, ... are copied to NumPy on
     first access;
   * options that have no device implementation yet ('gem' placement, 'COLS', scalings
-    'median' / 'vast_2..4', ``axis_cnt=None``, ``sampling=``) raise ``NotImplementedError`` --
+    'median' / 'vast_2..4', ``axis_cnt=None``) raise ``NotImplementedError`` --
     they never fall back to a CPU path.
 
 Row sharding: pass ``shard=RowShard(row0, n_global, group)`` and the local block of rows;
@@ -343,16 +343,43 @@ class ROM:
         self._stats_pass(scale_type)
         return self.X0
 
+    def _csr_device(self, C, known=None):
+        """(indptr, indices, vals) device tensors of a dense / scipy.sparse matrix with n columns."""
+        import scipy.sparse as sp
+        eng = self._engine()
+        if known is not None:
+            indptr, indices, vals = known
+        else:
+            Cs = C.tocsr() if sp.issparse(C) else sp.csr_matrix(np.asarray(C, dtype=np.float64))
+            Cs.sort_indices()
+            indptr, indices, vals = Cs.indptr, Cs.indices, Cs.data
+        t = eng.torch
+        return (eng.to_device(indptr, dtype=t.int64), eng.to_device(indices, dtype=t.int64), eng.to_device(vals))
+
+    def _sampled(self, sampling):
+        """S.Ur, S.X_cnt, S.X_scl for a sampling matrix S (s, n) -- reference :233, :366."""
+        if sampling.shape[1] != self._n_global:
+            raise ValueError('The number of columns of sampling does not match the number of rows of X.')
+        eng = self._engine()
+        ip, ix, v = self._csr_device(sampling)
+        Th, cnt, scl = eng.measure_csr(ip, ix, v, self._d['Ur'], self._row0, self._d['rowmean'],
+                                       scale=self._d['scale'], n_points=self.n_points)
+        return self._all_reduce(Th), self._all_reduce(cnt), self._all_reduce(scl)
+
     # ------------------------------------------------------------------ a11 unscale_data
     def unscale_data(self, x0, sampling=None):
-        """Reference :212-240: x = X_scl * x0 + X_cnt for an (n_local,) vector."""
-        if sampling is not None:
-            raise NotImplementedError('unscale_data(sampling=...) has no device implementation yet.')
+        """Reference :212-240: x = X_scl * x0 + X_cnt for an (n_local,) vector, or with ``sampling`` (s, n)
+        x = (S X_scl) * x0 + S X_cnt for an (s,) vector."""
         if type(x0) is not np.ndarray:
             raise NotImplementedError('unscale_data of a cvxpy expression is outside the device path.')
         eng = self._engine()
-        t = eng.unscale(eng.to_device(x0), self._row0, self.n_points, self.n_features, self._d['rowmean'],
-                        self._d['scale'])
+        if sampling is not None:
+            _, cnt, scl = self._sampled(sampling)
+            ones = eng.to_device(np.ones(1))
+            t = eng.unscale(eng.to_device(x0), 0, x0.shape[0], 1, cnt, ones, rowscale=scl)
+        else:
+            t = eng.unscale(eng.to_device(x0), self._row0, self.n_points, self.n_features, self._d['rowmean'],
+                            self._d['scale'])
         return eng.to_host(t)
 
     # ------------------------------------------------------------------ a4 reduction
@@ -478,13 +505,17 @@ class ROM:
 
         ``to_host=False`` returns the device tensor of shape (n_p, n) instead (same values,
         column-major) and skips the PCIe copy."""
-        if sampling is not None:
-            raise NotImplementedError('reconstruct(sampling=...) has no device implementation yet.')
         eng = self._engine()
         Ar = np.asarray(Ar, dtype=np.float64) if not hasattr(Ar, 'is_cuda') else Ar
         if Ar.ndim < 2:
             Ar = Ar[None, :]
         A_d = Ar if hasattr(Ar, 'is_cuda') else eng.to_device(Ar)
+        if sampling is not None:                              # :365-368 -- (S Ur) Ar^T, un-scaled with S X_scl, S X_cnt
+            Th, cnt, scl = self._sampled(sampling)
+            ones = eng.to_device(np.ones(1))
+            Thp = Th if Th.shape[1] % 2 == 0 else eng.torch.nn.functional.pad(Th, (0, 1))[:, :Th.shape[1]]
+            out = eng.reconstruct(Thp, 0, Th.shape[0], 1, cnt, ones, A_d, rowscale=scl)
+            return out if not to_host else eng.to_host(out).T
         Ur_d = self._d['Ur']
         n_loc = Ur_d.shape[0]
         n_p = A_d.shape[0]
@@ -555,17 +586,12 @@ class SPR(ROM):
         eng = self._engine()
         if not is_Theta:
             placed = getattr(self, '_placed', None)
-            import scipy.sparse as sp
+            known = None
             if placed is not None and placed[0] is C:
                 piv = placed[1]
-                indptr, indices, vals = np.arange(len(piv) + 1), piv, np.ones(len(piv))
-            else:
-                Cs = C.tocsr() if sp.issparse(C) else sp.csr_matrix(np.asarray(C, dtype=np.float64))
-                Cs.sort_indices()
-                indptr, indices, vals = Cs.indptr, Cs.indices, Cs.data
-            t = eng.torch
-            Theta_d, cnt_d = eng.measure_csr(eng.to_device(indptr, dtype=t.int64), eng.to_device(indices, dtype=t.int64),
-                                             eng.to_device(vals), self._d['Ur'], self._row0, self._d['rowmean'])
+                known = (np.arange(len(piv) + 1), piv, np.ones(len(piv)))
+            ip, ix, v = self._csr_device(C, known)
+            Theta_d, cnt_d = eng.measure_csr(ip, ix, v, self._d['Ur'], self._row0, self._d['rowmean'])
             Theta_d = self._all_reduce(Theta_d)
             cnt_d = self._all_reduce(cnt_d)
             self.C = C

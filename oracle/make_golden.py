@@ -117,6 +117,15 @@ def run_case(sps, name, X, n_features, select_modes, n_modes, seed, mask_frac=No
     chk = (spr.Ur @ A3.T) * spr.X_scl + spr.X_cnt    # stand-in independence check
     assert np.array_equal(chk, X3), 'cvxpy stand-in changed the arithmetic'
     out['X_rec1'], out['X_rec3'] = X1, X3
+    # partial-field reconstruction through a sampling matrix (:365-368, :232-233): 7 rows, mixed one-hot / averaging
+    S = np.zeros((7, n))
+    S[np.arange(4), rng.integers(0, n, 4)] = 1.0
+    for k in range(4, 7):
+        cols = rng.integers(0, n, 5)
+        S[k, cols] = rng.random(5)
+    out['sampling'] = S
+    out['X_rec3_sampled'] = spr.reconstruct(A3, sampling=S)
+    out['unscale_sampled'] = spr.unscale_data(np.linspace(-1, 1, 7), sampling=S)
     path = os.path.join(OUT, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: n={n} m={m} r={spr.r} piv[:6]={piv[:6]} cond={spr.k:.3g} '

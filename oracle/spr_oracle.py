@@ -283,6 +283,22 @@ def unscale(x0, X_cnt, X_scl):
     return np.multiply(X_scl[:, 0], x0) + X_cnt[:, 0]
 
 
+def unscale_sampled(x0, sampling, X_cnt, X_scl):
+    """:233 x = (sampling @ X_scl[:,0]) * x0 + sampling @ X_cnt[:,0]."""
+    return np.multiply(sampling @ X_scl[:, 0], x0) + sampling @ X_cnt[:, 0]
+
+
+def reconstruct_sampled(Ar, Ur, X_cnt, X_scl, sampling):
+    """:365-368 X_rec = sampling . Ur . Ar^T, un-scaled column by column with the sampled scale/centre.
+    Returns (s, n_p)."""
+    if Ar.ndim < 2:
+        Ar = Ar[np.newaxis, :]
+    X_rec = np.linalg.multi_dot([sampling, Ur, Ar.T])
+    for i in range(X_rec.shape[1]):
+        X_rec[:, i] = unscale_sampled(X_rec[:, i], sampling, X_cnt, X_scl)
+    return X_rec
+
+
 def reconstruct(Ar, Ur, X_cnt, X_scl):
     """:362-363 1-D -> (1,r); :371 X_rec = Ur @ Ar.T; :372-373 unscale column by column.
     Returns (n, n_p)."""

@@ -74,14 +74,16 @@ class NumpyEngine:
         feat = self._feat(X.shape[0], row0, n_points, n_features)
         return torch.from_numpy((X.numpy() - rowmean.numpy()[:, None]) * inv_scale.numpy()[feat][:, None])
 
-    def unscale(self, x0, row0, n_points, n_features, rowmean, scale):
+    def unscale(self, x0, row0, n_points, n_features, rowmean, scale, rowscale=None):
         feat = self._feat(x0.shape[0], row0, n_points, n_features)
-        return torch.from_numpy(scale.numpy()[feat] * x0.numpy() + rowmean.numpy())
+        sc = scale.numpy()[feat] if rowscale is None else rowscale.numpy()
+        return torch.from_numpy(sc * x0.numpy() + rowmean.numpy())
 
     # K10 + K11
-    def reconstruct(self, Ur, row0, n_points, n_features, rowmean, scale, A, out=None):
+    def reconstruct(self, Ur, row0, n_points, n_features, rowmean, scale, A, out=None, rowscale=None):
         feat = self._feat(Ur.shape[0], row0, n_points, n_features)
-        x = (Ur.numpy() @ A.numpy().T) * scale.numpy()[feat][:, None] + rowmean.numpy()[:, None]
+        sc = scale.numpy()[feat] if rowscale is None else rowscale.numpy()
+        x = (Ur.numpy() @ A.numpy().T) * sc[:, None] + rowmean.numpy()[:, None]
         return torch.from_numpy(np.ascontiguousarray(x.T))
 
     # K6
@@ -137,11 +139,12 @@ class NumpyEngine:
         pass                                         # the model down-dates every row at every step
 
     # K7 + K8
-    def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean):
+    def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean, scale=None, n_points=0):
         ip, ix, v = indptr.numpy(), indices.numpy(), vals.numpy()
         s, n, r = len(ip) - 1, Ur.shape[0], Ur.shape[1]
         Theta = np.zeros((s, r))
         cnt = np.zeros(s)
+        scl = np.zeros(s)
         U, mu = Ur.numpy(), rowmean.numpy()
         for i in range(s):
             for e in range(ip[i], ip[i + 1]):
@@ -149,7 +152,10 @@ class NumpyEngine:
                 if 0 <= col < n:
                     Theta[i] += v[e] * U[col]
                     cnt[i] += v[e] * mu[col]
-        return torch.from_numpy(Theta), torch.from_numpy(cnt)
+                    if scale is not None:
+                        scl[i] += v[e] * scale.numpy()[min(ix[e] // n_points, scale.shape[0] - 1)]
+        out = (torch.from_numpy(Theta), torch.from_numpy(cnt))
+        return out if scale is None else out + (torch.from_numpy(scl),)
 
     # K8 + K9
     def solve_ols(self, Theta, cnt, scale, y):

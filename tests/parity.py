@@ -88,4 +88,15 @@ def run_fixture(g, engine, check_pivots=True):
     if rw == r:
         assert rel_fro(X1, g['X_rec1']) <= REL_FRO
         assert rel_fro(X3, g['X_rec3']) <= REL_FRO
+    # partial-field reconstruction / un-scaling through a sampling matrix (:365-368, :232-233)
+    S = g['sampling']
+    if rw == r:
+        Xs = spr.reconstruct(g['Ar_pred3'] * sg_r, sampling=S)
+        assert Xs.shape == g['X_rec3_sampled'].shape
+        np.testing.assert_allclose(Xs, g['X_rec3_sampled'], rtol=1e-9, atol=1e-9 * np.abs(g['X_rec3_sampled']).max())
+    np.testing.assert_allclose(spr.unscale_data(np.linspace(-1, 1, 7), sampling=S), g['unscale_sampled'], rtol=1e-11,
+                               atol=1e-12 * np.abs(g['unscale_sampled']).max())
+    import scipy.sparse as sps_
+    np.testing.assert_allclose(spr.unscale_data(np.linspace(-1, 1, 7), sampling=sps_.csr_matrix(S)), g['unscale_sampled'],
+                               rtol=1e-11, atol=1e-12 * np.abs(g['unscale_sampled']).max())
     return spr

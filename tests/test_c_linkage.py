@@ -15,7 +15,7 @@ C_SRC = r'''
 int main(void) {
   if (spr_abi_version() != 1) return 1;
   /* argument validation happens before any device work */
-  int rc = spr_reconstruct_f64(NULL, 10, 4, 4, 0, 10, 1, NULL, NULL, NULL, 1, NULL, 10, NULL);
+  int rc = spr_reconstruct_f64(NULL, 10, 4, 4, 0, 10, 1, NULL, NULL, NULL, NULL, 1, NULL, 10, NULL);
   if (rc != SPR_E_INVALID) return 2;
   if (!strstr(spr_last_error(), "NULL")) return 3;
   rc = spr_project_f64((const double *)8, 10, 300, 300, 0, 10, 1, 0, (const double *)8, NULL, (const double *)8, 4,

@@ -34,7 +34,7 @@ def test_loader_and_error_text():
     lib = _lib.load()
     assert lib.spr_abi_version() == 1
     # argument validation happens before any device work: a NULL matrix is rejected on a CPU-only box
-    rc = lib.spr_reconstruct_f64(None, 10, 4, 4, 0, 10, 1, None, None, None, 1, None, 10, None)
+    rc = lib.spr_reconstruct_f64(None, 10, 4, 4, 0, 10, 1, None, None, None, None, 1, None, 10, None)
     assert rc == -1
     assert b'NULL' in lib.spr_last_error()
     with pytest.raises(ValueError):

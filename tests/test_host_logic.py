@@ -67,8 +67,8 @@ def test_unsupported_options_raise_not_fallback(small):
         spr.optimal_placement(calc_type='bogus')       # :752-754
     with pytest.raises(NotImplementedError):
         spr.train(np.eye(20), method='COLS')
-    with pytest.raises(NotImplementedError):
-        spr.reconstruct(np.zeros(5), sampling=np.eye(20))
+    with pytest.raises(ValueError):
+        spr.reconstruct(np.zeros(5), sampling=np.eye(19))
 
 
 def test_train_predict_errors(small):                  # :791-793, :801-803, :848-854

@@ -66,6 +66,10 @@ def test_predict_and_reconstruct(golden):
     assert X1.shape == (n, 1) and X3.shape == (n, 3)
     np.testing.assert_array_equal(X1, g['X_rec1'])
     np.testing.assert_array_equal(X3, g['X_rec3'])
+    S = g['sampling']
+    np.testing.assert_array_equal(orc.reconstruct_sampled(A3, Ur_m, st['X_cnt'], st['X_scl'], S), g['X_rec3_sampled'])
+    np.testing.assert_array_equal(orc.unscale_sampled(np.linspace(-1, 1, 7), S, st['X_cnt'], st['X_scl']),
+                                  g['unscale_sampled'])
 
 
 # ---- the reference's own unit tests (tests/test_rom.py, tests/test_spr.py), restated on

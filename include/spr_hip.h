@@ -99,6 +99,18 @@ int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t
                            int64_t n_points, int32_t n_features, double *d_minmax,
                            void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- axis_cnt=None (np.average(x, axis=None), :112): scalar centre per feature ----------------
+ * spr_colsums_f64: d_out[f][0][m] = sum_i (x_i - mean_i), d_out[f][1][m] = sum_i mean_i (x_i - mean_i)
+ * over the LOCAL rows of feature f -- the two vectors that turn the row-centred Gram blocks into the
+ * Gram blocks of (X - mu_f) (csrc/scale.hip).  One extra read of X, only for this option.
+ * spr_fill_feature_f64: d_out[i] = d_values[feature of row i] (the new X_cnt column). */
+size_t spr_colsums_workspace(int32_t m, int32_t n_features);
+int spr_colsums_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                    int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_fill_feature_f64(double *d_out, int64_t n_rows, int64_t row0, int64_t n_points, int32_t n_features,
+                         const double *d_values, void *stream);
+
 /* ---- K10 + K11 : reconstruction  x = X_scl * (Ur a) + X_cnt -------------------------
  * Replaces Ur @ Ar.T (:371) and unscale_data (:235, :372-373) in one streaming pass.
  * d_A is n_p x r row-major (the Ar argument); output d_Xrec is COLUMN-major

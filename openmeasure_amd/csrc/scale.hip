@@ -157,3 +157,108 @@ extern "C" int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
+
+// ---- axis_cnt=None support (scalar centring per feature, sparse_sensing.py:112 with axis=None) ----
+// The Gram pass centres every row by its own mean.  For X0 = (X - mu_f)/scl the Gram matrix is
+//   sum_i (c_i + d_i 1)(c_i + d_i 1)^T = G_c + v 1^T + 1 v^T + (sum d_i^2) 1 1^T,   d_i = mean_i - mu_f,
+// with v = sum_i d_i c_i = w_f - mu_f z_f, w_f = sum_i mean_i c_i, z_f = sum_i c_i (c_i = x_i - mean_i).
+// spr_colsums_f64 produces z_f and w_f (one extra read of X, only for this option);
+// spr_fill_feature_f64 expands a per-feature scalar to a per-row vector (the new X_cnt).
+namespace {
+
+__global__ __launch_bounds__(256) void colsums_kernel(const double *__restrict__ X, int64_t ldx, int m, SegPlan plan,
+                                                      const double *__restrict__ rowmean, double *__restrict__ part) {
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  double z[2] = {0.0, 0.0}, w[2] = {0.0, 0.0};
+  for (int64_t row = lo + wl; row < hi; row += wpf) {
+    const double mu = rowmean[row];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = threadIdx.x + 256 * q;
+      if (c < m) {
+        const double d = X[row * ldx + c] - mu;
+        z[q] += d;
+        w[q] += mu * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = threadIdx.x + 256 * q;
+    if (c < m) {
+      part[((int64_t)blockIdx.x * 2 + 0) * m + c] = z[q];
+      part[((int64_t)blockIdx.x * 2 + 1) * m + c] = w[q];
+    }
+  }
+}
+
+__global__ void colsums_finalize_kernel(const double *__restrict__ part, int m, SegPlan plan, double *__restrict__ out) {
+  const int f = blockIdx.x;
+  int base = 0, wpf = 0, acc = 0;
+  for (int ff = seg_first_feature(plan); ff <= seg_last_feature(plan); ++ff) {
+    int64_t lo, hi;
+    seg_range(plan, ff, lo, hi);
+    const int wgs = seg_wgs(plan, hi - lo);
+    if (ff == f) { base = acc; wpf = wgs; }
+    acc += wgs;
+  }
+  for (int e = threadIdx.x; e < 2 * m; e += blockDim.x) {
+    const int k = e / m, c = e - k * m;
+    double s = 0.0;
+    for (int p = 0; p < wpf; ++p) s += part[((int64_t)(base + p) * 2 + k) * m + c];
+    out[((int64_t)f * 2 + k) * m + c] = s;
+  }
+}
+
+__global__ void fill_feature_kernel(double *__restrict__ out, int64_t n_rows, int64_t row0, int64_t n_points,
+                                    int n_features, const double *__restrict__ values) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t f = (row0 + i) / n_points;
+    if (f > n_features - 1) f = n_features - 1;
+    out[i] = values[f];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t spr_colsums_workspace(int32_t m, int32_t n_features) {
+  const int cus = spr_cached_cus();
+  return sizeof(double) * 2 * (size_t)(m > 0 ? m : 1) * ((size_t)4 * (cus > 0 ? cus : 256) + (size_t)n_features);
+}
+
+extern "C" int spr_colsums_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
+                               void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_out && d_workspace, SPR_E_INVALID, "spr_colsums_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && m > 0 && m <= 512 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
+                  row0 + n_rows <= n_points * (int64_t)n_features,
+              SPR_E_INVALID, "spr_colsums_f64: bad shape");
+  SPR_REQUIRE(workspace_bytes >= spr_colsums_workspace(m, n_features), SPR_E_WORKSPACE,
+              "spr_colsums_f64: workspace too small");
+  const int cus = spr_cached_cus();
+  SegPlan plan;
+  plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
+  plan.total_wg = 4 * (cus > 0 ? cus : 256); plan.chunk_rows = 1;
+  const int grid = seg_total_wgs(plan);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(colsums_kernel, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, plan, d_rowmean,
+                     static_cast<double *>(d_workspace));
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsums_finalize_kernel, dim3(n_features), dim3(256), 0, st,
+                     static_cast<const double *>(d_workspace), (int)m, plan, d_out);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+extern "C" int spr_fill_feature_f64(double *d_out, int64_t n_rows, int64_t row0, int64_t n_points, int32_t n_features,
+                                    const double *d_values, void *stream) {
+  SPR_REQUIRE(d_out && d_values, SPR_E_INVALID, "spr_fill_feature_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && row0 >= 0 && n_points > 0 && n_features > 0, SPR_E_INVALID,
+              "spr_fill_feature_f64: bad shape");
+  hipLaunchKernelGGL(fill_feature_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     d_out, n_rows, row0, n_points, (int)n_features, d_values);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}

@@ -141,6 +141,22 @@ class HipEngine:
                                                    ws.numel(), self._stream()), 'spr_feature_minmax_f64')
         return out
 
+    def colsums(self, X, row0, n_points, n_features, rowmean):
+        """-> (F, 2, m): sum_i c_i and sum_i mean_i c_i per feature (c_i = x_i - mean_i), local rows."""
+        n, m, ld = self._check_matrix(X)
+        out = self.empty((n_features, 2, m))
+        ws = self._workspace('colsums', self.lib.spr_colsums_workspace(m, n_features))
+        _lib.check(self.lib.spr_colsums_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(rowmean), _ptr(out),
+                                            _ptr(ws), ws.numel(), self._stream()), 'spr_colsums_f64')
+        return out
+
+    def fill_feature(self, n_rows, row0, n_points, values):
+        """-> (n_rows,) vector holding values[feature of the row]."""
+        out = self.empty((n_rows,))
+        _lib.check(self.lib.spr_fill_feature_f64(_ptr(out), n_rows, row0, n_points, values.shape[0], _ptr(values),
+                                                 self._stream()), 'spr_fill_feature_f64')
+        return out
+
     # ---- K2 / K11 stand-alone ---------------------------------------------------------------
     def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
         n, m, ld = self._check_matrix(X)

@@ -29,7 +29,7 @@ What differs from the reference, by design:
   * fitted arrays live in HBM; ``X_cnt``, ``X_scl``, ``Ur``, ... are copied to NumPy on
     first access;
   * options that have no device implementation yet ('gem' placement, 'COLS', scalings
-    'median' / 'vast_2..4', ``axis_cnt=None``) raise ``NotImplementedError`` --
+    'median' / 'vast_2..4') raise ``NotImplementedError`` --
     they never fall back to a CPU path.
 
 Row sharding: pass ``shard=RowShard(row0, n_global, group)`` and the local block of rows;
@@ -269,9 +269,9 @@ class ROM:
         if scale_type not in self._DEVICE_SCALINGS:
             raise NotImplementedError(f"scale_type={scale_type!r} has no device implementation (needs a per-feature "
                                       'median / kurtosis); no CPU fallback.')
-        if axis_cnt != 1:
-            raise NotImplementedError(f'axis_cnt={axis_cnt!r}: only row centring (axis_cnt=1) has a device '
-                                      'implementation (no CPU fallback).')
+        if axis_cnt not in (1, None):
+            raise NotImplementedError(f'axis_cnt={axis_cnt!r}: row centring (1) and scalar centring (None) have a '
+                                      'device implementation; no CPU fallback for the rest.')
 
     def _feature_scale(self, scale_type, cnt, mu, var, m):
         """Per-feature scaling factor (:114-161) from the merged block statistics: cnt rows, block mean mu,
@@ -300,7 +300,7 @@ class ROM:
             fmin, fmax = mm[:, :, 0].min(axis=0), mm[:, :, 1].max(axis=0)
             return fmax - fmin if scale_type == 'range' else fmax
 
-    def _stats_pass(self, scale_type='std'):
+    def _stats_pass(self, scale_type='std', axis_cnt=1):
         """Fused K1+K3a pass, cross-rank merge, per-feature scale. Leaves rowmean/scale on the device."""
         eng = self._engine()
         Xd = self._Xd()
@@ -328,6 +328,13 @@ class ROM:
             var_f = (tr + m * m2) / (cnt * m)                # population variance of the raw block (:115)
         self._scl_f = self._feature_scale(scale_type, cnt, mu, var_f, m)
         self._var_f = self._scl_f ** 2                        # what the Gram blocks are divided by
+        if axis_cnt is None:
+            # scalar centre per feature (:112 with axis=None): turn the row-centred Gram blocks into those
+            # of (X - mu_f) with the two column-sum vectors, and make X_cnt the per-feature constant
+            cs = eng.to_host(self._all_reduce(eng.colsums(Xd, self._row0, self.n_points, F, rowmean)))
+            v = cs[:, 1, :] - mu[:, None] * cs[:, 0, :]       # sum_i (mean_i - mu_f) c_i
+            G_f = G_f + v[:, :, None] + v[:, None, :] + m2[:, None, None]
+            rowmean = eng.fill_feature(Xd.shape[0], self._row0, self.n_points, eng.to_device(mu))
         self._G_f = G_f
         self._d['rowmean'] = rowmean
         self._d['scale'] = eng.to_device(self._scl_f)
@@ -340,7 +347,7 @@ class ROM:
     def scale_data(self, scale_type='std', axis_cnt=1):
         """Reference :83-171.  Sets X_cnt / X_scl and returns the scaled matrix X0."""
         self._check_scaling(scale_type, axis_cnt)
-        self._stats_pass(scale_type)
+        self._stats_pass(scale_type, axis_cnt)
         return self.X0
 
     def _csr_device(self, C, known=None):
@@ -474,7 +481,7 @@ class ROM:
             raise ValueError('The select_mode value is wrong.')
         eng = self._engine()
         self.scale_type = scale_type
-        self._stats_pass(scale_type)
+        self._stats_pass(scale_type, axis_cnt)
         self._host.clear()
         if basis is None:
             with np.errstate(invalid='ignore', divide='ignore'):

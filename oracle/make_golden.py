@@ -58,14 +58,14 @@ def synth(n_points, n_features, m, k, rho, eps, seed):
 
 
 def run_case(sps, name, X, n_features, select_modes, n_modes, seed, mask_frac=None, store_X0=False,
-             scale_type='std'):
+             scale_type='std', axis_cnt=1):
     n, m = X.shape
     n_points = n // n_features
     rng = np.random.default_rng(seed + 7)
     xyz = rng.random((n_points, 3))
     spr = sps.SPR(X.copy(), n_features, xyz)
-    spr.fit(scale_type=scale_type, select_modes=select_modes, n_modes=n_modes)
-    out = dict(X=X, scale_type=np.array(scale_type), n_features=np.int64(n_features), select_modes=np.array(select_modes),
+    spr.fit(scale_type=scale_type, axis_cnt=axis_cnt, select_modes=select_modes, n_modes=n_modes)
+    out = dict(X=X, scale_type=np.array(scale_type), axis_cnt=np.int64(-1 if axis_cnt is None else axis_cnt), n_features=np.int64(n_features), select_modes=np.array(select_modes),
                n_modes=np.float64(n_modes), X_cnt=spr.X_cnt, X_scl=spr.X_scl,
                Ur=np.array(spr.Ur), Ar=np.array(spr.Ar), Vr=spr.Vr, Sigma_r=spr.Sigma_r,
                r=np.int64(spr.r))
@@ -157,6 +157,9 @@ def main():
     X = synth(500, 3, 12, 12, 0.7, 1e-3, 202) * 0.05 + 5.0
     for k, st in enumerate(['none', 'pareto', 'vast', 'level', 'variance', 'poisson', 'l2-norm', 'range', 'max']):
         run_case(sps, 'g5_' + st.replace('-', ''), X, 3, 'number', 4, 500 + k, scale_type=st)
+    # scalar centring per feature (axis_cnt=None, tests/test_rom.py:23-29)
+    run_case(sps, 'g6_axisnone', X, 3, 'number', 4, 600, axis_cnt=None)
+    run_case(sps, 'g6_axisnone_pareto', X, 3, 'number', 5, 601, axis_cnt=None, scale_type='pareto')
 
 
 if __name__ == '__main__':

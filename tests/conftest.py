@@ -28,6 +28,7 @@ def load_golden(name):
     g['n_modes'] = int(nm) if g['select_modes'] == 'number' else nm
     g['name'] = name
     g['scale_type'] = str(g['scale_type']) if 'scale_type' in g else 'std'
+    g['axis_cnt'] = None if ('axis_cnt' in g and int(g['axis_cnt']) < 0) else 1
     return g
 
 

@@ -56,7 +56,7 @@ class NumpyEngine:
     def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
         x = X.numpy()
         n = x.shape[0]
-        mean = x.mean(axis=1) if center else np.zeros(n)
+        mean = (rowmean.numpy() if rowmean is not None else x.mean(axis=1)) if center else np.zeros(n)
         feat = self._feat(n, row0, n_points, n_features)
         U = ((x - mean[:, None]) @ W.numpy()) * inv_scale.numpy()[feat][:, None]
         return torch.from_numpy(np.ascontiguousarray(U))
@@ -69,6 +69,20 @@ class NumpyEngine:
             sel = feat == f
             out[f] = (x[sel].min(), x[sel].max()) if sel.any() else (np.inf, -np.inf)
         return torch.from_numpy(out)
+
+    def colsums(self, X, row0, n_points, n_features, rowmean):
+        x, mu = X.numpy(), rowmean.numpy()
+        c = x - mu[:, None]
+        feat = self._feat(x.shape[0], row0, n_points, n_features)
+        out = np.zeros((n_features, 2, x.shape[1]))
+        for f in range(n_features):
+            sel = feat == f
+            out[f, 0] = c[sel].sum(axis=0)
+            out[f, 1] = (mu[sel, None] * c[sel]).sum(axis=0)
+        return torch.from_numpy(out)
+
+    def fill_feature(self, n_rows, row0, n_points, values):
+        return torch.from_numpy(values.numpy()[self._feat(n_rows, row0, n_points, values.shape[0])].copy())
 
     def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
         feat = self._feat(X.shape[0], row0, n_points, n_features)

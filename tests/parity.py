@@ -30,7 +30,8 @@ def run_fixture(g, engine, check_pivots=True):
     n, m = X.shape
     F = g['n_features']
     spr = SPR(X, F, None, engine=engine)
-    spr.fit(scale_type=g.get('scale_type', 'std'), select_modes=g['select_modes'], n_modes=g['n_modes'])
+    spr.fit(scale_type=g.get('scale_type', 'std'), axis_cnt=g.get('axis_cnt', 1), select_modes=g['select_modes'],
+            n_modes=g['n_modes'])
     r = g['r']
     assert spr.r == r
     # a2: centring / scaling

@@ -42,7 +42,8 @@ def _worker(rank, world, port, fixture, out_dir):
         row0 = rank * n_loc
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None,
                   shard=RowShard(row0, n), engine=NumpyEngine())
-        spr.fit(scale_type=g['scale_type'], select_modes=g['select_modes'], n_modes=g['n_modes'])
+        spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'],
+                n_modes=g['n_modes'])
         mask = g.get('mask')
         C = spr.optimal_placement(mask=None if mask is None else mask[row0:row0 + n_loc])
         spr.train(C)
@@ -56,7 +57,7 @@ def _worker(rank, world, port, fixture, out_dir):
 
 
 @pytest.mark.parametrize('fixture,world', [('g2_num4', 2), ('g2_num4', 3), ('g3_num8', 2), ('g2_num4_mask', 2), ('g4_num5', 3),
-                                           ('g5_range', 2), ('g5_l2norm', 3)])
+                                           ('g5_range', 2), ('g5_l2norm', 3), ('g6_axisnone', 2)])
 def test_sharded_path_matches_reference(tmp_path, fixture, world):
     from tests.conftest import load_golden
     from tests.parity import REL_FRO, align_signs, rel_fro

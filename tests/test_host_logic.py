@@ -59,7 +59,7 @@ def test_unsupported_options_raise_not_fallback(small):
     with pytest.raises(NotImplementedError):
         spr.fit(scale_type='bogus')                    # :164
     with pytest.raises(NotImplementedError):
-        spr.fit(axis_cnt=None)
+        spr.fit(axis_cnt=0)
     spr.fit(n_modes=100)
     with pytest.raises(NotImplementedError):
         spr.optimal_placement(calc_type='gem')

@@ -8,11 +8,12 @@ from oracle import spr_oracle as orc
 
 
 def _fit(g):
-    return orc.fit(g['X'], g['n_features'], g['select_modes'], g['n_modes'], scale_type=g['scale_type'])
+    return orc.fit(g['X'], g['n_features'], g['select_modes'], g['n_modes'], scale_type=g['scale_type'],
+                   axis_cnt=g['axis_cnt'])
 
 
 def test_scale_data_bit_exact(golden):
-    X_cnt, X_scl, X0 = orc.scale_data(golden['X'], golden['n_features'], golden['scale_type'])
+    X_cnt, X_scl, X0 = orc.scale_data(golden['X'], golden['n_features'], golden['scale_type'], golden['axis_cnt'])
     np.testing.assert_array_equal(X_cnt, golden['X_cnt'])
     np.testing.assert_array_equal(X_scl, golden['X_scl'])
     if 'X0' in golden:

@@ -17,6 +17,15 @@
 #pragma once
 #include "common.hpp"
 
+// Wave-uniform "no selects needed" fast paths.  Measured: the extra branch costs more than the selects it
+// saves in the projection staging (basic-block split -> conservative waits), so it is off there.
+#ifndef ROWTILE_RAW_FAST
+#define ROWTILE_RAW_FAST 0
+#endif
+#ifndef ROWTILE_CENTER_FAST
+#define ROWTILE_CENTER_FAST 1
+#endif
+
 struct RowStats {  // running statistics of the row means seen by one lane group
   // Shifted sums: d = x - ref with ref = the first row mean seen, so no division sits in the
   // streaming loop; converted to the (count, mean, M2) form that Chan's merge wants at the end.
@@ -112,8 +121,12 @@ struct RowTile {
     const bool rv = crow0 + rloc < seg_hi;
     const int col = 2 * (lig + v * LPR);
     f64x2 c = pre[it][v];
-    c.x = (rv && col < m) ? c.x : 0.0;
-    c.y = (rv && col + 1 < m) ? c.y : 0.0;
+    // wave-uniform fast path: whole pass inside the segment and no padded columns -> no selects
+    const bool fast = ROWTILE_RAW_FAST && (crow0 + (it + 1) * ROWS_PER_IT <= seg_hi) && (m == MPAD);
+    if (!fast) {
+      c.x = (rv && col < m) ? c.x : 0.0;
+      c.y = (rv && col + 1 < m) ? c.y : 0.0;
+    }
     if constexpr (WIDE_STORE) {
       *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
     } else {
@@ -142,7 +155,7 @@ struct RowTile {
     const int64_t lrow = crow0 + rloc;
     const bool rv = lrow < seg_hi;
     // wave-uniform fast path: whole pass inside the segment and no padded columns -> no selects
-    const bool fast = (crow0 + (it + 1) * ROWS_PER_IT <= seg_hi) && (m == MPAD);
+    const bool fast = ROWTILE_CENTER_FAST && (crow0 + (it + 1) * ROWS_PER_IT <= seg_hi) && (m == MPAD);
     if (fast) {
       double s = 0.0;
 #pragma unroll

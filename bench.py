@@ -36,6 +36,8 @@ WORKLOADS = {
     'c2': dict(cells=1_000_000, features=4, m=64, s=32, cpu_cells=1_000_000),
     'c3': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=100_000),
     'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000),   # c3 at 1/10 of the rows
+    # config-5 shape (16 features x 512 snapshots, 128 sensors) in f64 at 1M cells/GPU (65.5 GB): the column-split path
+    'c5s': dict(cells=1_000_000, features=16, m=512, s=128, cpu_cells=15_000),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F64_PEAK_TF = 78.6     # AMD public spec for MI355X FP64 matrix; tools/mfma_probe measures 73.6 on the box

@@ -38,7 +38,8 @@ extern "C" {
 #define SPR_E_HIP (-3)       /* a HIP runtime call failed                        */
 #define SPR_E_WORKSPACE (-4) /* workspace too small                              */
 
-#define SPR_MAX_M 256        /* snapshots (columns of X) supported by the Gram kernel */
+#define SPR_MAX_M 256        /* snapshots (columns of X) one Gram / projection launch handles   */
+#define SPR_MAX_M_WIDE 512   /* ... and with the column-split path (spr_rowstats / spr_gram_cross) */
 #define SPR_MAX_R 128        /* retained modes / sensors                              */
 
 int spr_abi_version(void);
@@ -67,18 +68,39 @@ int spr_stats_gram_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx
                        double *d_rowmean, void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_stats_gram_finalize_f64(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points,
                                 int32_t n_features, const void *d_workspace, size_t workspace_bytes,
-                                double *d_fstats, double *d_gram, void *stream);
+                                double *d_fstats, double *d_gram, int32_t ldg, int32_t origin,
+                                void *stream);
+/* ldg / origin: the m x m block is written at (origin, origin) of per-feature ldg x ldg matrices
+ * (ldg = m, origin = 0 for a stand-alone Gram).
+ *
+ * 256 < m <= 512 (column-split path, csrc/gram_wide.hip): columns A = [0,256), B = [256,m).
+ *   spr_rowstats_f64      row means of the FULL rows + per-feature statistics (one read of X);
+ *   spr_stats_gram_f64    on the slices (d_X, 256) and (d_X + 256, m - 256), ldx = full stride,
+ *                         center = 2: the row means are READ from d_rowmean (no statistics; give
+ *                         the finalize call a scratch d_fstats), finalize with ldg = m and
+ *                         origin = 0 / 256;
+ *   spr_gram_cross_f64    A^T B and its transpose into the same ldg = m matrices (center = 2 or 0). */
+size_t spr_rowstats_workspace(int32_t n_features);
+int spr_rowstats_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                     int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
+                     void *d_workspace, size_t workspace_bytes, void *stream);
+size_t spr_gram_cross_workspace(int32_t m, int32_t n_features);
+int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                       int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                       double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- K4 : basis projection  Ur = X0 . W,  W = V_r Sigma_r^-1 (m x r) ----------------
  * Replaces the U factor of np.linalg.svd (:272) and the truncation U[:, :r] (:336).
  * Second read of X.  center = 1: d_rowmean (the row means written by spr_stats_gram_f64)
  * is removed in the epilogue as x.W - mean*(1^T W); the per-feature 1/X_scl
  * (d_inv_scale[n_features]) is applied there too, so X0 never exists.  center = 0:
- * rows are used as they are (d_rowmean may be NULL). */
+ * rows are used as they are (d_rowmean may be NULL).  accumulate = 1 adds to d_Ur instead of
+ * overwriting it: a wider X (m <= 512) is projected as two column slices, (d_X, d_W) and
+ * (d_X + 256, d_W + 256 r), the second one accumulating. */
 int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx,
                     int64_t row0, int64_t n_points, int32_t n_features, int32_t center,
                     const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
-                    double *d_Ur, int64_t ldu, void *stream);
+                    double *d_Ur, int64_t ldu, int32_t accumulate, void *stream);
 
 /* ---- K2 / K11 as stand-alone calls (ROM.scale_data's return value, ROM.unscale_data) --
  * spr_scale_rows:  X0 = (X - rowmean) * inv_scale[feature]   (:169), n_rows x m.

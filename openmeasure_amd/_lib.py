@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libspr_hip.so')
 
 SPR_MAX_M = 256
+SPR_MAX_M_WIDE = 512
 SPR_MAX_R = 128
 
 _i32, _i64, _u64, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
@@ -32,8 +33,12 @@ PROTOTYPES = {
     'spr_device_cus': (C.c_int, [C.POINTER(C.c_int)]),
     'spr_stats_gram_workspace': (_sz, [_i32, _i32]),
     'spr_stats_gram_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),
-    'spr_stats_gram_finalize_f64': (C.c_int, [_i64, _i32, _i64, _i64, _i32, _p, _sz, _p, _p, _p]),
-    'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
+    'spr_stats_gram_finalize_f64': (C.c_int, [_i64, _i32, _i64, _i64, _i32, _p, _sz, _p, _p, _i32, _i32, _p]),
+    'spr_rowstats_workspace': (_sz, [_i32]),
+    'spr_rowstats_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
+    'spr_gram_cross_workspace': (_sz, [_i32, _i32]),
+    'spr_gram_cross_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
+    'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _i32, _p]),
     'spr_scale_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
     'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     'spr_feature_minmax_workspace': (_sz, [_i32]),

@@ -1,0 +1,270 @@
+// Gram matrix for 256 < m <= 512 snapshots (BASELINE config 5 has m = 512).
+//
+// One workgroup cannot hold the 528 upper tiles of a 512 x 512 Gram matrix in registers, so
+// the columns are split into A = [0, 256) and B = [256, m):
+//     G = [ A^T A   A^T B ]      A^T A, B^T B : the symmetric kernel of stats_gram.hip on column
+//         [ B^T A   B^T B ]                     slices (ldx = full row stride, centre mode 2),
+//                                A^T B        : gram_cross_kernel below.
+// The row means must be those of the WHOLE row, so they are produced first by a light streaming
+// pass (rowstats_kernel: row means + per-feature Welford partials) and handed to the three Gram
+// launches as external means.  MFMA work is exactly the 528 tiles (136 + 136 + 256); X is read
+// 1 + 1 + 2 times instead of once, which at m > 256 is still far below the MFMA time.
+#include "rowtile.hpp"
+
+namespace {
+
+__device__ inline void chan_merge_w(double &n, double &mu, double &m2, double nb, double mb, double sb) {
+  if (nb > 0.0) {
+    const double tot = n + nb, d = mb - mu;
+    mu += d * nb / tot;
+    m2 += sb + d * d * n * nb / tot;
+    n = tot;
+  }
+}
+
+// ---- row means + per-feature statistics of full rows (any m) --------------------------------
+__global__ __launch_bounds__(256) void rowstats_kernel(const double *__restrict__ X, int64_t ldx, int m, int vec_ok,
+                                                       SegPlan plan, double *__restrict__ rowmean,
+                                                       double *__restrict__ stat_part) {
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double inv_m = 1.0 / (double)m;
+  RowStats st;
+  st.init();
+  for (int64_t row = lo + (int64_t)wl * 4 + wave; row < hi; row += (int64_t)wpf * 4) {
+    const double *rp = X + row * ldx;
+    double s = 0.0;
+    if (vec_ok) {
+      for (int c = 2 * lane; c < m; c += 128) {
+        const f64x2 t = *reinterpret_cast<const f64x2 *>(rp + c);
+        s += t.x + t.y;
+      }
+    } else {
+      for (int c = lane; c < m; c += 64) s += rp[c];
+    }
+    s = group_sum_t<64>(s);
+    const double mean = s * inv_m;
+    if (lane == 0) rowmean[row] = mean;
+    st.push(mean, true);
+  }
+  if (lane == 0) {
+    double *q = stat_part + ((int64_t)blockIdx.x * 4 + wave) * 3;
+    q[0] = st.cnt; q[1] = st.mean(); q[2] = st.m2();
+  }
+}
+
+__global__ void rowstats_finalize_kernel(const double *__restrict__ stat_part, SegPlan plan, double *__restrict__ fstats) {
+  const int f = blockIdx.x;
+  int base = 0, wpf = 0, acc = 0;
+  for (int ff = seg_first_feature(plan); ff <= seg_last_feature(plan); ++ff) {
+    int64_t lo, hi;
+    seg_range(plan, ff, lo, hi);
+    const int w = seg_wgs(plan, hi - lo);
+    if (ff == f) { base = acc; wpf = w; }
+    acc += w;
+  }
+  if (threadIdx.x == 0) {   // fixed order: reproducible
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    const double *q = stat_part + (int64_t)base * 4 * 3;
+    for (int p = 0; p < wpf * 4; ++p) chan_merge_w(n, mu, m2, q[3 * p], q[3 * p + 1], q[3 * p + 2]);
+    fstats[3 * f] = n; fstats[3 * f + 1] = mu; fstats[3 * f + 2] = m2;
+  }
+}
+
+// ---- cross block A^T B ------------------------------------------------------------------------
+// Panels of 16 full rows (both column halves) in LDS, centred with the external row means.  Two
+// workgroup flavours (og = 0, 1) share the 16 tile rows of A: wave w of flavour og owns tile row
+// ti = 8 og + w and all NTJ tile columns of B -- one A fragment and NTJ B fragments per k step for
+// NTJ MFMAs, everything at compile-time offsets except the wave's own A column block.
+constexpr int CW = 8;        // waves
+constexpr int CR = 16;       // panel rows
+constexpr int CMA = 256;     // width of A
+
+template <int NTJ, int VEC>
+__global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const double *__restrict__ X, int64_t ldx, int m,
+                                                            int center, SegPlan plan,
+                                                            const double *__restrict__ rowmean,
+                                                            double *__restrict__ slab) {
+  constexpr int MTF = 16 + NTJ;                 // padded full width in tiles
+  constexpr int MP = 16 * MTF + ((MTF % 2 == 0) ? 16 : 0);
+  constexpr int KSTEPS = CR / 4;
+  using RT = RowTile<MTF, CR, MP, CW, 32>;
+  __shared__ double lds[2][CR * MP];
+
+  const int og = blockIdx.x & 1;
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x >> 1, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ti = og * 8 + wave;
+
+  f64x4 acc[NTJ];
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j) acc[j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  RT tile;
+  RowStats st;   // unused (external means), required by the staging interface
+  st.init();
+  const double *mean_in = rowmean;
+  const int64_t nchunks = (hi - lo + CR - 1) / CR;
+  int64_t c = wl;
+  tile.template load<VEC>(X, ldx, m, lo + c * CR, hi, wave, lane, mean_in);
+  tile.template center_store<false>(lds[0], m, center, lo + c * CR, hi, wave, lane, nullptr, &st);
+  int64_t cn = c + wpf;
+  int64_t nrow0 = (cn < nchunks) ? lo + cn * CR : hi;
+  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in);
+  int buf = 0;
+  const int frag = (lane >> 4) * MP + (lane & 15);
+  while (c < nchunks) {
+    double *cur = lds[buf];
+    double *nxt = lds[buf ^ 1];
+    const int64_t c2 = cn + wpf;
+    const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * CR : hi;
+    __syncthreads();
+    const double *pa = cur + frag + 16 * ti;
+    const double *pb = cur + frag + CMA;
+#pragma unroll
+    for (int k = 0; k < KSTEPS; ++k) {
+      const double a = pa[k * 4 * MP];
+      double b[NTJ];
+#pragma unroll
+      for (int j = 0; j < NTJ; ++j) b[j] = pb[k * 4 * MP + 16 * j];
+#pragma unroll
+      for (int j = 0; j < NTJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[j], 0, 0, 0);
+      if (k == 0) {
+        tile.template center_store_pass<false>(0, nxt, m, center, nrow0, hi, wave, lane, nullptr, &st);
+        tile.template load_pass<VEC>(0, X, ldx, m, n2row0, hi, wave, lane, mean_in);
+      }
+    }
+    buf ^= 1;
+    c = cn;
+    cn = c2;
+    nrow0 = n2row0;
+  }
+  // slab[(block >> 1)][ti][tj][reg][lane]   (the two flavours of a block pair write disjoint tile rows)
+  double *sp = slab + (((int64_t)(blockIdx.x >> 1) * 16 + ti) * NTJ) * 256 + lane;
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j) {
+    double *tp = sp + (int64_t)j * 256;
+    tp[0] = acc[j].x; tp[64] = acc[j].y; tp[128] = acc[j].z; tp[192] = acc[j].w;
+  }
+}
+
+// grid (16 * NTJ tiles, n_features), 256 threads: fixed-order sum over the feature's block pairs
+template <int NTJ>
+__global__ __launch_bounds__(256) void gram_cross_finalize_kernel(const double *__restrict__ slab, int m, SegPlan plan,
+                                                                  double *__restrict__ gram) {
+  const int f = blockIdx.y;
+  const int ti = blockIdx.x / NTJ, tj = blockIdx.x % NTJ;
+  int base = 0, wpf = 0, acc = 0;
+  for (int ff = seg_first_feature(plan); ff <= seg_last_feature(plan); ++ff) {
+    int64_t lo, hi;
+    seg_range(plan, ff, lo, hi);
+    const int w = seg_wgs(plan, hi - lo);
+    if (ff == f) { base = acc; wpf = w; }
+    acc += w;
+  }
+  const int e = threadIdx.x;
+  double s = 0.0;
+  for (int p = 0; p < wpf; ++p) s += slab[((((int64_t)(base + p) * 16 + ti) * NTJ) + tj) * 256 + e];
+  const int l = e & 63, reg = e >> 6;
+  const int gi = ti * 16 + (l >> 4) + 4 * reg, gj = CMA + tj * 16 + (l & 15);
+  if (gj < m) {
+    double *G = gram + (int64_t)f * m * m;
+    G[(int64_t)gi * m + gj] = s;
+    G[(int64_t)gj * m + gi] = s;
+  }
+}
+
+int plan_wgs(SegPlan &plan, int64_t n_rows, int64_t row0, int64_t n_points, int32_t n_features, int chunk_rows,
+             int per_cu) {
+  const int cus = spr_cached_cus();
+  plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
+  plan.total_wg = per_cu * (cus > 0 ? cus : 256);
+  plan.chunk_rows = chunk_rows;
+  return seg_total_wgs(plan);
+}
+
+template <int NTJ>
+int launch_cross(const double *X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
+                 int32_t n_features, int center, const double *rowmean, double *gram, void *ws, size_t ws_bytes,
+                 hipStream_t st) {
+  SegPlan plan;
+  const int pairs = plan_wgs(plan, n_rows, row0, n_points, n_features, CR, 1);   // one workgroup per CU: 2 flavours share them
+  // halve the pair count so that pairs * 2 workgroups still fit one per CU
+  plan.total_wg = plan.total_wg / 2 > 0 ? plan.total_wg / 2 : 1;
+  const int npairs = seg_total_wgs(plan);
+  (void)pairs;
+  const size_t need = (size_t)npairs * 16 * NTJ * 256 * sizeof(double);
+  SPR_REQUIRE(ws_bytes >= need, SPR_E_WORKSPACE, "spr_gram_cross_f64: workspace %zu < %zu", ws_bytes, need);
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  double *slab = static_cast<double *>(ws);
+  if (vec_ok)
+    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 1>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
+                       rowmean, slab);
+  else
+    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 0>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
+                       rowmean, slab);
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_cross_finalize_kernel<NTJ>, dim3(16 * NTJ, n_features), dim3(256), 0, st, slab, m, plan, gram);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t spr_rowstats_workspace(int32_t n_features) {
+  const int cus = spr_cached_cus();
+  return sizeof(double) * 3 * 4 * ((size_t)8 * (cus > 0 ? cus : 256) + (size_t)n_features);
+}
+
+extern "C" int spr_rowstats_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
+                                void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_fstats && d_workspace, SPR_E_INVALID, "spr_rowstats_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
+                  row0 + n_rows <= n_points * (int64_t)n_features,
+              SPR_E_INVALID, "spr_rowstats_f64: bad shape");
+  SPR_REQUIRE(workspace_bytes >= spr_rowstats_workspace(n_features), SPR_E_WORKSPACE,
+              "spr_rowstats_f64: workspace too small");
+  SegPlan plan;
+  const int grid = plan_wgs(plan, n_rows, row0, n_points, n_features, 4, 8);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
+  hipLaunchKernelGGL(rowstats_kernel, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, vec_ok, plan, d_rowmean,
+                     static_cast<double *>(d_workspace));
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rowstats_finalize_kernel, dim3(n_features), dim3(64), 0, st,
+                     static_cast<const double *>(d_workspace), plan, d_fstats);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+extern "C" size_t spr_gram_cross_workspace(int32_t m, int32_t n_features) {
+  const int cus = spr_cached_cus();
+  const int ntj = (m - CMA + 15) / 16;
+  const size_t pairs = (size_t)(cus > 0 ? cus : 256) + (size_t)n_features;
+  return pairs * 16 * (size_t)(ntj > 0 ? ((ntj + 3) / 4) * 4 : 4) * 256 * sizeof(double);
+}
+
+extern "C" int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                                  double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_gram && d_workspace, SPR_E_INVALID, "spr_gram_cross_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && m > CMA && m <= 512 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
+                  row0 + n_rows <= n_points * (int64_t)n_features,
+              SPR_E_INVALID, "spr_gram_cross_f64: bad shape (m must be in (256, 512])");
+  SPR_REQUIRE(center == 0 || center == 2, SPR_E_INVALID, "spr_gram_cross_f64: centre mode must be 0 or 2 (external means)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ntj = (m - CMA + 15) / 16;
+#define GX(N) return launch_cross<N>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_gram, \
+                                     d_workspace, workspace_bytes, st)
+  if (ntj <= 4) GX(4);
+  if (ntj <= 8) GX(8);
+  if (ntj <= 12) GX(12);
+  GX(16);
+#undef GX
+}

@@ -43,7 +43,7 @@ template <int MT, int RTILES, int VEC>
 __global__ __launch_bounds__(NW * 64) void project_kernel(
     const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     const double *__restrict__ inv_scale, const double *__restrict__ rowmean, const double *__restrict__ W, int r,
-    double *__restrict__ Ur, int64_t ldu) {
+    double *__restrict__ Ur, int64_t ldu, int accumulate) {
   constexpr int R = ProjRows<MT>::R;
   constexpr int MPAD = 16 * MT, MP = MPAD + PROJ_PAD;
   constexpr int KSTEPS = MPAD / 4;
@@ -146,16 +146,16 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
           const double s2 = (acc0.z + acc1.z - mu[2] * wbar) * isc, s3 = (acc0.w + acc1.w - mu[3] * wbar) * isc;
           if (PROJ_ABLATE == 3) asm volatile("" ::"v"(s0), "v"(s1), "v"(s2), "v"(s3));
           if (PROJ_ABLATE != 3) {
-            if (FULLP) {                                       // no predicates: one basic block per panel
+            if (FULLP && !accumulate) {                        // no predicates: one basic block per panel
               Ur[row * ldu + col] = s0;
               Ur[(row + 4) * ldu + col] = s1;
               Ur[(row + 8) * ldu + col] = s2;
               Ur[(row + 12) * ldu + col] = s3;
-            } else if (col < r) {
-              if (row < hi) Ur[row * ldu + col] = s0;
-              if (row + 4 < hi) Ur[(row + 4) * ldu + col] = s1;
-              if (row + 8 < hi) Ur[(row + 8) * ldu + col] = s2;
-              if (row + 12 < hi) Ur[(row + 12) * ldu + col] = s3;
+            } else if (col < r) {                              // accumulate: second column slice of a wide X
+              if (row < hi) Ur[row * ldu + col] = (accumulate ? Ur[row * ldu + col] : 0.0) + s0;
+              if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (accumulate ? Ur[(row + 4) * ldu + col] : 0.0) + s1;
+              if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (accumulate ? Ur[(row + 8) * ldu + col] : 0.0) + s2;
+              if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (accumulate ? Ur[(row + 12) * ldu + col] : 0.0) + s3;
             }
           }
         }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
 template <int MT, int RTILES>
 int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
            int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
-           double *Ur, int64_t ldu, hipStream_t st) {
+           double *Ur, int64_t ldu, int accumulate, hipStream_t st) {
   static int total_wg = 0;
   if (!total_wg) {
     int per_cu = 0;
@@ -197,7 +197,7 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   const int lm = vec_ok ? ((m == 16 * MT) ? 2 : 1) : 0;
 #define PJ_LAUNCH(LM)                                                                                         \
   hipLaunchKernelGGL((project_kernel<MT, RTILES, LM>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center, \
-                     plan, inv_scale, rowmean, W, (int)r, Ur, ldu)
+                     plan, inv_scale, rowmean, W, (int)r, Ur, ldu, accumulate)
   if (lm == 2) PJ_LAUNCH(2);
   else if (lm == 1) PJ_LAUNCH(1);
   else PJ_LAUNCH(0);
@@ -209,12 +209,12 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
 template <int MT>
 int launch_rt(int rt, const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
               int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
-              double *Ur, int64_t ldu, hipStream_t st) {
+              double *Ur, int64_t ldu, int accumulate, hipStream_t st) {
   switch (rt) {
-    case 1: return launch<MT, 1>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
-    case 2: return launch<MT, 2>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
-    case 4: return launch<MT, 4>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
-    case 8: return launch<MT, 8>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, st);
+    case 1: return launch<MT, 1>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 2: return launch<MT, 2>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 4: return launch<MT, 4>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 8: return launch<MT, 8>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
   }
   spr_set_error("spr_project_f64: r tile count %d not built", rt);
   return SPR_E_UNSUPPORTED;
@@ -225,12 +225,12 @@ int launch_rt(int rt, const double *X, int64_t n_rows, int32_t m, int64_t ldx, i
 extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                                int64_t n_points, int32_t n_features, int32_t center,
                                const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
-                               double *d_Ur, int64_t ldu, void *stream) {
+                               double *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
   SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && (d_rowmean || !center), SPR_E_INVALID,
               "spr_project_f64: NULL pointer");
   if (!center) d_rowmean = d_X;   // read (clamped, in range) but multiplied by a zero column sum
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "spr_project_f64: bad shape");
-  SPR_REQUIRE(r > 0 && r <= m && ldu >= r, SPR_E_INVALID, "spr_project_f64: bad r=%d (m=%d ldu=%lld)", r, m,
+  SPR_REQUIRE(r > 0 && ldu >= r, SPR_E_INVALID, "spr_project_f64: bad r=%d (m=%d ldu=%lld)", r, m,
               (long long)ldu);
   SPR_REQUIRE(n_points > 0 && n_features > 0 && row0 >= 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
@@ -239,7 +239,7 @@ extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int
   const int need = (r + 15) / 16;
   const int rt = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define PJ(MTV) return launch_rt<MTV>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, st)
+#define PJ(MTV) return launch_rt<MTV>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, st)
   switch (spr_round_mt(m)) {
     case 1: PJ(1);
     case 2: PJ(2);

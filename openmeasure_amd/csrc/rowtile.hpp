@@ -64,6 +64,7 @@ struct RowTile {
   static constexpr bool WIDE_STORE = (MP % 2 == 0);   // odd stride: rows are only 8-byte aligned in LDS
 
   f64x2 pre[IT][VPL];
+  double pmean[IT];   // centre mode 2: the caller-supplied row mean of each staged row (loaded with the row)
 
   // Pass `it` (a constant after unrolling) of the panel whose first local row is crow0.
   // VEC 0: any layout (8-byte loads); 1: rows 16-byte aligned, m even; 2: additionally m == 16*MT
@@ -71,11 +72,12 @@ struct RowTile {
   // and columns >= m re-read column 0; center_store_pass discards both.
   template <int VEC>
   __device__ inline void load_pass(int it, const double *__restrict__ X, int64_t ldx, int m, int64_t crow0,
-                                   int64_t seg_hi, int wave, int lane) {
+                                   int64_t seg_hi, int wave, int lane, const double *__restrict__ mean_in = nullptr) {
     const int grp = lane / LPR, lig = lane % LPR;
     int64_t lrow = crow0 + it * ROWS_PER_IT + wave * RPW + grp;
     lrow = lrow < seg_hi ? lrow : seg_hi - 1;
     const double *rp = X + lrow * ldx;
+    if (mean_in) pmean[it] = mean_in[lrow];   // callers pass either nullptr at compile time or a pointer that is always valid
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int col = 2 * (lig + v * LPR);
@@ -137,16 +139,16 @@ struct RowTile {
 
   template <int VEC>
   __device__ inline void load(const double *__restrict__ X, int64_t ldx, int m, int64_t crow0, int64_t seg_hi,
-                              int wave, int lane) {
+                              int wave, int lane, const double *__restrict__ mean_in = nullptr) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) load_pass<VEC>(it, X, ldx, m, crow0, seg_hi, wave, lane);
+    for (int it = 0; it < IT; ++it) load_pass<VEC>(it, X, ldx, m, crow0, seg_hi, wave, lane, mean_in);
   }
 
   // one pass of mean -> centre -> LDS; optionally stores the row means and feeds the running
   // statistics.  Split per pass so that a caller can slot the passes between the MFMA steps of
   // the previous panel.
   template <bool WRITE_MEAN>
-  __device__ inline void center_store_pass(int it, double *__restrict__ lds, int m, bool center, int64_t crow0,
+  __device__ inline void center_store_pass(int it, double *__restrict__ lds, int m, int center, int64_t crow0,
                                            int64_t seg_hi, int wave, int lane, double *__restrict__ rowmean,
                                            RowStats *st) {
     const int grp = lane / LPR, lig = lane % LPR;
@@ -161,10 +163,10 @@ struct RowTile {
 #pragma unroll
       for (int v = 0; v < VPL; ++v) s += pre[it][v].x + pre[it][v].y;
       s = group_sum_t<LPR>(s);
-      const double mean = center ? s * inv_m : 0.0;
+      const double mean = center == 2 ? pmean[it] : (center ? s * inv_m : 0.0);
       if (WRITE_MEAN) {
-        if (lig == 0) rowmean[lrow] = mean;
-        st->push(mean, true);
+        if (lig == 0 && center != 2) rowmean[lrow] = mean;
+        st->push(mean, center != 2);
       }
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
@@ -186,10 +188,10 @@ struct RowTile {
       s += (col < m ? pre[it][v].x : 0.0) + (col + 1 < m ? pre[it][v].y : 0.0);
     }
     s = group_sum_t<LPR>(s);
-    const double mean = center ? s * inv_m : 0.0;
+    const double mean = center == 2 ? pmean[it] : (center ? s * inv_m : 0.0);
     if (WRITE_MEAN) {
-      if (rv && lig == 0) rowmean[lrow] = mean;
-      st->push(mean, rv);
+      if (rv && lig == 0 && center != 2) rowmean[lrow] = mean;
+      st->push(mean, rv && center != 2);
     }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -238,7 +240,7 @@ struct RowTile {
   }
 
   template <bool WRITE_MEAN>
-  __device__ inline void center_store(double *__restrict__ lds, int m, bool center, int64_t crow0, int64_t seg_hi,
+  __device__ inline void center_store(double *__restrict__ lds, int m, int center, int64_t crow0, int64_t seg_hi,
                                       int wave, int lane, double *__restrict__ rowmean, RowStats *st) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)

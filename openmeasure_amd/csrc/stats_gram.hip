@@ -66,7 +66,7 @@ __device__ inline void tile_coords(int idx, int &ti, int &tj) {
 // an A and a B operand) and issues its MFMAs from registers; the fragments of step k+1 are
 // requested before the MFMAs of step k so LDS latency hides behind the 64-cycle MFMAs.
 template <int MT, int U, int VEC>
-__device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int m, bool center,
+__device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int m, int center,
                                  int64_t lo, int64_t hi, int wl, int wpf, int ks, int wave, int lane,
                                  double *__restrict__ lds0, double *__restrict__ lds1,
                                  double *__restrict__ rowmean, double *__restrict__ stat_part,
@@ -97,11 +97,15 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
   // one row pass between k steps, and then requests panel c+2 from HBM.
   const int64_t nchunks = (hi - lo + R - 1) / R;
   int64_t c = wl;
-  tile.template load<VEC>(X, ldx, m, lo + c * R, hi, wave, lane);
+  // centre mode 2 (column slice of a wider X): the row means come from rowmean[].  The load is issued in
+  // every mode (the array is always valid memory; the value is only selected in mode 2) so that the loop
+  // body keeps one shape and stays a single basic block.
+  const double *mean_in = rowmean;
+  tile.template load<VEC>(X, ldx, m, lo + c * R, hi, wave, lane, mean_in);
   tile.template center_store<true>(lds0, m, center, lo + c * R, hi, wave, lane, rowmean, &st);
   int64_t cn = c + wpf;
   int64_t nrow0 = (cn < nchunks) ? lo + cn * R : hi;      // past-the-end panel: every row invalid
-  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane);
+  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in);
   int buf = 0;
   const int frag = (lane >> 4) * MP + (lane & 15) + ks * KROWS * MP + RA * 16;
   while (c < nchunks) {
@@ -131,7 +135,7 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
         for (int it = 0; it < RT::IT; ++it)
           if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
             tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
-            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane);   // panel c+2 into the freed registers
+            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane, mean_in);   // panel c+2 into the freed registers
           }
       }
     } else {  // register-tight shapes: one operand set, three waves per SIMD cover the LDS latency
@@ -150,7 +154,7 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
         for (int it = 0; it < RT::IT; ++it)
           if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
             tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
-            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane);   // panel c+2 into the freed registers
+            tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane, mean_in);   // panel c+2 into the freed registers
           }
       }
     }
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
 #define GRAM_UNIT(UV)                                                                                        \
   case UV:                                                                                                   \
     if constexpr (UV < NU)                                                                                   \
-      gram_wave<MT, UV, VEC>(X, ldx, m, center_i != 0, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
+      gram_wave<MT, UV, VEC>(X, ldx, m, center_i, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
                         lds[1], rowmean, stat_part, slab);                                                   \
     break;
   switch (unit) {
@@ -225,7 +229,7 @@ __device__ inline void chan_merge(double &n, double &mu, double &m2, double nb, 
 template <int MT>
 __global__ __launch_bounds__(1024) void gram_finalize_kernel(
     const double *__restrict__ slab, const double *__restrict__ stat_part, int m, SegPlan plan,
-    int slots_per_wg, double *__restrict__ gram, double *__restrict__ fstats) {
+    int slots_per_wg, double *__restrict__ gram, double *__restrict__ fstats, int ldg, int origin) {
   constexpr int T = GramShape<MT>::T;
   constexpr int KS = GramCfg<MT>::KS;
   __shared__ double red[4][256];
@@ -266,9 +270,9 @@ __global__ __launch_bounds__(1024) void gram_finalize_kernel(
     const int l = e & 63, reg = e >> 6;
     const int gi = ti * 16 + (l >> 4) + 4 * reg, gj = tj * 16 + (l & 15);
     if (gi < m && gj < m) {
-      double *G = gram + (int64_t)f * m * m;
-      G[(int64_t)gi * m + gj] = sum;
-      if (ti != tj) G[(int64_t)gj * m + gi] = sum;
+      double *G = gram + (int64_t)f * ldg * ldg + (int64_t)origin * ldg + origin;   // block (origin, origin) of an ldg x ldg matrix
+      G[(int64_t)gi * ldg + gj] = sum;
+      if (ti != tj) G[(int64_t)gj * ldg + gi] = sum;
     }
   }
   if (tile == 0) {  // Chan merge of the Welford partials: strided per thread, then a fixed binary tree
@@ -350,7 +354,8 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
 
 template <int MT>
 int launch_finalize(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points, int32_t n_features,
-                    double *fstats, double *gram, const void *ws, size_t ws_bytes, hipStream_t st) {
+                    double *fstats, double *gram, int ldg, int origin, const void *ws, size_t ws_bytes,
+                    hipStream_t st) {
   using RT = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW, GramCfg<MT>::LPRMAX>;
   SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
               "spr_stats_gram_finalize_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
@@ -359,7 +364,7 @@ int launch_finalize(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points, i
   const double *slab = static_cast<const double *>(ws);
   const double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
   hipLaunchKernelGGL(gram_finalize_kernel<MT>, dim3(GramShape<MT>::T, n_features), dim3(1024), 0, st, slab,
-                     stat_part, (int)m, plan, (int)RT::ROWS_PER_IT, gram, fstats);
+                     stat_part, (int)m, plan, (int)RT::ROWS_PER_IT, gram, fstats, ldg, origin);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
@@ -418,13 +423,16 @@ extern "C" int spr_stats_gram_f64(const double *d_X, int64_t n_rows, int32_t m, 
 
 extern "C" int spr_stats_gram_finalize_f64(int64_t n_rows, int32_t m, int64_t row0, int64_t n_points,
                                            int32_t n_features, const void *d_workspace, size_t workspace_bytes_,
-                                           double *d_fstats, double *d_gram, void *stream) {
+                                           double *d_fstats, double *d_gram, int32_t ldg, int32_t origin,
+                                           void *stream) {
   int rc = check_args("spr_stats_gram_finalize_f64", d_workspace, n_rows, m, m, row0, n_points, n_features);
   if (rc != SPR_OK) return rc;
   SPR_REQUIRE(d_fstats && d_gram, SPR_E_INVALID, "spr_stats_gram_finalize_f64: NULL output");
+  SPR_REQUIRE(origin >= 0 && ldg >= origin + m, SPR_E_INVALID, "spr_stats_gram_finalize_f64: block (%d,%d)+%d outside ldg=%d",
+              origin, origin, m, ldg);
   rc = SPR_E_UNSUPPORTED;
 #define FIN_CALL(MTV)                                                                                 \
-  rc = launch_finalize<MTV>(n_rows, m, row0, n_points, n_features, d_fstats, d_gram, d_workspace,    \
+  rc = launch_finalize<MTV>(n_rows, m, row0, n_points, n_features, d_fstats, d_gram, ldg, origin, d_workspace, \
                             workspace_bytes_, static_cast<hipStream_t>(stream))
   SPR_DISPATCH_MT(spr_round_mt(m), FIN_CALL)
 #undef FIN_CALL

@@ -90,12 +90,14 @@ class HipEngine:
         """-> rowmean (n,), fstats (F,3) = (count, mean, M2) of the local row means,
         gram (F,m,m) = per-feature sum of centred outer products over the local rows."""
         n, m, ld = self._check_matrix(X)
+        if m > _lib.SPR_MAX_M:
+            return self._stats_gram_wide(X, row0, n_points, n_features, center)
         rowmean = self.empty((n,))
         fstats = self.empty((n_features, 3))
         gram = self.empty((n_features, m, m))
         nbytes = self.lib.spr_stats_gram_workspace(m, n_features)
         if nbytes == 0:
-            raise NotImplementedError(f'stats_gram: m={m} outside the built range (1..{_lib.SPR_MAX_M})')
+            raise NotImplementedError(f'stats_gram: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
         ws = self._workspace('gram', nbytes)
         tic, toc = self._timed('stats_gram')
         tic()
@@ -104,8 +106,44 @@ class HipEngine:
                    'spr_stats_gram_f64')
         toc()
         _lib.check(self.lib.spr_stats_gram_finalize_f64(n, m, row0, n_points, n_features, _ptr(ws), ws.numel(),
-                                                        _ptr(fstats), _ptr(gram), self._stream()),
+                                                        _ptr(fstats), _ptr(gram), m, 0, self._stream()),
                    'spr_stats_gram_finalize_f64')
+        return rowmean, fstats, gram
+
+    def _stats_gram_wide(self, X, row0, n_points, n_features, center):
+        """256 < m <= 512: row means of the full rows first, then A^T A, B^T B (column slices of the symmetric
+        kernel with external means) and A^T B (cross kernel) into one (F, m, m) result -- see spr_hip.h."""
+        n, m, ld = self._check_matrix(X)
+        if m > _lib.SPR_MAX_M_WIDE:
+            raise NotImplementedError(f'stats_gram: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
+        F, mA, st = n_features, _lib.SPR_MAX_M, self._stream()
+        mB = m - mA
+        fstats = self.zeros((F, 3))
+        gram = self.empty((F, m, m))
+        tic, toc = self._timed('stats_gram')
+        tic()
+        if center:
+            rowmean = self.empty((n,))
+            ws = self._workspace('rowstats', self.lib.spr_rowstats_workspace(F))
+            _lib.check(self.lib.spr_rowstats_f64(_ptr(X), n, m, ld, row0, n_points, F, _ptr(rowmean), _ptr(fstats),
+                                                 _ptr(ws), ws.numel(), st), 'spr_rowstats_f64')
+        else:
+            rowmean = self.zeros((n,))
+        mode = 2 if center else 0
+        scratch = self.empty((F, 3))
+        esz = X.element_size()
+        for origin, width in ((0, mA), (mA, mB)):
+            ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(width, F))
+            xp = X.data_ptr() + origin * esz
+            _lib.check(self.lib.spr_stats_gram_f64(xp, n, width, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(ws),
+                                                   ws.numel(), st), 'spr_stats_gram_f64')
+            _lib.check(self.lib.spr_stats_gram_finalize_f64(n, width, row0, n_points, F, _ptr(ws), ws.numel(),
+                                                            _ptr(scratch), _ptr(gram), m, origin, st),
+                       'spr_stats_gram_finalize_f64')
+        ws = self._workspace('cross', self.lib.spr_gram_cross_workspace(m, F))
+        _lib.check(self.lib.spr_gram_cross_f64(_ptr(X), n, m, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(gram),
+                                               _ptr(ws), ws.numel(), st), 'spr_gram_cross_f64')
+        toc()
         return rowmean, fstats, gram
 
     # ---- K4 --------------------------------------------------------------------------------
@@ -125,10 +163,17 @@ class HipEngine:
             buf = self.empty((n, ldu))
         tic, toc = self._timed('project')
         tic()
-        _lib.check(self.lib.spr_project_f64(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
-                                            _ptr(inv_scale), _ptr(rowmean) if center else None, _ptr(W.contiguous()), r,
-                                            _ptr(buf), ldu,
-                                            self._stream()), 'spr_project_f64')
+        Wc = W.contiguous()
+        mA = _lib.SPR_MAX_M
+        slices = ((0, m),) if m <= mA else ((0, mA), (mA, m - mA))     # a wide X goes as two column slices
+        if m > _lib.SPR_MAX_M_WIDE:
+            raise NotImplementedError(f'project: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
+        for k, (c0, width) in enumerate(slices):
+            _lib.check(self.lib.spr_project_f64(X.data_ptr() + c0 * X.element_size(), n, width, ld, row0, n_points,
+                                                n_features, int(bool(center)), _ptr(inv_scale),
+                                                _ptr(rowmean) if center else None,
+                                                Wc.data_ptr() + c0 * r * Wc.element_size(), r, _ptr(buf), ldu,
+                                                int(k > 0), self._stream()), 'spr_project_f64')
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf
 

@@ -19,8 +19,8 @@ int main(void) {
   if (rc != SPR_E_INVALID) return 2;
   if (!strstr(spr_last_error(), "NULL")) return 3;
   rc = spr_project_f64((const double *)8, 10, 300, 300, 0, 10, 1, 0, (const double *)8, NULL, (const double *)8, 4,
-                       (double *)8, 4, NULL);
-  if (rc != SPR_E_UNSUPPORTED) return 4;           /* m = 300 > SPR_MAX_M: refused, not mis-computed */
+                       (double *)8, 4, 0, NULL);
+  if (rc != SPR_E_UNSUPPORTED) return 4;           /* m = 300 > SPR_MAX_M in ONE launch: refused, not mis-computed */
   printf("qr batch %d, workspace %zu\n", (int)spr_qr_batch(), spr_qr_workspace(1000));
   return 0;
 }

@@ -45,6 +45,7 @@ def test_golden_fixture(golden, eng):
 @pytest.mark.parametrize('n_points,F,m', [
     (10, 2, 5), (333, 3, 7), (257, 1, 16), (1000, 3, 33), (4099, 2, 48), (700, 4, 64),
     (513, 2, 80), (1200, 3, 128), (640, 2, 190), (900, 9, 256), (31, 1, 256),
+    (400, 2, 257), (333, 3, 300), (500, 2, 384), (450, 4, 511), (260, 16, 512),
 ])
 def test_stats_gram_vs_oracle(eng, n_points, F, m):
     X = synth_host(n_points, F, m, min(m, 12), 0.8, 1e-3, 1000 + m)
@@ -64,6 +65,7 @@ def test_stats_gram_vs_oracle(eng, n_points, F, m):
 @pytest.mark.parametrize('n_points,F,m,r', [
     (10, 2, 5, 4), (333, 3, 7, 5), (1000, 3, 33, 17), (700, 4, 64, 32), (513, 2, 80, 40),
     (1200, 3, 128, 64), (900, 9, 256, 64), (300, 2, 256, 128), (2000, 1, 48, 1),
+    (333, 3, 300, 33), (400, 2, 384, 64), (260, 16, 512, 128),
 ])
 def test_project_vs_oracle(eng, n_points, F, m, r):
     X = synth_host(n_points, F, m, min(m, 2 * r), 0.9, 1e-3, 2000 + m + r)
@@ -118,7 +120,8 @@ def _full_path(eng, X, F, r, engine_kwargs=None):
     return spr, ref, xr
 
 
-@pytest.mark.parametrize('n_points,F,m,r', [(18362, 9, 41, 14), (20000, 4, 64, 32), (6000, 3, 128, 16)])
+@pytest.mark.parametrize('n_points,F,m,r', [(18362, 9, 41, 14), (20000, 4, 64, 32), (6000, 3, 128, 16),
+                                            (3000, 16, 512, 128), (2500, 2, 320, 24)])
 def test_end_to_end_vs_oracle(eng, n_points, F, m, r):
     """config-1 shape (18 362 cells x 9 features x 41 snapshots, 14 sensors) and two others:
     ordered sensor indices exact, reconstructed field within 1e-6 rel-Frobenius."""
@@ -263,13 +266,13 @@ def test_kernels_on_row_shards(eng, n_points, F, m, r, world):
     assert int(best[1]) == int(np.argmax(nrm)) and abs(best[0] - nrm.max()) <= 1e-12 * nrm.max()
 
 
-@pytest.mark.parametrize('n_points,F,m,r', [(1, 1, 2, 1), (3, 2, 2, 2), (17, 1, 1, 1), (5, 3, 300, 2)])
+@pytest.mark.parametrize('n_points,F,m,r', [(1, 1, 2, 1), (3, 2, 2, 2), (17, 1, 1, 1), (5, 3, 300, 2), (5, 3, 600, 2)])
 def test_tiny_and_out_of_range_shapes(eng, n_points, F, m, r):
     """shapes far below one panel / one workgroup, and m beyond the built range (must fail loudly)"""
     rng = np.random.default_rng(n_points + m)
     X = rng.standard_normal((n_points * F, m)) + 3.0
     Xd = eng.to_device(X)
-    if m > 256:
+    if m > 512:
         with pytest.raises(NotImplementedError):
             eng.stats_gram(Xd, 0, n_points, F)
         return

@@ -89,6 +89,22 @@ int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx
                        int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
                        double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- K3b : device-side spectrum for m <= spr_spectrum_max_m() (= 64) ------------------------
+ * Replaces, for small snapshot counts, the host eigen-solve behind np.linalg.svd (:272), the block
+ * statistics merge (np.std :115 and the other scale_type formulas :117-161 that derive from block
+ * mean / variance), A = (diag(S) Vt)^T (:273) and the explained variance (:274-275), so that fit()
+ * needs no host synchronisation.  d_gram [F][m][m] and d_fstats_all [n_ranks][F][3] are the
+ * (all-reduced / all-gathered) outputs of spr_stats_gram_finalize_f64.  scale_code: 0 'std',
+ * 1 'none', 2 'pareto', 3 'vast', 4 'level', 5 'variance', 6 'poisson', 7 'l2-norm'.
+ * Outputs: d_feat [F][5] = (count, block mean, block variance, scale, 1/scale); d_scale, d_inv_scale
+ * [F]; d_lam, d_S, d_expvar [m] (descending); d_V [m][m] (columns = eigenvectors, largest-magnitude
+ * entry positive); d_W = V_r S_r^-1 and d_Ar = V_r S_r [m][r]; d_info = (Jacobi sweeps, off^2, diag^2). */
+int32_t spr_spectrum_max_m(void);
+int spr_spectrum_f64(const double *d_gram, const double *d_fstats_all, int32_t n_ranks,
+                     int32_t n_features, int32_t m, int32_t scale_code, int32_t r, double *d_feat,
+                     double *d_scale, double *d_inv_scale, double *d_lam, double *d_S, double *d_expvar,
+                     double *d_V, double *d_W, double *d_Ar, double *d_info, void *stream);
+
 /* ---- K4 : basis projection  Ur = X0 . W,  W = V_r Sigma_r^-1 (m x r) ----------------
  * Replaces the U factor of np.linalg.svd (:272) and the truncation U[:, :r] (:336).
  * Second read of X.  center = 1: d_rowmean (the row means written by spr_stats_gram_f64)

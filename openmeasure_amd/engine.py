@@ -146,6 +146,27 @@ class HipEngine:
         toc()
         return rowmean, fstats, gram
 
+    # ---- K3b: device-side spectrum (m <= 64) ------------------------------------------------------
+    SCALE_CODES = {'std': 0, 'none': 1, 'pareto': 2, 'vast': 3, 'level': 4, 'variance': 5, 'poisson': 6, 'l2-norm': 7}
+
+    @property
+    def spectrum_max_m(self):
+        return int(self.lib.spr_spectrum_max_m())
+
+    def spectrum(self, gram, fstats_all, scale_type, r):
+        """gram (F,m,m) all-reduced, fstats_all (ranks,F,3). -> dict of device tensors (see spr_hip.h)."""
+        F, m = gram.shape[0], gram.shape[1]
+        out = dict(feat=self.empty((F, 5)), scale=self.empty((F,)), inv_scale=self.empty((F,)), lam=self.empty((m,)),
+                   S=self.empty((m,)), expvar=self.empty((m,)), V=self.empty((m, m)), W=self.empty((m, r)),
+                   Ar=self.empty((m, r)), info=self.empty((3,)))
+        _lib.check(self.lib.spr_spectrum_f64(_ptr(gram.contiguous()), _ptr(fstats_all.contiguous()),
+                                             fstats_all.shape[0], F, m, self.SCALE_CODES[scale_type], r,
+                                             _ptr(out['feat']), _ptr(out['scale']), _ptr(out['inv_scale']),
+                                             _ptr(out['lam']), _ptr(out['S']), _ptr(out['expvar']), _ptr(out['V']),
+                                             _ptr(out['W']), _ptr(out['Ar']), _ptr(out['info']), self._stream()),
+                   'spr_spectrum_f64')
+        return out
+
     # ---- K4 --------------------------------------------------------------------------------
     def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
         """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even.

@@ -42,6 +42,7 @@ import numpy as np
 
 __all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix']
 
+_DEVICE_SPECTRUM_MAX_M = 24   # above this the single-workgroup Jacobi is slower than host dsyevd (csrc/spectrum.hip)
 _DENSE_C_LIMIT = 1 << 26   # optimal_placement returns a dense ndarray below this many bytes (64 MiB)
 
 
@@ -180,6 +181,38 @@ class ROM:
         self._eng = engine
         self._d = {}            # device-resident state
         self._host = {}         # lazily downloaded copies
+
+    # ------------------------------------------------------------------ lazily fetched fit results
+    _LAZY = ('Ar', 'Sigma_r', 'Vr', 'exp_variance_', 'S_', '_scl_f', '_var_f')
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: results of the sync-free device fit (m <= 64) stay in HBM
+        # until somebody reads them
+        pend = self.__dict__.get('_pending')
+        if pend is not None and name in ROM._LAZY:
+            self._materialize()
+            if name in self.__dict__:
+                return self.__dict__[name]
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def _materialize(self):
+        """One D2H round trip for everything the device spectrum left in HBM."""
+        pend = self.__dict__.pop('_pending', None)
+        if pend is None:
+            return
+        eng = self._engine()
+        r = pend['r']
+        feat = eng.to_host(pend['feat'])
+        S = eng.to_host(pend['S'])
+        V = eng.to_host(pend['V'])
+        self._scl_f = feat[:, 3].copy()
+        self._var_f = self._scl_f ** 2
+        self.S_ = S
+        self.exp_variance_ = eng.to_host(pend['expvar'])[:r].copy()
+        self.Ar = eng.to_host(pend['Ar'])
+        self.Sigma_r = np.linalg.norm(self.Ar, axis=0)         # :504-508
+        Vr = V[:, :r]
+        self.Vr = Vr * (np.linalg.norm(Vr, axis=0) ** -1)
 
     # ------------------------------------------------------------------ plumbing
     def _engine(self):
@@ -481,6 +514,10 @@ class ROM:
             raise ValueError('The select_mode value is wrong.')
         eng = self._engine()
         self.scale_type = scale_type
+        for k in ROM._LAZY + ('C', 'Theta', '_pending'):
+            self.__dict__.pop(k, None)
+        if self._device_fit(scale_type, axis_cnt, select_modes, n_modes, basis):
+            return
         self._stats_pass(scale_type, axis_cnt)
         self._host.clear()
         if basis is None:
@@ -502,9 +539,42 @@ class ROM:
             self.Vr = V_r * (np.linalg.norm(V_r, axis=0) ** -1)   # = Ar / Sigma_r, also when a sigma underflowed to 0
         else:
             self.Vr = Ar / Sigma_r
-        for k in ('C', 'Theta'):
-            self.__dict__.pop(k, None)
         self._trace.report()
+
+    def _device_fit(self, scale_type, axis_cnt, select_modes, n_modes, basis):
+        """fit() without any host synchronisation: statistics merge, feature scales, eigen-decomposition
+        (Jacobi, csrc/spectrum.hip) and W = V_r S_r^-1 all stay on the device.  Taken when the spectrum fits one
+        workgroup and beats the host round trip (m <= 24), the number of modes is given, and the scaling derives
+        from block mean/variance;
+        Ar, Sigma_r, Vr, exp_variance_, X_scl are copied to the host on first access."""
+        eng = self._engine()
+        if basis is not None or select_modes != 'number' or axis_cnt != 1 or not hasattr(eng, 'spectrum'):
+            return False
+        if scale_type not in eng.SCALE_CODES:
+            return False
+        Xd = self._Xd()
+        m = Xd.shape[1]
+        if m > min(eng.spectrum_max_m, _DEVICE_SPECTRUM_MAX_M):
+            return False
+        r = self._select_rank(None, m, 'number', n_modes)      # same TypeError / ValueError as the reference
+        F = self.n_features
+        tr_ = self._trace = _Trace(eng)
+        rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+        gram = self._all_reduce(gram)
+        sp = eng.spectrum(gram, self._all_gather(fstats), scale_type, r)
+        tr_.mark('stats_gram+spectrum')
+        self._host.clear()
+        self._d['rowmean'] = rowmean
+        self._d['scale'] = sp['scale']
+        self._d['inv_scale'] = sp['inv_scale']
+        self._d['Ur'] = eng.project(Xd, self._row0, self.n_points, F, sp['inv_scale'], sp['W'], center=True,
+                                    out=self._d.pop('Ur', None), rowmean=rowmean)
+        tr_.mark('project')
+        self.r = r
+        sp['r'] = r
+        self._pending = sp
+        tr_.report()
+        return True
 
     # ------------------------------------------------------------------ a10 reconstruct
     def reconstruct(self, Ar, sampling=None, to_host=True):

@@ -222,6 +222,30 @@ def test_general_csr_measurement_matrix(eng):
     np.testing.assert_allclose(eng.to_host(cnt), C @ mu, atol=1e-12)
 
 
+@pytest.mark.parametrize('n_points,F,m,r,scale_type', [(500, 3, 12, 4, 'std'), (800, 9, 41, 14, 'pareto'), (600, 4, 64, 32, 'std'),
+                                                        (300, 2, 7, 7, 'l2-norm'), (400, 70, 16, 5, 'vast')])
+def test_device_spectrum_vs_lapack(eng, n_points, F, m, r, scale_type):
+    """spr_spectrum_f64 (Jacobi, m <= 64) against numpy.linalg.eigh on the same scaled Gram matrix, and the
+    feature scales against the oracle's scale_data"""
+    X = synth_host(n_points, F, m, min(m, 2 * r), 0.8, 1e-3, 4000 + m) * 0.05 + 5.0
+    X_cnt, X_scl, X0 = orc.scale_data(X, F, scale_type)
+    rowmean, fstats, gram = eng.stats_gram(eng.to_device(X), 0, n_points, F)
+    sp = eng.spectrum(gram, fstats[None], scale_type, r)
+    np.testing.assert_allclose(eng.to_host(sp['scale']), X_scl[::n_points, 0], rtol=1e-11)
+    S_ref = np.linalg.svd(X0, compute_uv=False)
+    S = eng.to_host(sp['S'])
+    rw = int(np.sum(S_ref > 1e-6 * S_ref[0]))
+    np.testing.assert_allclose(S[:rw], S_ref[:rw], rtol=1e-8)
+    V = eng.to_host(sp['V'])
+    assert np.abs(V.T @ V - np.eye(m)).max() < 1e-12
+    G = X0.T @ X0
+    assert np.abs(V.T @ G @ V - np.diag(eng.to_host(sp['lam']))).max() <= 1e-10 * S_ref[0] ** 2
+    rr = min(r, rw)
+    W = eng.to_host(sp['W'])
+    np.testing.assert_allclose(W[:, :rr] * S[:rr], V[:, :rr], atol=1e-12)
+    assert eng.to_host(sp['info'])[0] <= 15
+
+
 # ---- row shards: the kernels see rows [row0, row0+n_loc) of a global feature-major matrix ----
 @pytest.mark.parametrize('n_points,F,m,r,world', [(1000, 3, 24, 8, 2), (777, 4, 64, 16, 3), (500, 9, 40, 14, 4), (64, 2, 256, 32, 2)])
 def test_kernels_on_row_shards(eng, n_points, F, m, r, world):

@@ -116,14 +116,23 @@ class _Trace:
         print('[spr trace] ' + ' '.join(parts) + f' total={1e3 * (prev - t0):.2f} ms', file=sys.stderr)
 
 
+_BLAS_CTL = None
+
+
 def _eigh_small(G):
     """LAPACK dsyevd on the (m, m) Gram matrix with the BLAS pool capped: the problem is far too
-    small for a many-core pool (128 threads made it 10x slower on the GPU host)."""
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:                                   # pragma: no cover
+    small for a many-core pool (128 threads made it 10x slower on the GPU host).  The threadpoolctl
+    controller is built once -- discovering the loaded BLAS libraries costs more than the solve."""
+    global _BLAS_CTL
+    if _BLAS_CTL is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _BLAS_CTL = ThreadpoolController()
+        except ImportError:                               # pragma: no cover
+            _BLAS_CTL = False
+    if not _BLAS_CTL:
         return np.linalg.eigh(G)
-    with threadpool_limits(limits=4, user_api='blas'):
+    with _BLAS_CTL.limit(limits=1 if G.shape[0] <= 96 else 4, user_api='blas'):
         return np.linalg.eigh(G)
 
 

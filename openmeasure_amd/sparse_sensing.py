@@ -132,7 +132,7 @@ def _eigh_small(G):
             _BLAS_CTL = False
     if not _BLAS_CTL:
         return np.linalg.eigh(G)
-    with _BLAS_CTL.limit(limits=1 if G.shape[0] <= 96 else 4, user_api='blas'):
+    with _BLAS_CTL.limit(limits=1, user_api='blas'):       # tools/eigh_probe.py: 1 thread is fastest for m <= 512
         return np.linalg.eigh(G)
 
 

@@ -21,7 +21,7 @@
 // Candidate record (one per rank, all-gathered between steps when sharded), r+3 doubles:
 //   [0] best residual norm^2   [1] its global row (as double, exact below 2^53)
 //   [2] runner-up norm^2 among this rank's candidates   [3..3+r) the row of Ur
-#include "common.hpp"
+#include "rowtile.hpp"
 
 namespace {
 
@@ -29,7 +29,8 @@ constexpr int QR_THREADS = 256;
 constexpr int QR_UNR = 4;
 constexpr int QR_TOPT = 8;          // rows kept per sweep block
 constexpr int QR_MAX_BLOCKS = 1024; // sweep grid cap -> at most 8192 candidates
-constexpr int QR_BATCH = 8;         // directions applied per refresh sweep
+constexpr int QR_BATCH = 16;        // directions applied per refresh sweep (one MFMA tile of columns)
+constexpr int QR_VBATCH = 8;        // ... by the VALU form of the sweep (kept for reference / cross-checks)
 
 struct Best {
   double v1; int64_t i1; double v2;
@@ -76,6 +77,62 @@ __device__ inline f64x2 load_row_piece(const double *__restrict__ rp, int k0, in
   return t;
 }
 
+// Per-lane sorted list of the QR_TOPT largest (value, global row) pairs seen, and its block-level merge.
+struct TopList {
+  double tv[QR_TOPT];
+  long long ti[QR_TOPT];
+  __device__ inline void init() {
+#pragma unroll
+    for (int k = 0; k < QR_TOPT; ++k) { tv[k] = -2.0; ti[k] = -1; }
+  }
+  // rows reach a lane in increasing index order, so "strictly greater" keeps the lowest index among equals
+  __device__ inline void insert(double v, long long gi, bool mine) {
+    const bool ins = mine && (v > tv[QR_TOPT - 1]);
+    if (__any(ins)) {
+#pragma unroll
+      for (int k = QR_TOPT - 1; k >= 0; --k) {
+        const bool here = ins && (v > tv[k]);
+        const bool above = (k > 0) ? (v > tv[k > 0 ? k - 1 : 0]) : false;
+        const double nv = above ? tv[k > 0 ? k - 1 : 0] : v;
+        const long long ni = above ? ti[k > 0 ? k - 1 : 0] : gi;
+        tv[k] = here ? nv : tv[k];
+        ti[k] = here ? ni : ti[k];
+      }
+    }
+  }
+  // QR_TOPT rounds of arg-max over the 256 x QR_TOPT list entries (wave 0), result sorted to out[QR_TOPT][2]
+  __device__ inline void block_merge(double *sval, long long *sidx, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < QR_TOPT; ++k) {
+      sval[threadIdx.x * QR_TOPT + k] = tv[k];
+      sidx[threadIdx.x * QR_TOPT + k] = ti[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      for (int round = 0; round < QR_TOPT; ++round) {
+        double bv = -3.0; long long bi = INT64_MAX; int bp = -1;
+        for (int e = lane; e < QR_THREADS * QR_TOPT; e += 64) {
+          const double v = sval[e]; const long long i = sidx[e];
+          if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bp = e; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          const double ov = __shfl_xor(bv, o, 64);
+          const long long oi = __shfl_xor(bi, o, 64);
+          const int op = __shfl_xor(bp, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = op; }
+        }
+        if (lane == 0) {
+          out[2 * round] = bv > -2.5 ? bv : -2.0;
+          out[2 * round + 1] = (double)(bv > -2.5 ? bi : -1);
+          if (bp >= 0) sval[bp] = -3.0;
+        }
+        __builtin_amdgcn_wave_barrier();   // one wave only: LDS accesses of a wave are issued and serviced in order
+      }
+    }
+  }
+};
+
 // Full sweep over the rank's rows.  MODE 0: nrm = |u|^2.  MODE 2: nrm <- nrm down-dated by nq
 // directions (rows already chosen keep -1).  Both: the block's QR_TOPT largest (value, global
 // row) pairs, sorted, to tops[block][QR_TOPT][2].
@@ -91,16 +148,14 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
   const int grp = lane / LPR, lig = lane % LPR;
   const bool vec_ok = vec_ok_i != 0;
   const int k0 = 2 * lig;
-  double q0[QR_BATCH], q1[QR_BATCH];
+  double q0[QR_VBATCH], q1[QR_VBATCH];
 #pragma unroll
-  for (int t = 0; t < QR_BATCH; ++t) {
+  for (int t = 0; t < QR_VBATCH; ++t) {
     q0[t] = (MODE == 2 && t < nq && k0 < r) ? Q[(int64_t)t * r + k0] : 0.0;
     q1[t] = (MODE == 2 && t < nq && k0 + 1 < r) ? Q[(int64_t)t * r + k0 + 1] : 0.0;
   }
-  double tv[QR_TOPT];
-  long long ti[QR_TOPT];
-#pragma unroll
-  for (int k = 0; k < QR_TOPT; ++k) { tv[k] = -2.0; ti[k] = -1; }
+  TopList top;
+  top.init();
 
   const int64_t nsteps = (n_rows + ROWS_IT - 1) / ROWS_IT;
   for (int64_t s = blockIdx.x; s < nsteps; s += gridDim.x) {
@@ -120,56 +175,103 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
         v = group_sum_t<LPR>(u[j].x * u[j].x + u[j].y * u[j].y);
       } else {
         const double old = mine ? nrm[row] : 0.0;
-        v = downdate<LPR, QR_BATCH>(old, u[j], q0, q1, nq);
+        v = downdate<LPR, QR_VBATCH>(old, u[j], q0, q1, nq);
         v = old < 0.0 ? -1.0 : v;
       }
       if (mine) nrm[row] = v;
-      // per-lane sorted top list; rows arrive in increasing index order, so "strictly greater"
-      // keeps the lowest index among equal values
-      const bool ins = mine && (v > tv[QR_TOPT - 1]);
-      if (__any(ins)) {
-        const long long gi = row0 + row;
+      top.insert(v, row0 + row, mine);
+    }
+  }
+  top.block_merge(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2);
+}
+
+// Refresh sweep, MFMA form: nrm <- nrm - sum_t (u_i . q_t)^2 for up to 16 directions at once.
+// Panels of 64 rows of Ur go to LDS raw (rowtile.hpp staging, double-buffered, loads of the panel
+// after next issued behind the stores); wave w multiplies its 16-row block with Q^T (directions as
+// the 16 MFMA columns, fragments in registers): r/4 v_mfma_f64_16x16x4_f64 per block, far below the
+// HBM time of the panel, where the VALU form spends 8 x (fma + 5-step butterfly) per row pair.
+// The squared products are summed over the 16 direction lanes with a DPP butterfly; lanes 0/16/32/48
+// of a wave own rows a, a+4, a+8, a+12 of the block (increasing order, as TopList needs).
+template <int MTR, int VEC>
+__global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
+    const double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
+    const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
+  constexpr int NW = QR_THREADS / 64, R = 64;
+  constexpr int MPAD = 16 * MTR, MP = MPAD + 2, KSTEPS = MPAD / 4;
+  using RT = RowTile<MTR, R, MP, NW>;
+  constexpr int PANELS = 2 * R * MP, MERGE = 2 * QR_THREADS * QR_TOPT;
+  __shared__ double smem[PANELS > MERGE ? PANELS : MERGE];    // panels during the sweep, merge lists afterwards
+  double *const lds0 = smem, *const lds1 = smem + R * MP;
+  double *const sval = smem;
+  long long *const sidx = reinterpret_cast<long long *>(smem + QR_THREADS * QR_TOPT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  double bfrag[KSTEPS];          // B[k][j] = Q[j][k]: direction j = lane & 15, k = 4 ks + (lane >> 4)
 #pragma unroll
-        for (int k = QR_TOPT - 1; k >= 0; --k) {
-          const bool here = ins && (v > tv[k]);
-          const bool above = (k > 0) ? (v > tv[k > 0 ? k - 1 : 0]) : false;
-          const double nv = above ? tv[k > 0 ? k - 1 : 0] : v;
-          const long long ni = above ? ti[k > 0 ? k - 1 : 0] : gi;
-          tv[k] = here ? nv : tv[k];
-          ti[k] = here ? ni : ti[k];
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int k = 4 * ks + (lane >> 4), j = lane & 15;
+    bfrag[ks] = (j < nq && k < r) ? Q[(int64_t)j * r + k] : 0.0;
+  }
+  TopList top;
+  top.init();
+  RT tile;
+  const int64_t npanels = (n_rows + R - 1) / R;
+  int64_t c = blockIdx.x;
+  if (c < npanels) {
+    tile.template load<VEC>(Ur, ldu, r, c * R, n_rows, wave, lane);
+    tile.raw_store(lds0, r, c * R, n_rows, wave, lane);
+    int64_t cn = c + gridDim.x;
+    int64_t nrow0 = (cn < npanels) ? cn * R : n_rows;
+    tile.template load<VEC>(Ur, ldu, r, nrow0, n_rows, wave, lane);
+    int buf = 0;
+    const int afrag = (lane & 15) * MP + (lane >> 4);
+    while (c < npanels) {
+      const double *cur = buf ? lds1 : lds0;
+      double *nxt = buf ? lds0 : lds1;
+      const int64_t c2 = cn + gridDim.x;
+      const int64_t n2row0 = (c2 < npanels) ? c2 * R : n_rows;
+      __syncthreads();
+      const int64_t brow = c * R + wave * 16 + (lane >> 4);       // this lane's first row of the block
+      double old[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rr = brow + 4 * i;
+        old[i] = nrm[rr < n_rows ? rr : n_rows - 1];               // requested before the MFMAs
+      }
+      const double *p = cur + wave * 16 * MP + afrag;
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[4 * ks], bfrag[ks], acc, 0, 0, 0);
+        if (ks == 0) {
+#pragma unroll
+          for (int it = 0; it < RT::IT; ++it) {
+            tile.raw_store_pass(it, nxt, r, nrow0, n_rows, wave, lane);
+            tile.template load_pass<VEC>(it, Ur, ldu, r, n2row0, n_rows, wave, lane);
+          }
         }
       }
-    }
-  }
-  // block merge: QR_TOPT rounds of arg-max over the 256 x QR_TOPT list entries (one wave)
+      const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
+                            group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
 #pragma unroll
-  for (int k = 0; k < QR_TOPT; ++k) {
-    sval[threadIdx.x * QR_TOPT + k] = tv[k];
-    sidx[threadIdx.x * QR_TOPT + k] = ti[k];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    double *out = tops + (int64_t)blockIdx.x * QR_TOPT * 2;
-    for (int round = 0; round < QR_TOPT; ++round) {
-      double bv = -3.0; long long bi = INT64_MAX; int bp = -1;
-      for (int e = lane; e < QR_THREADS * QR_TOPT; e += 64) {
-        const double v = sval[e]; const long long i = sidx[e];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bp = e; }
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rr = brow + 4 * i;
+        const bool mine = ((lane & 15) == 0) && (rr < n_rows);
+        double v = old[i] - d2[i];
+        v = v < 0.0 ? 0.0 : v;
+        v = old[i] < 0.0 ? -1.0 : v;
+        if (mine) nrm[rr] = v;
+        top.insert(v, row0 + rr, mine);
       }
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(bv, o, 64);
-        const long long oi = __shfl_xor(bi, o, 64);
-        const int op = __shfl_xor(bp, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = op; }
-      }
-      if (lane == 0) {
-        out[2 * round] = bv > -2.5 ? bv : -2.0;
-        out[2 * round + 1] = (double)(bv > -2.5 ? bi : -1);
-        if (bp >= 0) sval[bp] = -3.0;
-      }
-      __builtin_amdgcn_wave_barrier();   // one wave only: LDS accesses of a wave are issued and serviced in order
+      buf ^= 1;
+      c = cn;
+      cn = c2;
+      nrow0 = n2row0;
     }
   }
+  __syncthreads();   // the panels are dead from here on: their LDS is reused for the merge
+  top.block_merge(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2);
 }
 
 // grid = sweep blocks: copy each block's top rows into the compact candidate arrays
@@ -515,7 +617,23 @@ extern "C" int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r,
   QrWs w(d_workspace);
   hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + j0, (int)nq, row0, n_rows, d_nrm);
   SPR_LAUNCH_CHECK();
-  rc = launch_sweep<2>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, d_Q + (int64_t)j0 * r, nq, d_nrm, w.tops);
-  if (rc != SPR_OK) return rc;
+  {
+    const double *Qj = d_Q + (int64_t)j0 * r;
+    const int mtr = spr_round_mt(r);      // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
+    const int lm = vec_ok ? ((r == 16 * mtr) ? 2 : 1) : 0;
+#define RF(MTV, LM) hipLaunchKernelGGL((qr_refresh_mfma_kernel<MTV, LM>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows, (int)r, ldu, row0, Qj, (int)nq, d_nrm, w.tops)
+#define RFV(MTV) do { if (lm == 2) RF(MTV, 2); else if (lm == 1) RF(MTV, 1); else RF(MTV, 0); } while (0)
+    switch (mtr) {
+      case 1: RFV(1); break;
+      case 2: RFV(2); break;
+      case 3: RFV(3); break;
+      case 4: RFV(4); break;
+      case 6: RFV(6); break;
+      default: RFV(8); break;
+    }
+#undef RFV
+#undef RF
+    SPR_LAUNCH_CHECK();
+  }
   return build_candidates(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
 }

@@ -34,7 +34,7 @@ def main():
         ws = eng._workspace('gram', lib.spr_stats_gram_workspace(m, F))
         st = eng._stream()
         t_g = timeit(lambda: lib.spr_stats_gram_f64(X.data_ptr(), n, m, m, 0, cells, F, 1, rowmean.data_ptr(), ws.data_ptr(), ws.numel(), st))
-        t_f = timeit(lambda: lib.spr_stats_gram_finalize_f64(n, m, 0, cells, F, ws.data_ptr(), ws.numel(), fstats.data_ptr(), gram.data_ptr(), st))
+        t_f = timeit(lambda: lib.spr_stats_gram_finalize_f64(n, m, 0, cells, F, ws.data_ptr(), ws.numel(), fstats.data_ptr(), gram.data_ptr(), m, 0, st))
         W = eng.to_device(np.random.default_rng(0).standard_normal((m, r)))
         inv = eng.to_device(np.ones(F))
         Ur = eng.project(X, 0, cells, F, inv, W, rowmean=rowmean)
@@ -47,12 +47,13 @@ def main():
         for j in range(1, 8):
             eng.qr_step(qs, j, qs['rec'][None], qs['tau'][None], True)
         t_q8 = timeit(lambda: eng.qr_refresh(qs, 0, 8))
+        t_n = timeit(lambda: eng.qr_begin(Ur, 0, 8))
         xb = n * m * 8
         print(f'cells={cells} F={F} m={m} r={r}  X={xb / 1e9:.2f} GB')
         print(f'  stats_gram  {t_g:8.3f} ms  {xb / t_g / 1e6:8.1f} GB/s  {n * m * m / t_g / 1e9:7.2f} TF   (finalize {t_f:.3f} ms)')
         print(f'  project     {t_p:8.3f} ms  {(xb + n * r * 8) / t_p / 1e6:8.1f} GB/s  {2.0 * n * m * r / t_p / 1e9:7.2f} TF')
         print(f'  reconstruct {t_r:8.3f} ms  {(n * r * 8 + 16 * n) / t_r / 1e6:8.1f} GB/s')
-        print(f'  qr_sweep x1 {t_q:8.3f} ms  {(n * r * 8 + 16 * n) / t_q / 1e6:8.1f} GB/s   x8 directions {t_q8:8.3f} ms  {(n * r * 8 + 16 * n) / t_q8 / 1e6:8.1f} GB/s')
+        print(f'  qr_sweep x1 {t_q:8.3f} ms  {(n * r * 8 + 16 * n) / t_q / 1e6:8.1f} GB/s   x8 directions {t_q8:8.3f} ms  {(n * r * 8 + 16 * n) / t_q8 / 1e6:8.1f} GB/s   init(norms+cands) {t_n:8.3f} ms')
         del X, Ur, out, rowmean
         torch.cuda.empty_cache()
 

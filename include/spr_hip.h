@@ -46,6 +46,12 @@ int spr_abi_version(void);
 const char *spr_last_error(void);
 /* number of compute units of the current device (used to size persistent grids) */
 int spr_device_cus(int *out_cus);
+/* Small host -> device upload executed as a kernel on `stream` (no copy-engine dependency in front of the next
+ * kernel): h_pinned_src is page-locked, device-visible host memory (hipHostMalloc / torch pin_memory), n_bytes a
+ * multiple of 8.  Carries the small operands the reference keeps as host ndarrays next to X -- W = V_r S_r^-1
+ * (sparse_sensing.py:272-279), X_scl per feature (:115), the coefficient vectors of reconstruct (:371) -- to
+ * the device.  The source may be rewritten once work queued after this call on the stream has completed. */
+int spr_upload_bytes(void *d_dst, const void *h_pinned_src, int64_t n_bytes, void *stream);
 
 /* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
  * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised

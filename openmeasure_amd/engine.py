@@ -35,6 +35,8 @@ class HipEngine:
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         self._ws = {}
         self._timing = {}
+        self._stage = None                                   # ring of pinned host staging buffers for small uploads
+        self._dstage = None                                  # pinned landing buffer for small downloads
 
     # ---- plumbing ---------------------------------------------------------------------
     def _stream(self):
@@ -46,15 +48,63 @@ class HipEngine:
     def zeros(self, shape, dtype=None):
         return self.torch.zeros(shape, dtype=dtype or self.torch.float64, device=self.device)
 
+    _STAGE_BYTES = 1 << 20
+    _STAGE_SLOTS = 8
+
     def to_device(self, a, dtype=None):
-        """Host ndarray -> contiguous device tensor (float64 unless told otherwise)."""
-        t = self.torch.as_tensor(np.ascontiguousarray(a))
+        """Host ndarray -> contiguous device tensor (float64 unless told otherwise).  Small arrays are copied
+        into one of a ring of pinned staging buffers and carried to the device by a kernel on the current stream
+        (spr_upload_bytes): the host never blocks, and no copy-engine dependency sits in front of the next
+        kernel -- with hipMemcpyAsync there, the projection was measured to start 10/20/30 ms late in every
+        other fit() at config 3 (tools/fit_probe.py).  A slot is reused only after the event recorded behind
+        its upload has completed."""
+        torch = self.torch
         if dtype is None:
-            dtype = self.torch.float64
-        return t.to(device=self.device, dtype=dtype).contiguous()
+            dtype = torch.float64
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0 or nbytes > self._STAGE_BYTES or nbytes % 8:
+            return t.to(device=self.device).contiguous()
+        if self._stage is None:
+            self._stage = [[torch.empty(self._STAGE_BYTES, dtype=torch.uint8, pin_memory=True), None]
+                           for _ in range(self._STAGE_SLOTS)]
+            self._stage_next = 0
+        slot = self._stage[self._stage_next]
+        self._stage_next = (self._stage_next + 1) % self._STAGE_SLOTS
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:nbytes].view(dtype).view(t.shape).copy_(t)
+        out = torch.empty(t.shape, dtype=dtype, device=self.device)
+        _lib.check(self.lib.spr_upload_bytes(out.data_ptr(), slot[0].data_ptr(), nbytes, self._stream()),
+                   'spr_upload_bytes')
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
+        return out
+
+    _HOST_STAGE_BYTES = 64 << 20
 
     def to_host(self, t):
-        return t.detach().cpu().numpy()
+        """Device tensor -> fresh host ndarray.  Results up to 64 MiB (statistics, Gram blocks, flags, Theta,
+        coefficient vectors) come back through a pinned buffer: a D2H copy into pageable memory in the middle of
+        fit() left the compute queue stalled for 10/20/30 ms in every other call at config 3 (tools/fit_probe.py:
+        gap between the Gram and projection kernels 3.9 ms with the pinned target, 4-37 ms without)."""
+        torch = self.torch
+        t = t.detach()
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0 or nbytes > self._HOST_STAGE_BYTES or not t.is_cuda:
+            return t.cpu().numpy()
+        if self._dstage is None or self._dstage.numel() < nbytes:
+            self._dstage = None
+            self._dstage = torch.empty(max(1 << 20, -(-nbytes // (1 << 20)) << 20), dtype=torch.uint8, pin_memory=True)
+            self._dstage_ev = torch.cuda.Event()
+        buf = self._dstage[:nbytes].view(t.dtype).view(t.shape)
+        buf.copy_(t, non_blocking=True)
+        self._dstage_ev.record(torch.cuda.current_stream(self.device))
+        self._dstage_ev.synchronize()
+        return buf.numpy().copy()
 
     def _workspace(self, key, nbytes):
         cur = self._ws.get(key)

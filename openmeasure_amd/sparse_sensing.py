@@ -492,7 +492,9 @@ class ROM:
         floor = S[0] * np.sqrt(m * np.finfo(float).eps)
         S_safe = np.maximum(S[:r], floor if floor > 0 else 1.0)
         W = V[:, :r] / S_safe
-        Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, eng.to_device(W),
+        W_d = eng.to_device(W)
+        self._trace.mark('upload')
+        Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, W_d,
                            center=center, out=self._d.pop('Ur', None), rowmean=self._d.get('rowmean'))
         self._trace.mark('project')
         Ar = V[:, :r] * S[:r]                                # A = (diag(S) Vt).T  (:273)

@@ -290,6 +290,17 @@ class ROM:
         """(n_local, r) POD basis rows held by this rank."""
         return self._lazy('Ur', lambda: np.ascontiguousarray(self._engine().to_host(self._d['Ur'])))
 
+    @Ur.setter
+    def Ur(self, value):
+        # subclasses written against the reference assign the result of decomposition() (gpr.py:386):
+        # that array already has its device twin; anything else is uploaded
+        last = self.__dict__.get('_last_decomp')
+        if last is not None and value is last[0]:
+            self._d['Ur'] = last[1]
+        else:
+            self._d['Ur'] = self._engine().to_device(np.asarray(value, dtype=np.float64))
+        self._host['Ur'] = value
+
     @property
     def X0(self):
         """(n_local, m) centred/scaled matrix (:169, :492); built on first access only."""
@@ -299,6 +310,10 @@ class ROM:
                                self._d['inv_scale'])
             return eng.to_host(t)
         return self._lazy('X0', make)
+
+    @X0.setter
+    def X0(self, value):
+        self._host['X0'] = value                              # gpr.py:379 stores what scale_data returned
 
     # ------------------------------------------------------------------ a2 scale_data
     _DEVICE_SCALINGS = ('std', 'none', 'pareto', 'vast', 'range', 'level', 'max', 'variance', 'poisson', 'l2-norm')
@@ -502,20 +517,32 @@ class ROM:
 
     def decomposition(self, X0, select_modes='variance', n_modes=99):
         """Reference :242-279 on a caller-supplied scaled matrix X0 (host ndarray, local rows).
-        Returns (Ur, Ar, exp_variance[:r]) as host arrays."""
+        Returns (Ur, Ar, exp_variance[:r]) as host arrays.  When X0 is the very array scale_data() returned
+        (the pattern of GPR.fit, gpr.py:379-381) the Gram blocks of that pass and the resident X are used instead
+        of uploading X0 and reading it twice."""
         eng = self._engine()
-        X0d = eng.to_device(X0)
-        _, _, gram = eng.stats_gram(X0d, 0, X0d.shape[0], 1, center=False)
-        G = eng.to_host(self._all_reduce(gram))[0]
-        ones = eng.to_device(np.ones(1))
-        S, V, exp_variance = self._spectrum(G)
-        m = X0d.shape[1]
-        r = self._select_rank(exp_variance, m, select_modes, n_modes)
-        floor = S[0] * np.sqrt(m * np.finfo(float).eps)
-        W = V[:, :r] / np.maximum(S[:r], floor if floor > 0 else 1.0)
-        Ur_d = eng.project(X0d, 0, X0d.shape[0], 1, ones, eng.to_device(W), center=False)
+        if X0 is self._host.get('X0') and '_G_f' in self.__dict__ and 'rowmean' in self._d:
+            with np.errstate(invalid='ignore', divide='ignore'):
+                G = np.sum(self._G_f / self._var_f[:, None, None], axis=0)
+            self._trace = _Trace(eng)
+            self._d.pop('Ur', None)
+            Ur_d, Ar, expv, _, r, _ = self._basis_from_gram(G, select_modes, n_modes, True, self._d['inv_scale'])
+        else:
+            X0d = eng.to_device(X0)
+            _, _, gram = eng.stats_gram(X0d, 0, X0d.shape[0], 1, center=False)
+            G = eng.to_host(self._all_reduce(gram))[0]
+            ones = eng.to_device(np.ones(1))
+            S, V, exp_variance = self._spectrum(G)
+            m = X0d.shape[1]
+            r = self._select_rank(exp_variance, m, select_modes, n_modes)
+            floor = S[0] * np.sqrt(m * np.finfo(float).eps)
+            W = V[:, :r] / np.maximum(S[:r], floor if floor > 0 else 1.0)
+            Ur_d = eng.project(X0d, 0, X0d.shape[0], 1, ones, eng.to_device(W), center=False)
+            Ar, expv = V[:, :r] * S[:r], exp_variance[:r]
         self.r = r
-        return np.ascontiguousarray(eng.to_host(Ur_d)), V[:, :r] * S[:r], exp_variance[:r]
+        Ur = np.ascontiguousarray(eng.to_host(Ur_d))
+        self._last_decomp = (Ur, Ur_d)
+        return Ur, Ar, expv
 
     # ------------------------------------------------------------------ a5 fit
     def fit(self, scale_type='std', axis_cnt=1, select_modes='variance', n_modes=99, basis=None):

@@ -101,3 +101,49 @@ def run_fixture(g, engine, check_pivots=True):
     np.testing.assert_allclose(spr.unscale_data(np.linspace(-1, 1, 7), sampling=sps_.csr_matrix(S)), g['unscale_sampled'],
                                rtol=1e-11, atol=1e-12 * np.abs(g['unscale_sampled']).max())
     return spr
+
+
+class _GprLike:
+    """Mixin reproducing the ROM calls of the reference's GPR.fit (gpr.py:379-402) and GPR.predict's
+    reconstruct -- the GP itself (gpytorch) is outside the device path."""
+
+    def fit_like_gpr(self, scale_type, axis_cnt, select_modes, n_modes):
+        self.X0 = self.scale_data(scale_type, axis_cnt)
+        Ur, Ar, _ = self.decomposition(self.X0, select_modes, n_modes)
+        self.Ur = Ur
+        self.Ar = Ar
+        self.r = Ar.shape[1]
+        self.Sigma_r = np.linalg.norm(Ar, axis=0)
+        with np.errstate(invalid='ignore', divide='ignore'):   # the null mode of a full-rank row-centred fit
+            self.Vr = Ar / self.Sigma_r
+
+
+def run_gpr_style(g, engine, foreign_basis=False):
+    """scale_data -> decomposition -> attribute assignment -> reconstruct, as a ROM subclass does it."""
+    from openmeasure_amd.sparse_sensing import ROM
+
+    class GprLike(_GprLike, ROM):
+        pass
+
+    X = g['X'].copy()
+    rom = GprLike(X, g['n_features'], None, engine=engine)
+    rom.fit_like_gpr(g.get('scale_type', 'std'), g.get('axis_cnt', 1), g['select_modes'], g['n_modes'])
+    assert rom.r == g['r']
+    X0_ref = g['X0'] if 'X0' in g else (g['X'] - g['X_cnt']) / g['X_scl']
+    np.testing.assert_allclose(rom.X0, X0_ref, rtol=0, atol=1e-12 * np.abs(X0_ref).max())
+    rw = well_defined_rank(g)
+    sg = align_signs(rom.Ar[:, :rw], g['Ar'][:, :rw])
+    np.testing.assert_allclose(rom.Ur[:, :rw] * sg, g['Ur'][:, :rw], rtol=0, atol=1e-8)
+    if foreign_basis:                                         # a basis that did not come from decomposition()
+        rom.Ur = g['Ur'].copy()
+        rom.Ar = g['Ar'].copy()
+        Ar_pred = g['Ar'][:3]
+    else:
+        Ar_pred = rom.Ar[:3]
+    X_rec = rom.reconstruct(Ar_pred)                          # gpr.py predict -> ROM.reconstruct
+    want = g['X'][:, :3]
+    # the first three training snapshots are reproduced up to the truncation error of the fixture's own basis
+    ref = (g['Ur'] @ g['Ar'][:3].T) * g['X_scl'] + g['X_cnt']
+    assert rel_fro(X_rec, ref) < REL_FRO
+    assert X_rec.shape == want.shape
+    return rom

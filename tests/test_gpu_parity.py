@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import spr_oracle as orc
-from tests.parity import REL_FRO, align_signs, rel_fro, run_fixture
+from tests.parity import REL_FRO, align_signs, rel_fro, run_fixture, run_gpr_style
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,32 @@ def test_native_library_is_loaded(eng):
 
 def test_golden_fixture(golden, eng):
     run_fixture(golden, eng)
+
+
+@pytest.mark.parametrize('foreign', [False, True])
+def test_gpr_style_subclass(golden, eng, foreign):       # gpr.py:379-402: ROM as the base class of GPR
+    run_gpr_style(golden, eng, foreign_basis=foreign)
+
+
+def test_upload_download_staging(eng):
+    """to_device / to_host go through pinned staging (spr_upload_bytes kernel, pinned D2H): values, dtypes, ring reuse."""
+    import torch
+    rng = np.random.default_rng(5)
+    keep = []
+    for i in range(3 * eng._STAGE_SLOTS):                 # more uploads than ring slots, all kept alive
+        a = rng.standard_normal((i + 1, 7))
+        keep.append((a, eng.to_device(a)))
+    for a, t in keep:
+        np.testing.assert_array_equal(eng.to_host(t), a)
+    idx = np.arange(13, dtype=np.int32)
+    t = eng.to_device(idx, dtype=torch.int64)
+    assert t.dtype == torch.int64 and eng.to_host(t).tolist() == list(range(13))
+    odd = eng.to_device(np.arange(5, dtype=np.uint8), dtype=torch.uint8)      # 5 bytes: not a multiple of 8
+    assert eng.to_host(odd).tolist() == [0, 1, 2, 3, 4]
+    big = rng.standard_normal((300, 1000))                # 2.4 MB: above the upload staging size
+    np.testing.assert_array_equal(eng.to_host(eng.to_device(big)), big)
+    view = eng.to_device(big)[::2, 1:50]                  # non-contiguous download
+    np.testing.assert_array_equal(eng.to_host(view), big[::2, 1:50])
 
 
 # ---- kernel-level parity against the oracle, shapes chosen to hit every template family ----

@@ -7,11 +7,17 @@ import scipy.sparse as sp
 
 from openmeasure_amd.sparse_sensing import ROM, SPR
 from tests.numpy_engine import NumpyEngine
-from tests.parity import run_fixture
+from tests.parity import run_fixture, run_gpr_style
 
 
 def test_fixture_through_host_logic(golden):
     run_fixture(golden, NumpyEngine())
+
+
+@pytest.mark.parametrize('foreign', [False, True])
+def test_gpr_style_subclass(golden, foreign):           # gpr.py:379-402: a ROM subclass assigns X0 / Ur / Ar itself
+    rom = run_gpr_style(golden, NumpyEngine(), foreign_basis=foreign)
+    assert isinstance(rom.Ur, np.ndarray)
 
 
 @pytest.fixture

@@ -143,6 +143,18 @@ int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t
                            int64_t n_points, int32_t n_features, double *d_minmax,
                            void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- per-feature order statistics of the raw block: np.median(x) of scale_type 'median' (:140-141).
+ * Radix selection on order-preserving keys (key(x) = bits(x) ^ sign for x >= 0, ~bits(x) for x < 0): one call
+ * counts, for every feature f with local rows and for two targets t (lower / upper middle element), the keys
+ * whose bits above position shift+bits equal those of d_prefix[2f+t], by the `bits`-wide digit at position
+ * `shift` (1 <= bits <= 13; shift + bits == 64 counts every key).  Counts are ADDED to
+ * d_hist[f][t][1 << bits] (caller zeroes it; ranks sum them).  two_targets = 0 when both prefixes are equal
+ * (one histogram is built and written to both halves).  Five calls (13+13+13+13+12 bits) pin down both keys;
+ * the caller walks the cumulative counts between calls.  One read of X per call. */
+int spr_feature_digit_hist_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, const uint64_t *d_prefix, int32_t shift,
+                               int32_t bits, int32_t two_targets, uint64_t *d_hist, void *stream);
+
 /* ---- axis_cnt=None (np.average(x, axis=None), :112): scalar centre per feature ----------------
  * spr_colsums_f64: d_out[f][0][m] = sum_i (x_i - mean_i), d_out[f][1][m] = sum_i mean_i (x_i - mean_i)
  * over the LOCAL rows of feature f -- the two vectors that turn the row-centred Gram blocks into the

@@ -46,6 +46,7 @@ PROTOTYPES = {
     'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     'spr_feature_minmax_workspace': (_sz, [_i32]),
     'spr_feature_minmax_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    'spr_feature_digit_hist_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _i32, _i32, _i32, _p, _p]),
     'spr_colsums_workspace': (_sz, [_i32, _i32]),
     'spr_colsums_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     'spr_fill_feature_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p]),

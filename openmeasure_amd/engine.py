@@ -257,6 +257,16 @@ class HipEngine:
                                                    ws.numel(), self._stream()), 'spr_feature_minmax_f64')
         return out
 
+    def feature_digit_hist(self, X, row0, n_points, n_features, prefix, shift, bits, two_targets):
+        """One radix-selection pass (spr_feature_digit_hist_f64).  prefix: (F, 2) int64 tensor holding the uint64 key
+        prefixes; -> (F, 2, 1 << bits) int64 counts over the local rows."""
+        n, m, ld = self._check_matrix(X)
+        hist = self.zeros((n_features, 2, 1 << bits), dtype=self.torch.int64)
+        _lib.check(self.lib.spr_feature_digit_hist_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(prefix),
+                                                       shift, bits, int(bool(two_targets)), _ptr(hist),
+                                                       self._stream()), 'spr_feature_digit_hist_f64')
+        return hist
+
     def colsums(self, X, row0, n_points, n_features, rowmean):
         """-> (F, 2, m): sum_i c_i and sum_i mean_i c_i per feature (c_i = x_i - mean_i), local rows."""
         n, m, ld = self._check_matrix(X)

@@ -316,7 +316,8 @@ class ROM:
         self._host['X0'] = value                              # gpr.py:379 stores what scale_data returned
 
     # ------------------------------------------------------------------ a2 scale_data
-    _DEVICE_SCALINGS = ('std', 'none', 'pareto', 'vast', 'range', 'level', 'max', 'variance', 'poisson', 'l2-norm')
+    _DEVICE_SCALINGS = ('std', 'none', 'pareto', 'vast', 'range', 'level', 'max', 'variance', 'median', 'poisson',
+                        'l2-norm')
 
     def _check_scaling(self, scale_type, axis_cnt):
         known = ['std', 'none', 'pareto', 'vast', 'range', 'level', 'max', 'variance', 'median', 'poisson',
@@ -324,8 +325,10 @@ class ROM:
         if scale_type not in known:
             raise NotImplementedError('The scaling method selected has not been implemented yet')   # :164
         if scale_type not in self._DEVICE_SCALINGS:
-            raise NotImplementedError(f"scale_type={scale_type!r} has no device implementation (needs a per-feature "
-                                      'median / kurtosis); no CPU fallback.')
+            # the reference's own 'vast_2/3/4' branches assign scipy's per-column kurtosis (an m-vector) to a
+            # column of n_points rows (:147-157) and fail with a broadcast error unless n_points == m
+            raise NotImplementedError(f"scale_type={scale_type!r} has no device implementation (per-column kurtosis, "
+                                      'ill-defined in the reference itself); no CPU fallback.')
         if axis_cnt not in (1, None):
             raise NotImplementedError(f'axis_cnt={axis_cnt!r}: row centring (1) and scalar centring (None) have a '
                                       'device implementation; no CPU fallback for the rest.')
@@ -351,11 +354,47 @@ class ROM:
                 return np.sqrt(mu)
             if scale_type == 'l2-norm':
                 return np.sqrt(cnt * m * (var + mu * mu))
+            if scale_type == 'median':
+                return self._feature_median()
             eng = self._engine()
             mm = self._all_gather(eng.feature_minmax(self._Xd(), self._row0, self.n_points, self.n_features))
             mm = eng.to_host(mm)                              # (world, F, 2)
             fmin, fmax = mm[:, :, 0].min(axis=0), mm[:, :, 1].max(axis=0)
             return fmax - fmin if scale_type == 'range' else fmax
+
+    _SELECT_DIGITS = (13, 13, 13, 13, 12)
+
+    def _feature_median(self):
+        """np.median of every raw feature block (:140-141) by radix selection on the device: five histogram passes
+        over X (csrc/select.hip), the cumulative walk between passes on the host; histograms are all-reduced so
+        every rank follows the same path.  Exact: returns the mean of the two middle order statistics."""
+        eng = self._engine()
+        Xd = self._Xd()
+        F, m = self.n_features, Xd.shape[1]
+        N = self.n_points * m                                  # values per feature block (global)
+        want = np.array([(N - 1) // 2, N // 2], dtype=np.int64)
+        rank = np.tile(want, (F, 1))                           # remaining rank inside the current prefix
+        prefix = np.zeros((F, 2), dtype=np.uint64)
+        shift = 64
+        i64 = eng.torch.int64
+        for bits in self._SELECT_DIGITS:
+            shift -= bits
+            two = bool(np.any(prefix[:, 0] != prefix[:, 1]))
+            hist = eng.feature_digit_hist(Xd, self._row0, self.n_points, F, eng.to_device(prefix.view(np.int64), dtype=i64),
+                                          shift, bits, two)
+            hist = eng.to_host(self._all_reduce(hist))          # (F, 2, 1 << bits)
+            cum = np.cumsum(hist, axis=2)
+            for f in range(F):
+                for t in range(2):
+                    b = int(np.searchsorted(cum[f, t], rank[f, t], side='right'))
+                    if b >= cum.shape[2]:
+                        raise RuntimeError('median selection lost its target (NaN in X?)')
+                    rank[f, t] -= cum[f, t, b - 1] if b > 0 else 0
+                    prefix[f, t] |= np.uint64(b) << np.uint64(shift)
+        sign = np.uint64(1) << np.uint64(63)
+        bits_ = np.where(prefix & sign, prefix ^ sign, ~prefix)   # inverse of the order-preserving key
+        vals = bits_.view(np.float64)
+        return 0.5 * (vals[:, 0] + vals[:, 1])
 
     def _stats_pass(self, scale_type='std', axis_cnt=1):
         """Fused K1+K3a pass, cross-rank merge, per-feature scale. Leaves rowmean/scale on the device."""

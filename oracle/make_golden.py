@@ -57,8 +57,13 @@ def synth(n_points, n_features, m, k, rho, eps, seed):
     return np.ascontiguousarray(X)
 
 
+ONLY = set(sys.argv[1:])
+
+
 def run_case(sps, name, X, n_features, select_modes, n_modes, seed, mask_frac=None, store_X0=False,
              scale_type='std', axis_cnt=1):
+    if ONLY and name not in ONLY:                            # `make_golden.py name ...` regenerates just those cases
+        return
     n, m = X.shape
     n_points = n // n_features
     rng = np.random.default_rng(seed + 7)
@@ -155,7 +160,7 @@ def main():
     # the other per-feature scalings of ROM.scale_data (:117-161) on the G2 matrix (positive data so
     # that 'level' / 'poisson' / 'vast' are well defined)
     X = synth(500, 3, 12, 12, 0.7, 1e-3, 202) * 0.05 + 5.0
-    for k, st in enumerate(['none', 'pareto', 'vast', 'level', 'variance', 'poisson', 'l2-norm', 'range', 'max']):
+    for k, st in enumerate(['none', 'pareto', 'vast', 'level', 'variance', 'poisson', 'l2-norm', 'range', 'max', 'median']):
         run_case(sps, 'g5_' + st.replace('-', ''), X, 3, 'number', 4, 500 + k, scale_type=st)
     # scalar centring per feature (axis_cnt=None, tests/test_rom.py:23-29)
     run_case(sps, 'g6_axisnone', X, 3, 'number', 4, 600, axis_cnt=None)

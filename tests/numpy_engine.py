@@ -70,6 +70,23 @@ class NumpyEngine:
             out[f] = (x[sel].min(), x[sel].max()) if sel.any() else (np.inf, -np.inf)
         return torch.from_numpy(out)
 
+    def feature_digit_hist(self, X, row0, n_points, n_features, prefix, shift, bits, two_targets):
+        x = X.numpy()
+        feat = self._feat(x.shape[0], row0, n_points, n_features)
+        u = x.view(np.uint64)
+        sign = np.uint64(1) << np.uint64(63)
+        key = np.where(u & sign, ~u, u | sign)
+        pre = prefix.numpy().view(np.uint64)
+        out = np.zeros((n_features, 2, 1 << bits), dtype=np.int64)
+        top = shift + bits
+        for f in range(n_features):
+            k = key[feat == f].ravel()
+            for t in range(2):
+                sel = k if top >= 64 else k[(k >> np.uint64(top)) == (pre[f, t] >> np.uint64(top))]
+                d = ((sel >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+                out[f, t] = np.bincount(d, minlength=1 << bits)
+        return torch.from_numpy(out)
+
     def colsums(self, X, row0, n_points, n_features, rowmean):
         x, mu = X.numpy(), rowmean.numpy()
         c = x - mu[:, None]

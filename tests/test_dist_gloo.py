@@ -57,7 +57,7 @@ def _worker(rank, world, port, fixture, out_dir):
 
 
 @pytest.mark.parametrize('fixture,world', [('g2_num4', 2), ('g2_num4', 3), ('g3_num8', 2), ('g2_num4_mask', 2), ('g4_num5', 3),
-                                           ('g5_range', 2), ('g5_l2norm', 3), ('g6_axisnone', 2)])
+                                           ('g5_range', 2), ('g5_l2norm', 3), ('g5_median', 3), ('g6_axisnone', 2)])
 def test_sharded_path_matches_reference(tmp_path, fixture, world):
     from tests.conftest import load_golden
     from tests.parity import REL_FRO, align_signs, rel_fro

@@ -46,6 +46,29 @@ def test_gpr_style_subclass(golden, eng, foreign):       # gpr.py:379-402: ROM a
     run_gpr_style(golden, eng, foreign_basis=foreign)
 
 
+@pytest.mark.parametrize('n_points,F,m,seed', [(5000, 3, 64, 0), (1001, 2, 7, 1), (257, 5, 256, 2), (40000, 1, 1, 3)])
+def test_median_scaling_vs_numpy(eng, n_points, F, m, seed):      # :140-141, radix selection (csrc/select.hip)
+    from openmeasure_amd.sparse_sensing import ROM
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n_points * F, m)) * np.repeat(10.0 ** rng.integers(-3, 4, F), n_points)[:, None]
+    X[::3] = np.round(X[::3], 1)                                    # many exact ties, both signs
+    X += np.repeat(rng.integers(-1, 2, F), n_points)[:, None] * 2.5
+    rom = ROM(X, F, None, engine=eng)
+    rom.scale_data('median')
+    want = np.array([np.median(X[f * n_points:(f + 1) * n_points]) for f in range(F)])
+    np.testing.assert_array_equal(rom._scl_f, want)
+    # per-shard histograms add up to the histogram of the whole block (what the all-reduce relies on)
+    import torch
+    Xd = eng.to_device(X)
+    pre = eng.to_device(np.zeros((F, 2), dtype=np.int64), dtype=torch.int64)
+    whole = eng.to_host(eng.feature_digit_hist(Xd, 0, n_points, F, pre, 51, 13, False))
+    cut = (n_points * F) // 3 + 1
+    parts = (eng.to_host(eng.feature_digit_hist(Xd[:cut], 0, n_points, F, pre, 51, 13, False))
+             + eng.to_host(eng.feature_digit_hist(Xd[cut:], cut, n_points, F, pre, 51, 13, False)))
+    np.testing.assert_array_equal(whole, parts)
+    assert whole[:, 0].sum(axis=1).tolist() == [n_points * m] * F
+
+
 def test_upload_download_staging(eng):
     """to_device / to_host go through pinned staging (spr_upload_bytes kernel, pinned D2H): values, dtypes, ring reuse."""
     import torch

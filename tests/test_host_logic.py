@@ -59,8 +59,6 @@ def test_unsupported_options_raise_not_fallback(small):
     X, F, xyz = small
     spr = SPR(X, F, xyz, engine=NumpyEngine())
     with pytest.raises(NotImplementedError):
-        spr.fit(scale_type='median')
-    with pytest.raises(NotImplementedError):
         spr.fit(scale_type='vast_2')
     with pytest.raises(NotImplementedError):
         spr.fit(scale_type='bogus')                    # :164
@@ -75,6 +73,18 @@ def test_unsupported_options_raise_not_fallback(small):
         spr.train(np.eye(20), method='COLS')
     with pytest.raises(ValueError):
         spr.reconstruct(np.zeros(5), sampling=np.eye(19))
+
+
+@pytest.mark.parametrize('n_points,F,m,seed', [(7, 2, 3, 0), (10, 3, 4, 1), (33, 1, 5, 2), (64, 4, 1, 3)])
+def test_median_scaling_by_radix_selection(n_points, F, m, seed):   # :140-141, odd and even block sizes, ties, signs
+    rng = np.random.default_rng(seed)
+    X = np.round(rng.standard_normal((n_points * F, m)) * 3, 1) + rng.integers(-2, 3, size=(n_points * F, 1)) + 0.05
+    X[0, 0] = -0.0
+    rom = ROM(X, F, None, engine=NumpyEngine())
+    rom.scale_data('median')
+    want = np.array([np.median(X[f * n_points:(f + 1) * n_points]) for f in range(F)])
+    np.testing.assert_array_equal(rom._scl_f, want)
+    np.testing.assert_array_equal(rom.X_scl[:, 0], np.repeat(want, n_points))
 
 
 def test_train_predict_errors(small):                  # :791-793, :801-803, :848-854

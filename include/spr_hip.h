@@ -201,7 +201,17 @@ int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t l
  *                   rows in one sweep (pivots marked), then new candidates / d_rec / d_tau.
  * Driver loop (host): up to spr_qr_batch() steps, read d_ok once, keep the certified prefix
  * (always >= 1 step), refresh, repeat.  Single GPU: d_recs == d_rec, d_taus == d_tau.
- * Workspace: spr_qr_workspace(n_rows) bytes, the same buffer for all calls of one run. */
+ * Workspace: spr_qr_workspace(n_rows) bytes, the same buffer for all calls of one run.
+ *
+ * calc_type='gem' (SPR.gem, :586-698) runs on the same machinery: the conditional variance of a row given the
+ * rows already picked is the squared residual of the row, centred over its r entries, after projecting out the
+ * centred picks -- i.e. the pivoting above with the direction 1/sqrt(r) applied first (host puts it in Q[0],
+ * piv[0] = -1, one refresh) and the steps numbered from 1.  Two extras:
+ * spr_qr_exclude     d_nrm[i] = -1 (out of the pool for good) for rows with d_mask[i] == 0 (search mask, :617)
+ *                    and for rows whose position d_xyz[(row0+i) % n_points][xyz_dim] lies closer than d_min to
+ *                    the position of one of the picks d_piv[0..nq) (:649-652); call it before the refresh that
+ *                    applies those picks.  d_mask / d_xyz may be NULL.
+ * spr_qr_step        with d_xyz != NULL also drops the candidates closer than d_min to the step's pick. */
 #define SPR_QR_REC_LEN(r) ((r) + 3)
 size_t spr_qr_workspace(int64_t n_rows);
 int32_t spr_qr_batch(void);
@@ -213,7 +223,11 @@ int spr_qr_init_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
 int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_recs, int32_t n_rec,
                     const double *d_taus, int32_t n_tau, int32_t first, double *d_Q,
                     int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
+                    const double *d_xyz, int32_t xyz_dim, int64_t n_points, double d_min,
                     void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_exclude_f64(double *d_nrm, int64_t n_rows, int64_t row0, int64_t n_points,
+                       const uint8_t *d_mask, const double *d_xyz, int32_t xyz_dim,
+                       const int64_t *d_piv, int32_t nq, double d_min, void *stream);
 int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
                        const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq,
                        double *d_nrm, double *d_rec, double *d_tau,

@@ -404,11 +404,20 @@ __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
   for (int k = threadIdx.x; k < r; k += QR_THREADS) Q[(int64_t)step * r + k] = v[k] * inv;
 }
 
-// candidate residuals <- down-dated by direction q; the pivot's own slot leaves the race
+// |p - c| < d_min with the reference's arithmetic (np.linalg.norm of the difference, :649-652)
+__device__ inline bool within(const double *p, const double *c, int dim, double d_min) {
+  double d2 = 0.0;
+  for (int d = 0; d < dim; ++d) d2 += (c[d] - p[d]) * (c[d] - p[d]);
+  return sqrt(d2) < d_min;
+}
+
+// candidate residuals <- down-dated by direction q; the pivot's own slot leaves the race (and, for GEM
+// placement, so does every candidate closer than d_min to it)
 template <int LPR>
 __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
     const double *__restrict__ cand_U, int n_cand, int r, int ldc, const int64_t *__restrict__ cand_idx,
-    const double *__restrict__ q, const int64_t *__restrict__ piv_ptr, double *__restrict__ cand_res) {
+    const double *__restrict__ q, const int64_t *__restrict__ piv_ptr, double *__restrict__ cand_res,
+    const double *__restrict__ xyz, int dim, int64_t n_points, double d_min) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / LPR, lig = lane % LPR;
@@ -417,6 +426,9 @@ __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
   q0[0] = (k0 < r) ? q[k0] : 0.0;
   q1[0] = (k0 + 1 < r) ? q[k0 + 1] : 0.0;
   const int64_t piv = *piv_ptr;
+  double pc[3] = {0.0, 0.0, 0.0};                       // position of the pick (GEM's d_min exclusion, :649-652)
+  if (xyz)
+    for (int d = 0; d < dim; ++d) pc[d] = xyz[(piv % n_points) * dim + d];
   const int stride = gridDim.x * (QR_THREADS / 64) * RPW;
   for (int c0 = (blockIdx.x * (QR_THREADS / 64) + wave) * RPW; c0 < n_cand; c0 += stride) {
     const int c = c0 + grp;
@@ -427,6 +439,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
     if (valid && lig == 0) {
       if (old < 0.0) v = old;
       if (cand_idx[c] == piv) v = -1.0;
+      if (xyz && within(xyz + (cand_idx[c] % n_points) * dim, pc, dim, d_min)) v = -1.0;
       cand_res[c] = v;
     }
   }
@@ -438,6 +451,28 @@ __global__ void qr_mark_kernel(const int64_t *__restrict__ piv, int n, int64_t r
   if (t < n) {
     const int64_t li = piv[t] - row0;
     if (li >= 0 && li < n_rows) nrm[li] = -1.0;
+  }
+}
+
+// GEM placement (:586-698): rows outside the search mask and rows closer than d_min to one of the picks
+// piv[0..nq) leave the pool for good (nrm = -1, as for rows already chosen)
+__global__ __launch_bounds__(QR_THREADS) void qr_exclude_kernel(double *__restrict__ nrm, int64_t n_rows, int64_t row0,
+                                                                int64_t n_points, const uint8_t *__restrict__ mask,
+                                                                const double *__restrict__ xyz, int dim,
+                                                                const int64_t *__restrict__ piv, int nq, double d_min) {
+  __shared__ double ctr[QR_BATCH][3];
+  if (threadIdx.x < nq && xyz) {
+    const int64_t g = piv[threadIdx.x];
+    for (int d = 0; d < 3; ++d) ctr[threadIdx.x][d] = (d < dim && g >= 0) ? xyz[(g % n_points) * dim + d] : INFINITY;
+  }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * QR_THREADS + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * QR_THREADS) {
+    bool out = mask && !mask[i];
+    if (!out && xyz && nq > 0) {
+      const double *p = xyz + ((row0 + i) % n_points) * dim;
+      for (int t = 0; t < nq; ++t) out = out || within(p, ctr[t], dim, d_min);
+    }
+    if (out) nrm[i] = -1.0;
   }
 }
 
@@ -566,10 +601,13 @@ extern "C" int spr_qr_init_f64(const double *d_Ur, int64_t n_rows, int32_t r, in
 
 extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_recs, int32_t n_rec,
                                const double *d_taus, int32_t n_tau, int32_t first, double *d_Q, int64_t *d_piv,
-                               double *d_gap, double *d_ok, double *d_rec, void *d_workspace,
-                               size_t workspace_bytes, void *stream) {
+                               double *d_gap, double *d_ok, double *d_rec, const double *d_xyz, int32_t xyz_dim,
+                               int64_t n_points, double d_min, void *d_workspace, size_t workspace_bytes,
+                               void *stream) {
   SPR_REQUIRE(d_recs && d_taus && d_Q && d_piv && d_ok && d_rec && d_workspace, SPR_E_INVALID,
               "spr_qr_step_f64: NULL pointer");
+  SPR_REQUIRE(!d_xyz || (xyz_dim >= 1 && xyz_dim <= 3 && n_points > 0), SPR_E_INVALID,
+              "spr_qr_step_f64: xyz needs 1..3 columns and n_points > 0");
   SPR_REQUIRE(n_rows > 0 && r > 0 && r <= SPR_MAX_R && step >= 0 && step < r && n_rec >= 1 && n_tau >= 1,
               SPR_E_INVALID, "spr_qr_step_f64: bad r=%d step=%d n_rec=%d", r, step, n_rec);
   SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "spr_qr_step_f64: workspace too small");
@@ -583,7 +621,7 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   const int rows_per_block = (QR_THREADS / 64) * (64 / lpr);
   int grid = (n_cand + rows_per_block - 1) / rows_per_block;
   if (grid > 256) grid = 256;
-#define CD(L) hipLaunchKernelGGL(qr_cand_downdate_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q + (int64_t)step * r, d_piv + step, w.cand_res); break
+#define CD(L) hipLaunchKernelGGL(qr_cand_downdate_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q + (int64_t)step * r, d_piv + step, w.cand_res, d_xyz, (int)xyz_dim, n_points, d_min); break
   switch (lpr) {
     case 1: CD(1);
     case 2: CD(2);
@@ -597,6 +635,22 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, (const double *)nullptr, 0, w.cand_idx,
                      w.cand_res, w.cand_U, n_cand, (int)r, ldc, (double *)nullptr, d_rec);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+extern "C" int spr_qr_exclude_f64(double *d_nrm, int64_t n_rows, int64_t row0, int64_t n_points,
+                                  const uint8_t *d_mask, const double *d_xyz, int32_t xyz_dim,
+                                  const int64_t *d_piv, int32_t nq, double d_min, void *stream) {
+  SPR_REQUIRE(d_nrm && n_rows > 0 && row0 >= 0 && n_points > 0, SPR_E_INVALID, "spr_qr_exclude_f64: bad arguments");
+  SPR_REQUIRE(nq >= 0 && nq <= QR_BATCH && (nq == 0 || (d_xyz && d_piv)), SPR_E_INVALID,
+              "spr_qr_exclude_f64: nq=%d picks need xyz and piv (at most %d per call)", nq, QR_BATCH);
+  SPR_REQUIRE(!d_xyz || (xyz_dim >= 1 && xyz_dim <= 3), SPR_E_INVALID, "spr_qr_exclude_f64: xyz needs 1..3 columns");
+  if (!d_mask && nq == 0) return SPR_OK;
+  int64_t blocks = (n_rows + QR_THREADS - 1) / QR_THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(qr_exclude_kernel, dim3((int)blocks), dim3(QR_THREADS), 0, static_cast<hipStream_t>(stream), d_nrm,
+                     n_rows, row0, n_points, d_mask, d_xyz, (int)xyz_dim, d_piv, (int)nq, d_min);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }

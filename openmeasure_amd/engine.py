@@ -340,12 +340,22 @@ class HipEngine:
                    'spr_qr_init_f64')
         return st
 
-    def qr_step(self, st, step, recs, taus, first):
-        """recs: (n_rank, r+3) records, taus: (n_rank, 1); one candidate-set step (see spr_hip.h)."""
+    def qr_step(self, st, step, recs, taus, first, xyz=None, n_points=0, d_min=0.0):
+        """recs: (n_rank, r+3) records, taus: (n_rank, 1); one candidate-set step (see spr_hip.h).
+        xyz (n_points, D) + d_min: GEM's distance exclusion around the step's pick."""
         _lib.check(self.lib.spr_qr_step_f64(st['n'], st['r'], step, _ptr(recs), recs.shape[0], _ptr(taus),
                                             taus.numel(), int(bool(first)), _ptr(st['Q']), _ptr(st['piv']),
-                                            _ptr(st['gap']), _ptr(st['ok']), _ptr(st['rec']), _ptr(st['ws']),
-                                            st['ws'].numel(), self._stream()), 'spr_qr_step_f64')
+                                            _ptr(st['gap']), _ptr(st['ok']), _ptr(st['rec']), _ptr(xyz),
+                                            xyz.shape[1] if xyz is not None else 0, n_points, float(d_min),
+                                            _ptr(st['ws']), st['ws'].numel(), self._stream()), 'spr_qr_step_f64')
+
+    def qr_exclude(self, st, mask=None, xyz=None, n_points=1, j0=0, nq=0, d_min=0.0):
+        """Rows outside `mask` (uint8 per local row) and rows closer than d_min to the picks piv[j0:j0+nq] leave
+        the pool (spr_qr_exclude_f64)."""
+        piv = st['piv'][j0:j0 + nq] if nq else None
+        _lib.check(self.lib.spr_qr_exclude_f64(_ptr(st['nrm']), st['n'], st['row0'], n_points, _ptr(mask), _ptr(xyz),
+                                               xyz.shape[1] if xyz is not None else 0, _ptr(piv), nq, float(d_min),
+                                               self._stream()), 'spr_qr_exclude_f64')
 
     def qr_refresh(self, st, j0, nq):
         """Apply the accepted directions Q[j0:j0+nq] to every row, redraw candidates / record / tau."""

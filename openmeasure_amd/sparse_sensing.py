@@ -136,21 +136,26 @@ def _eigh_small(G):
         return np.linalg.eigh(G)
 
 
-def pivot_loop(eng, st, s, all_gather=lambda t: t[None]):
+def pivot_loop(eng, st, s, all_gather=lambda t: t[None], start=0, near=None):
     """Host driver of the candidate-set pivoting (include/spr_hip.h, K6): batches of certified
-    steps on the candidate set, one full sweep per batch.  Returns the number of sweeps over Ur."""
-    j, sweeps = 0, 1
+    steps on the candidate set, one full sweep per batch.  Returns the number of sweeps over Ur.
+    start: first step index (GEM keeps its centring direction in slot 0); near = (xyz, n_points, d_min):
+    GEM's distance exclusion around every pick."""
+    kw = dict(xyz=near[0], n_points=near[1], d_min=near[2]) if near is not None else {}
+    j, sweeps = start, 1
     while j < s:
         nb = min(eng.qr_batch, s - j)
         taus = all_gather(st['tau'])
         for t in range(nb):                                   # steps on the candidate set, no host sync
-            eng.qr_step(st, j + t, all_gather(st['rec']), taus, first=(t == 0))
+            eng.qr_step(st, j + t, all_gather(st['rec']), taus, first=(t == 0), **kw)
         ok = eng.to_host(st['ok'][j:j + nb])                   # one sync per batch
         k = nb if ok.all() else int(np.argmin(ok))             # certified prefix (>= 1 by construction)
         if k < 1:
             raise RuntimeError('optimal_placement: first step after a sweep was not certified')
         j += k
         if j < s:
+            if near is not None:
+                eng.qr_exclude(st, j0=j - k, nq=k, **kw)
             eng.qr_refresh(st, j - k, k)
             sweeps += 1
     return sweeps
@@ -701,7 +706,7 @@ class SPR(ROM):
         a dense ndarray when it is small (< 64 MiB), a scipy.sparse CSR matrix otherwise.
         The ordered global sensor rows are also kept in ``self.sensors_``."""
         if calc_type == 'gem':
-            raise NotImplementedError("calc_type='gem' has no device implementation yet (no CPU fallback).")
+            return self._placement_gem(n_sensors, mask, d_min)
         if calc_type != 'qr':
             raise NotImplementedError('The sensor selection method has not been implemented yet')
         eng = self._engine()
@@ -721,6 +726,55 @@ class SPR(ROM):
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])
         import scipy.sparse as sp
+        C = sp.csr_matrix((np.ones(s), piv, np.arange(s + 1)), shape=(s, n))
+        if s * n * 8 <= _DENSE_C_LIMIT:
+            C = C.toarray()
+        self._placed = (C, piv)
+        return C
+
+    def _placement_gem(self, n_sensors, mask, d_min):
+        """calc_type='gem' (reference :586-698, :745-751): greedy maximisation of the conditional variance
+        sigma_y^2 - S_ya S_aa^-1 S_ay of a row of Ur (its r entries as samples) given the rows picked so far,
+        inside `mask`, never closer than d_min to an earlier pick.  That quantity is 1/(r-1) times the squared
+        residual of the row, centred over its entries, after projecting out the centred picks, so the run is the
+        QR pivoting above with the direction 1/sqrt(r) applied first.  The reference adds unseeded noise
+        1e-5*N(0,1) to the diagonal of S_aa before inverting it (:667-668); this implementation is the
+        noise-free limit, so picks whose lead over the runner-up is below that noise level are not comparable.
+        Beyond r-1 sensors S_aa is singular and the reference's picks are decided by that noise alone."""
+        eng = self._engine()
+        Ur_d = self._d['Ur']
+        r = self.r
+        if type(n_sensors) is not int or n_sensors < 1:
+            raise ValueError('n_sensors must be a positive integer.')
+        if n_sensors > r - 1:
+            raise NotImplementedError(f'gem with n_sensors={n_sensors} > r-1={r - 1}: the covariance of the picked rows '
+                                      'is singular there and the reference result is set by its unseeded noise.')
+        mask_d = None
+        if mask is not None:
+            mask = np.asarray(mask)
+            if mask.dtype != np.bool_ or mask.shape != (Ur_d.shape[0],):
+                raise IndexError('mask must be a boolean array with one entry per (local) row')
+            mask_d = eng.to_device(mask.astype(np.uint8), dtype=eng.torch.uint8)
+        near = None
+        if d_min > 0:
+            xyz = np.asarray(self.xyz, dtype=np.float64)
+            if xyz.ndim != 2 or xyz.shape[0] != self.n_points or not 1 <= xyz.shape[1] <= 3:
+                raise ValueError('gem with d_min > 0 needs xyz of shape (n_points, 1..3).')
+            near = (eng.to_device(xyz), self.n_points, float(d_min))
+        s = n_sensors
+        st = eng.qr_begin(Ur_d, self._row0, s + 1)
+        st['Q'][0] = r ** -0.5                                # centring direction; no row is attached to it
+        st['piv'][0] = -1
+        if mask_d is not None:
+            eng.qr_exclude(st, mask=mask_d, n_points=self.n_points)
+        eng.qr_refresh(st, 0, 1)
+        sweeps = 1 + pivot_loop(eng, st, s + 1, self._all_gather, start=1, near=near)
+        self.pivot_sweeps_ = sweeps
+        piv = eng.to_host(st['piv'])[1:].astype(np.int64)
+        self.sensors_ = piv
+        self.pivot_gap_ = eng.to_host(st['gap'])[1:]
+        import scipy.sparse as sp
+        n = self._n_global
         C = sp.csr_matrix((np.ones(s), piv, np.arange(s + 1)), shape=(s, n))
         if s * n * 8 <= _DENSE_C_LIMIT:
             C = C.toarray()

@@ -137,6 +137,35 @@ def run_case(sps, name, X, n_features, select_modes, n_modes, seed, mask_frac=No
           f'-> {os.path.getsize(path)/1e6:.2f} MB')
 
 
+def run_gem_case(sps, name, X, n_features, n_modes, n_sensors, seed, d_min=0.0, mask_frac=None, xyz_dim=3):
+    """calc_type='gem' (:586-698).  The reference regularises with UNSEEDED noise (:667); the case is run under
+    three np.random seeds and only kept if the picks agree, so the fixture pins the noise-free algorithm."""
+    if ONLY and name not in ONLY:
+        return
+    n = X.shape[0]
+    n_points = n // n_features
+    rng = np.random.default_rng(seed + 7)
+    xyz = rng.random((n_points, xyz_dim))
+    mask = (rng.random(n) < mask_frac) if mask_frac is not None else None
+    spr = sps.SPR(X.copy(), n_features, xyz)
+    spr.fit(select_modes='number', n_modes=n_modes)
+    picks = []
+    for np_seed in (0, 1, 2):
+        np.random.seed(np_seed)
+        C = spr.optimal_placement(calc_type='gem', n_sensors=n_sensors, mask=mask, d_min=d_min)
+        assert C.shape == (n_sensors, n)
+        picks.append(np.argmax(C, axis=1))
+    assert all(np.array_equal(picks[0], p) for p in picks[1:]), f'{name}: picks depend on the noise seed {picks}'
+    out = dict(X=X, n_features=np.int64(n_features), n_modes=np.int64(n_modes), n_sensors=np.int64(n_sensors),
+               xyz=xyz, d_min=np.float64(d_min), gem_piv=picks[0].astype(np.int64), Ur=spr.Ur.copy(), Ar=spr.Ar.copy(),
+               C_shape=np.array(C.shape))
+    if mask is not None:
+        out['mask'] = mask
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: n={n} r={spr.r} gem picks={picks[0]} -> {os.path.getsize(path)/1e6:.2f} MB')
+
+
 def main():
     sps = _import_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -165,6 +194,11 @@ def main():
     # scalar centring per feature (axis_cnt=None, tests/test_rom.py:23-29)
     run_case(sps, 'g6_axisnone', X, 3, 'number', 4, 600, axis_cnt=None)
     run_case(sps, 'g6_axisnone_pareto', X, 3, 'number', 5, 601, axis_cnt=None, scale_type='pareto')
+    # GEM placement: distance exclusion, search mask, 2-D coordinates, the full r-1 sensors
+    X = synth(300, 3, 12, 12, 0.7, 1e-3, 707)
+    run_gem_case(sps, 'gem_dmin', X, 3, 8, 6, 701, d_min=0.15)
+    run_gem_case(sps, 'gem_mask', X, 3, 8, 5, 702, mask_frac=0.5)
+    run_gem_case(sps, 'gem_xz_full', X, 3, 6, 5, 703, d_min=0.05, xyz_dim=2)
 
 
 if __name__ == '__main__':

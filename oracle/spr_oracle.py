@@ -191,6 +191,61 @@ def qr_pivots(Ur, mask=None):
     return np.asarray(P[:r], dtype=np.int64), Ur
 
 
+def gem_pivots(Ur, n_sensors, xyz, n_features, mask=None, d_min=0.0, noise=None):
+    """SPR.gem (:586-698): greedy conditional-variance ("entropy") maximisation.
+
+    Follows the reference statement by statement -- row variances with ddof=1 over the r entries (:621, :637),
+    scaling coef = 2/sqrt(max variance) (:622-624), first pick = largest variance (:641), then per step the
+    candidates filtered by the distance mask of the PREVIOUS pick (:655-657), S_aa = np.cov of the scaled
+    picked rows (:660), its inverse (:662-668), and sigma2y_cond = sigma2y - S_ya S_aa^-1 S_ay (:670-678) with
+    np.argmax's first-index tie-break (:681) -- except that the per-candidate Python loop of np.cov calls
+    (:670) is evaluated for all candidates at once (same covariance entries: centred dot products / (r-1)).
+    ``noise``: None -> the regularisation-free limit (what the device path computes);
+               a callable k -> vector of length k to reproduce the reference's 1e-5*np.random.normal (:667).
+    Returns the picked global rows (int64) and the relative lead of every pick over the runner-up."""
+    Ur = np.asarray(Ur, dtype=np.float64)
+    n, r = Ur.shape
+    if mask is None:
+        mask = np.ones((n,), dtype=bool)
+    index_org = np.arange(n)
+    sigma = np.var(Ur[mask], ddof=1, axis=1)
+    coef = 1 / np.sqrt(sigma.max()) * 2
+    Ur_msk = Ur[mask] * coef
+    Ur_scl = Ur * coef
+    xyz_msk = np.tile(xyz, (n_features, 1))[mask]
+    index_msk = index_org[mask]
+    picks, leads = [], []
+    sigma_coef = np.var(Ur_msk, ddof=1, axis=1)
+
+    def lead(v, i):
+        rest = np.delete(v, i)
+        return (v[i] - rest.max()) / v[i] if rest.size and v[i] > 0 else 0.0
+
+    for s in range(n_sensors):
+        if s == 0:
+            temp = sigma_coef
+        else:
+            Ur_msk, xyz_msk, index_msk = Ur_msk[mask_d], xyz_msk[mask_d], index_msk[mask_d]
+            A = Ur_scl[picks, :]
+            Ac = A - A.mean(axis=1, keepdims=True)
+            S_aa = np.atleast_2d(Ac @ Ac.T / (r - 1))            # np.cov(A, ddof=1)
+            if s == 1:
+                S_inv = 1 / S_aa
+            else:
+                reg = np.zeros(s) if noise is None else np.asarray(noise(s))
+                S_inv = np.linalg.inv(S_aa + np.diag(reg))
+            Yc = Ur_msk - Ur_msk.mean(axis=1, keepdims=True)
+            S_ya = Yc @ Ac.T / (r - 1)                            # rows: Sigma[-1, :-1] of every candidate
+            sigma2y = np.sum(Yc * Yc, axis=1) / (r - 1)
+            temp = sigma2y - np.sum((S_ya @ S_inv) * S_ya, axis=1)
+        i_sensor = int(np.argmax(temp))
+        picks.append(int(index_msk[i_sensor]))
+        leads.append(lead(temp, i_sensor))
+        d_sensor = np.linalg.norm(xyz_msk[i_sensor, :] - xyz_msk, axis=1)
+        mask_d = d_sensor >= d_min
+    return np.asarray(picks, dtype=np.int64), np.asarray(leads)
+
+
 def one_hot_C(piv, n):
     """Dense s x n one-hot measurement matrix (:741-743)."""
     C = np.zeros((len(piv), n))

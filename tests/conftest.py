@@ -10,8 +10,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
-GOLDEN = sorted(os.path.splitext(os.path.basename(p))[0]
-                for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+_ALL = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+GOLDEN = [n for n in _ALL if not n.startswith('gem_')]       # fit -> qr placement -> train -> predict -> reconstruct
+GOLDEN_GEM = [n for n in _ALL if n.startswith('gem_')]       # calc_type='gem' placement cases
 
 
 def pytest_configure(config):
@@ -35,3 +36,18 @@ def load_golden(name):
 @pytest.fixture(params=GOLDEN)
 def golden(request):
     return load_golden(request.param)
+
+
+def load_golden_gem(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    g = {k: z[k] for k in z.files}
+    for k in ('n_features', 'n_modes', 'n_sensors'):
+        g[k] = int(g[k])
+    g['d_min'] = float(g['d_min'])
+    g['name'] = name
+    return g
+
+
+@pytest.fixture(params=GOLDEN_GEM)
+def golden_gem(request):
+    return load_golden_gem(request.param)

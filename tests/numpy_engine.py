@@ -140,7 +140,23 @@ class NumpyEngine:
         self._record(st)
         return st
 
-    def qr_step(self, st, step, recs, taus, first):
+    def qr_exclude(self, st, mask=None, xyz=None, n_points=1, j0=0, nq=0, d_min=0.0):
+        nrm = st['nrm'].numpy()
+        if mask is not None:
+            nrm[mask.numpy() == 0] = -1.0
+        if nq and xyz is not None:
+            self._exclude_near(st, xyz.numpy(), n_points, st['piv'].numpy()[j0:j0 + nq], d_min)
+        self._record(st)
+
+    @staticmethod
+    def _exclude_near(st, xyz, n_points, picks, d_min):
+        nrm = st['nrm'].numpy()
+        pos = xyz[(st['row0'] + np.arange(st['n'])) % n_points]
+        for g in picks:
+            if g >= 0:
+                nrm[np.linalg.norm(pos - xyz[g % n_points], axis=1) < d_min] = -1.0
+
+    def qr_step(self, st, step, recs, taus, first, xyz=None, n_points=0, d_min=0.0):
         c = recs.numpy()
         order = np.lexsort((c[:, 1], -c[:, 0]))      # max value, then lowest index
         w = order[0]
@@ -164,10 +180,21 @@ class NumpyEngine:
         if 0 <= li < st['n']:
             new[li] = -1.0
         nrm[:] = new
+        if xyz is not None:
+            self._exclude_near(st, xyz.numpy(), n_points, [piv], d_min)
         self._record(st)
 
     def qr_refresh(self, st, j0, nq):
-        pass                                         # the model down-dates every row at every step
+        # the model down-dates every row at every step; only a direction that no step produced (GEM's
+        # centring direction Q[0]) is applied here
+        if st['piv'][j0] < 0:
+            q = st['Q'].numpy()[j0]
+            nrm = st['nrm'].numpy()
+            d = st['Ur'].numpy() @ q
+            new = np.maximum(nrm - d * d, 0.0)
+            new[nrm < 0] = -1.0
+            nrm[:] = new
+            self._record(st)
 
     # K7 + K8
     def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean, scale=None, n_points=0):

@@ -147,3 +147,23 @@ def run_gpr_style(g, engine, foreign_basis=False):
     assert rel_fro(X_rec, ref) < REL_FRO
     assert X_rec.shape == want.shape
     return rom
+
+
+def run_gem_fixture(g, engine):
+    """fit -> optimal_placement(calc_type='gem') on a GEM fixture: picks exact and ordered.
+    The variance of a row of Ur over its r entries changes when a column of Ur changes sign, so GEM's picks depend
+    on LAPACK's (arbitrary) singular-vector signs: the fitted basis is checked against the fixture up to sign, then
+    the placement runs on the reference's own basis through fit(basis=...) (:493-497)."""
+    X = g['X'].copy()
+    spr = SPR(X, g['n_features'], g['xyz'], engine=engine)
+    spr.fit(select_modes='number', n_modes=g['n_modes'])
+    sg = align_signs(spr.Ar, g['Ar'])
+    np.testing.assert_allclose(spr.Ur * sg, g['Ur'], rtol=0, atol=1e-8)
+    spr.fit(basis=(g['Ur'].copy(), g['Ar'].copy()))
+    C = spr.optimal_placement(calc_type='gem', n_sensors=g['n_sensors'], mask=g.get('mask'), d_min=g['d_min'])
+    assert C.shape == tuple(g['C_shape'])
+    np.testing.assert_array_equal(spr.sensors_, g['gem_piv'])
+    np.testing.assert_array_equal(np.argmax(np.asarray(C), axis=1), g['gem_piv'])
+    spr.train(C)                                              # the placement feeds train/predict like the QR one
+    assert spr.Theta.shape == (g['n_sensors'], spr.r)
+    return spr

@@ -89,3 +89,42 @@ def test_sharded_path_matches_reference(tmp_path, fixture, world):
     np.testing.assert_allclose(o['A3'] * sg, g['Ar_pred3'], atol=1e-7 * np.abs(g['Ar_pred3']).max())
     np.testing.assert_allclose(o['S3'], g['Ar_sigma3'], rtol=1e-6, atol=1e-9 * np.abs(g['Ar_sigma3']).max())
     assert o['gap'].min() > 1e-9
+
+
+def _gem_worker(rank, world, port, fixture, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden_gem
+        from tests.numpy_engine import NumpyEngine
+        g = load_golden_gem(fixture)
+        n = g['X'].shape[0]
+        n_loc = n // world
+        row0 = rank * n_loc
+        sl = slice(row0, row0 + n_loc)
+        spr = SPR(np.ascontiguousarray(g['X'][sl]), g['n_features'], g['xyz'], shard=RowShard(row0, n),
+                  engine=NumpyEngine())
+        spr.fit(basis=(np.ascontiguousarray(g['Ur'][sl]), g['Ar']))      # the reference's own basis signs (see parity.py)
+        mask = g.get('mask')
+        C = spr.optimal_placement(calc_type='gem', n_sensors=g['n_sensors'], d_min=g['d_min'],
+                                  mask=None if mask is None else mask[sl])
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, C_shape=C.shape)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fixture,world', [('gem_dmin', 2), ('gem_mask', 3), ('gem_xz_full', 2)])
+def test_sharded_gem_matches_reference(tmp_path, fixture, world):
+    """GEM placement over row shards: the d_min exclusion and the search mask act on every rank's own rows, the
+    pick records travel through the same all-gather as the QR placement (features straddle the shard cuts)."""
+    from tests.conftest import load_golden_gem
+    g = load_golden_gem(fixture)
+    assert g['X'].shape[0] % world == 0
+    mp.spawn(_gem_worker, args=(world, _free_port(), fixture, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        o = np.load(tmp_path / f'rank{r}.npz')
+        np.testing.assert_array_equal(o['piv'], g['gem_piv'])
+        assert tuple(o['C_shape']) == tuple(g['C_shape'])

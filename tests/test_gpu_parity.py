@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import spr_oracle as orc
-from tests.parity import REL_FRO, align_signs, rel_fro, run_fixture, run_gpr_style
+from tests.parity import REL_FRO, align_signs, rel_fro, run_fixture, run_gem_fixture, run_gpr_style
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,36 @@ def test_native_library_is_loaded(eng):
 
 def test_golden_fixture(golden, eng):
     run_fixture(golden, eng)
+
+
+def test_gem_fixture(golden_gem, eng):                    # calc_type='gem', picks pinned by the reference
+    run_gem_fixture(golden_gem, eng)
+
+
+@pytest.mark.parametrize('n_points,F,r,s,d_min,masked,seed', [(20000, 3, 16, 15, 0.05, False, 1), (5000, 4, 32, 20, 0.0, True, 2),
+                                                             (100000, 2, 8, 7, 0.02, True, 3), (3000, 1, 64, 40, 0.1, False, 4)])
+def test_gem_vs_oracle(eng, n_points, F, r, s, d_min, masked, seed):
+    """GEM on random bases large enough for several candidate-set batches, against the oracle's literal formulas."""
+    from openmeasure_amd.sparse_sensing import SPR
+    rng = np.random.default_rng(seed)
+    n = n_points * F
+    Ur = rng.standard_normal((n, r)) * (0.5 + rng.random((n, 1))) / np.sqrt(n)
+    xyz = rng.random((n_points, 3))
+    mask = rng.random(n) < 0.6 if masked else None
+    want, lead = orc.gem_pivots(Ur, s, xyz, F, mask, d_min)
+    spr = SPR(np.zeros((n, r + 2)), F, xyz, engine=eng)
+    spr.fit(basis=(Ur, np.eye(r + 2, r)))
+    C = spr.optimal_placement(calc_type='gem', n_sensors=s, mask=mask, d_min=d_min)
+    assert C.shape == (s, n)
+    k = int(np.argmax(lead < 1e-9)) if (lead < 1e-9).any() else s     # compare up to the first numerical tie
+    np.testing.assert_array_equal(spr.sensors_[:k], want[:k])
+    assert k >= min(s, 5)
+    if d_min > 0:                                          # no two sensors closer than d_min
+        p = xyz[spr.sensors_ % n_points]
+        d = np.linalg.norm(p[:, None] - p[None], axis=2) + np.eye(s)
+        assert d.min() >= d_min
+    if mask is not None:
+        assert mask[spr.sensors_].all()
 
 
 @pytest.mark.parametrize('foreign', [False, True])

@@ -7,7 +7,7 @@ import scipy.sparse as sp
 
 from openmeasure_amd.sparse_sensing import ROM, SPR
 from tests.numpy_engine import NumpyEngine
-from tests.parity import run_fixture, run_gpr_style
+from tests.parity import run_fixture, run_gem_fixture, run_gpr_style
 
 
 def test_fixture_through_host_logic(golden):
@@ -18,6 +18,10 @@ def test_fixture_through_host_logic(golden):
 def test_gpr_style_subclass(golden, foreign):           # gpr.py:379-402: a ROM subclass assigns X0 / Ur / Ar itself
     rom = run_gpr_style(golden, NumpyEngine(), foreign_basis=foreign)
     assert isinstance(rom.Ur, np.ndarray)
+
+
+def test_gem_fixture_through_host_logic(golden_gem):   # :586-698
+    run_gem_fixture(golden_gem, NumpyEngine())
 
 
 @pytest.fixture
@@ -66,7 +70,9 @@ def test_unsupported_options_raise_not_fallback(small):
         spr.fit(axis_cnt=0)
     spr.fit(n_modes=100)
     with pytest.raises(NotImplementedError):
-        spr.optimal_placement(calc_type='gem')
+        spr.optimal_placement(calc_type='gem', n_sensors=spr.r)      # > r-1: decided by the reference's noise
+    with pytest.raises(ValueError):
+        spr.optimal_placement(calc_type='gem', n_sensors=0)
     with pytest.raises(NotImplementedError):
         spr.optimal_placement(calc_type='bogus')       # :752-754
     with pytest.raises(NotImplementedError):

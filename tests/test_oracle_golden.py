@@ -148,3 +148,16 @@ def test_error_paths():
     assert orc.select_rank(ev, 3, 'variance', 99) == 3
     assert orc.select_rank(ev, 3, 'variance', 90) == 2
     assert orc.select_rank(ev, 3, 'variance', 100) == 3
+
+
+def test_gem_pivots(golden_gem):                       # :586-698, noise-free limit == the reference under 3 noise seeds
+    g = golden_gem
+    st = orc.fit(g['X'], g['n_features'], 'number', g['n_modes'])
+    np.testing.assert_array_equal(st['Ur'], g['Ur'])
+    piv, lead = orc.gem_pivots(st['Ur'], g['n_sensors'], g['xyz'], g['n_features'], g.get('mask'), g['d_min'])
+    np.testing.assert_array_equal(piv, g['gem_piv'])
+    assert lead.min() > 1e-3                            # far above the 1e-5 regularisation noise of the reference
+    rng = np.random.default_rng(3)
+    piv_n, _ = orc.gem_pivots(st['Ur'], g['n_sensors'], g['xyz'], g['n_features'], g.get('mask'), g['d_min'],
+                              noise=lambda k: 1e-5 * rng.standard_normal(k))
+    np.testing.assert_array_equal(piv_n, g['gem_piv'])

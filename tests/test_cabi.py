@@ -56,3 +56,19 @@ def test_product_has_no_cpu_fallback():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt and 'numpy_engine' not in txt.replace(
                     'tests/numpy_engine.py', ''), f
+
+
+def test_integration_doc_matches_prototypes():
+    """The ctypes stub shown in INTEGRATION.md declares the same argument lists as the library binding."""
+    import ctypes as C
+    import os
+    import re
+    from openmeasure_amd import _lib
+    names = {'_p': C.c_void_p, '_i32': C.c_int32, '_i64': C.c_int64, '_sz': C.c_size_t, '_dbl': C.c_double}
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    found = re.findall(r'_lib\.(spr_\w+)\.argtypes = \[([^\]]*)\]', text)
+    assert len(found) >= 5
+    for fn, args in found:
+        want = _lib.PROTOTYPES[fn][1]
+        got = [names[a.strip()] for a in args.split(',') if a.strip()]
+        assert got == list(want), fn

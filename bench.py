@@ -55,6 +55,8 @@ def main():
     ap.add_argument('--workload', default=os.environ.get('SPR_BENCH_WORKLOAD', 'c3'), choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline / parity leg')
     ap.add_argument('--extra', action='store_true', help='also time placement/train/predict')
+    ap.add_argument('--sync-gather', action='store_true',
+                    help='join the field all-gather at the end of every step instead of overlapping it with the next Gram pass')
     args = ap.parse_args()
 
     import torch
@@ -108,15 +110,20 @@ def main():
         if timers is not None:
             timers.append((eng.time_next('stats_gram'), eng.time_next('project'), eng.time_next('reconstruct')))
         spr.fit(select_modes='number', n_modes=s)
-        return spr.reconstruct(a_d, to_host=False)
+        # field all-gather left in flight: it overlaps the next step's (MFMA-bound) Gram pass
+        return spr.reconstruct(a_d, to_host=False, wait=args.sync_gather)
+
+    def done(f):
+        return f.wait() if hasattr(f, 'wait') else f
 
     for _ in range(args.warmup):
-        step()
+        done(step())
     timers = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         field = step(timers)
+    field = done(field)                           # the last gather joins the compute stream inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     if world > 1 or force_dist:

@@ -54,13 +54,18 @@ class RowShard:
     group     torch.distributed process group (None = default group); world size 1 if
               torch.distributed is not initialised.
     Every rank must hold the same number of rows (the field all-gather needs it).
+    broadcast_basis  every rank eigen-solves the same all-reduced Gram matrix (RCCL leaves identical bits on all
+              ranks) with the same single-threaded LAPACK, so on one node the factors agree bit for bit and nothing
+              is exchanged; set True when the ranks' hosts may differ (CPU type, LAPACK build): rank 0's
+              decomposition is then broadcast, at the price of one more round trip per fit.
     """
 
-    def __init__(self, row0, n_global, group=None, force_collectives=False):
+    def __init__(self, row0, n_global, group=None, force_collectives=False, broadcast_basis=False):
         self.row0 = int(row0)
         self.n_global = int(n_global)
         self.group = group
         self.force_collectives = bool(force_collectives)   # issue the collectives even in a 1-rank group (tests)
+        self.broadcast_basis = bool(broadcast_basis)
 
     @property
     def world(self):
@@ -82,6 +87,26 @@ class DeviceMatrix:
     @property
     def shape(self):
         return tuple(self.tensor.shape)
+
+
+class PendingField:
+    """Result of ``reconstruct(..., to_host=False, wait=False)``: the (n_p, n) field in HBM whose all-gather over the
+    ranks may still be in flight on the communication stream.  ``wait()`` makes the current stream wait for it and
+    returns the tensor; nothing else may read the tensor before that."""
+
+    def __init__(self, tensor, works=()):
+        self._tensor = tensor
+        self._works = list(works)
+
+    @property
+    def shape(self):
+        return tuple(self._tensor.shape)
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return self._tensor
 
 
 class _Trace:
@@ -192,6 +217,8 @@ class ROM:
         self._row0 = shard.row0 if shard is not None else 0
         if self._row0 + X.shape[0] > n:
             raise ValueError('The local row block does not fit in the global matrix.')
+        if shard is not None and X.shape[0] * shard.world != n:
+            raise ValueError('Every rank must hold n / world rows (the field all-gather needs equal shards).')
         self._eng = engine
         self._d = {}            # device-resident state
         self._host = {}         # lazily downloaded copies
@@ -411,8 +438,11 @@ class ROM:
         rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
         tr_.mark('stats_gram')
         gram = self._all_reduce(gram)
-        fs = eng.to_host(self._all_gather(fstats))          # (world, F, 3)
-        G_f = eng.to_host(gram)                              # (F, m, m)
+        fs_d = self._all_gather(fstats)                      # (world, F, 3)
+        # one download for both: every host round trip is a sync point the GPU idles at
+        packed = eng.to_host(eng.torch.cat([gram.reshape(-1), fs_d.reshape(-1)]))
+        G_f = packed[:gram.numel()].reshape(F, m, m)
+        fs = packed[gram.numel():].reshape(fs_d.shape[0], F, 3)
         tr_.mark('collect')
         cnt = np.zeros(F); mu = np.zeros(F); m2 = np.zeros(F)
         for w in range(fs.shape[0]):                         # Chan merge in rank order
@@ -522,8 +552,8 @@ class ROM:
     def _spectrum(self, G):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
         lam, V = _eigh_small(G)
-        if self._dist():
-            # every rank must project with bit-identical factors: rank 0's decomposition wins
+        if self._dist() and self._shard.broadcast_basis:
+            # heterogeneous hosts: every rank must project with bit-identical factors, rank 0's decomposition wins
             import torch.distributed as dist
             eng = self._engine()
             pack = eng.to_device(np.concatenate([lam, V.ravel()]))
@@ -659,11 +689,14 @@ class ROM:
         return True
 
     # ------------------------------------------------------------------ a10 reconstruct
-    def reconstruct(self, Ar, sampling=None, to_host=True):
+    def reconstruct(self, Ar, sampling=None, to_host=True, wait=True):
         """Reference :342-375.  Returns X_rec of shape (n, n_p) (all ranks' rows, gathered).
 
         ``to_host=False`` returns the device tensor of shape (n_p, n) instead (same values,
-        column-major) and skips the PCIe copy."""
+        column-major) and skips the PCIe copy.  With ``wait=False`` as well, a PendingField comes back
+        right after the all-gather of the field has been ENQUEUED, so the gather (720 MB per rank at config 4)
+        runs on the communication stream under whatever the caller launches next -- e.g. the MFMA-bound Gram
+        pass of the next fit(); call ``.wait()`` before reading it."""
         eng = self._engine()
         Ar = np.asarray(Ar, dtype=np.float64) if not hasattr(Ar, 'is_cuda') else Ar
         if Ar.ndim < 2:
@@ -687,10 +720,14 @@ class ROM:
             loc = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
                                   self._d['scale'], A_d)
             out = eng.empty((n_p, world * n_loc))
-            for p in range(n_p):                              # one contiguous all-gather per column
-                dist.all_gather_into_tensor(out[p], loc[p], group=self._shard.group)
+            works = [dist.all_gather_into_tensor(out[p], loc[p], group=self._shard.group, async_op=True)
+                     for p in range(n_p)]                     # one contiguous all-gather per column
+            if not to_host and not wait:
+                return PendingField(out, works)
+            for w in works:
+                w.wait()
         if not to_host:
-            return out
+            return out if wait else PendingField(out)
         return eng.to_host(out).T                             # (n, n_p), Fortran-ordered view
 
 

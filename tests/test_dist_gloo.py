@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, fixture, out_dir):
+def _worker(rank, world, port, fixture, out_dir, bcast=False):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -41,7 +41,7 @@ def _worker(rank, world, port, fixture, out_dir):
         assert n_loc * world == n
         row0 = rank * n_loc
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None,
-                  shard=RowShard(row0, n), engine=NumpyEngine())
+                  shard=RowShard(row0, n, broadcast_basis=bcast), engine=NumpyEngine())
         spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'],
                 n_modes=g['n_modes'])
         mask = g.get('mask')
@@ -49,6 +49,9 @@ def _worker(rank, world, port, fixture, out_dir):
         spr.train(C)
         A3, S3 = spr.predict(list(g['ys']))
         X3 = spr.reconstruct(A3)
+        pending = spr.reconstruct(A3, to_host=False, wait=False)      # gather left in flight, joined by wait()
+        assert pending.shape == (3, n)
+        np.testing.assert_array_equal(pending.wait().numpy().T, X3)
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, Sigma=spr.Sigma_r, X3=X3, A3=A3,
                  S3=S3, Theta=spr.Theta, X_cnt=spr.X_cnt, X_scl=spr.X_scl, Ur=spr.Ur, Ar=spr.Ar, C_shape=C.shape,
                  gap=spr.pivot_gap_)
@@ -59,13 +62,21 @@ def _worker(rank, world, port, fixture, out_dir):
 @pytest.mark.parametrize('fixture,world', [('g2_num4', 2), ('g2_num4', 3), ('g3_num8', 2), ('g2_num4_mask', 2), ('g4_num5', 3),
                                            ('g5_range', 2), ('g5_l2norm', 3), ('g5_median', 3), ('g6_axisnone', 2)])
 def test_sharded_path_matches_reference(tmp_path, fixture, world):
+    _run_sharded(tmp_path, fixture, world, False)
+
+
+def test_sharded_path_with_basis_broadcast(tmp_path):       # RowShard(broadcast_basis=True): rank 0's eigen-solve wins
+    _run_sharded(tmp_path, 'g3_num8', 2, True)
+
+
+def _run_sharded(tmp_path, fixture, world, bcast):
     from tests.conftest import load_golden
     from tests.parity import REL_FRO, align_signs, rel_fro
     g = load_golden(fixture)
     n = g['X'].shape[0]
     if n % world:
         pytest.skip('rows do not divide')
-    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path), bcast), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
     n_loc = n // world
     for r, o in enumerate(outs):

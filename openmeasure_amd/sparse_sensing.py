@@ -701,6 +701,9 @@ class ROM:
         Ar = np.asarray(Ar, dtype=np.float64) if not hasattr(Ar, 'is_cuda') else Ar
         if Ar.ndim < 2:
             Ar = Ar[None, :]
+        if Ar.shape[0] == 0:                                  # no measurement vectors: (n, 0), nothing to launch
+            rows = self._n_global if sampling is None else sampling.shape[0]
+            return np.zeros((rows, 0)) if to_host else eng.empty((0, rows))
         A_d = Ar if hasattr(Ar, 'is_cuda') else eng.to_device(Ar)
         if sampling is not None:                              # :365-368 -- (S Ur) Ar^T, un-scaled with S X_scl, S X_cnt
             Th, cnt, scl = self._sampled(sampling)
@@ -896,6 +899,8 @@ class SPR(ROM):
         if self.method != 'OLS':
             raise NotImplementedError('The prediction method selected has not been '
                                       'implemented yet')
+        if len(y) == 0:                                       # :863-864 allocate (0, r) and the loop never runs
+            return np.zeros((0, self.r)), np.zeros((0, self.r))
         Ar, Ar_sigma, y0 = self._solve(y)
         self.cnt_vector = self._engine().to_host(self._d['cnt'])
         self.scl_vector = self._scl_f[np.asarray(y[-1])[:, 2].astype('int')]

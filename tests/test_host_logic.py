@@ -93,6 +93,16 @@ def test_median_scaling_by_radix_selection(n_points, F, m, seed):   # :140-141, 
     np.testing.assert_array_equal(rom.X_scl[:, 0], np.repeat(want, n_points))
 
 
+def test_empty_batches(small):                          # :863-864, :362-373 with n_p = 0
+    X, F, xyz = small
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    spr.fit(select_modes='number', n_modes=3)
+    spr.train(spr.optimal_placement())
+    Ar, Ar_sigma = spr.predict([])
+    assert Ar.shape == (0, 3) and Ar_sigma.shape == (0, 3)
+    assert spr.reconstruct(np.zeros((0, 3))).shape == (20, 0)
+
+
 def test_train_predict_errors(small):                  # :791-793, :801-803, :848-854
     X, F, xyz = small
     spr = SPR(X, F, xyz, engine=NumpyEngine())

@@ -6,9 +6,122 @@
 // The dot product is closed with a butterfly over the LPR lanes and the un-scaling
 // (sparse_sensing.py:235) is applied before the store.  Workgroups are dealt to feature
 // segments (common.hpp) so the per-feature scale is a workgroup constant.
-#include "common.hpp"
+//
+// Two forms.  The MFMA form (default) treats the pass as the skinny product A . Ur^T with up to 16 coefficient
+// vectors at once: 64-row panels of Ur are staged raw in LDS by the rowtile.hpp loader (double-buffered, the
+// loads of the panel after next issued behind the stores), wave w multiplies the vectors (MFMA A operand, in
+// registers for the whole kernel) with its 16-row block (B operand, strided ds_read_b64): the result tile has
+// the vector index down the rows and the panel row across the 16 lanes of a group, so each store instruction
+// writes 16 consecutive field values per vector and no cross-lane reduction is needed at all.  r/4 MFMAs per
+// 16 rows are far below the HBM time of the panel.  The VALU form (dot product closed with a DPP butterfly,
+// 4 vectors per pass) is kept for cross-checks (SPR_RECONSTRUCT_VALU=1 at build time selects it).
+#include "rowtile.hpp"
+
+#ifndef SPR_RECONSTRUCT_VALU
+#define SPR_RECONSTRUCT_VALU 0
+#endif
 
 namespace {
+
+constexpr int RM_THREADS = 256;
+constexpr int RM_PB = 16;   // coefficient vectors per pass (one MFMA tile of rows)
+
+template <int MTR, int VEC>
+__global__ __launch_bounds__(RM_THREADS) void reconstruct_mfma_kernel(
+    const double *__restrict__ Ur, int r, int64_t ldu, SegPlan plan, const double *__restrict__ rowmean,
+    const double *__restrict__ scale, const double *__restrict__ rowscale, const double *__restrict__ A, int np0,
+    int npb, double *__restrict__ out, int64_t ldo) {
+  constexpr int NW = RM_THREADS / 64, R = 64;
+  constexpr int MPAD = 16 * MTR, MP = MPAD + 2, KSTEPS = MPAD / 4;
+  using RT = RowTile<MTR, R, MP, NW>;
+  __shared__ double smem[2 * R * MP];
+  double *const lds0 = smem, *const lds1 = smem + R * MP;
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const double sc = scale[f];
+
+  double vfrag[KSTEPS];          // MFMA A operand: A[i = lane & 15][k = lane >> 4] = vector np0+i, entry 4 ks + k
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int k = 4 * ks + (lane >> 4), j = lane & 15;
+    vfrag[ks] = (j < npb && k < r) ? A[(int64_t)(np0 + j) * r + k] : 0.0;
+  }
+  RT tile;
+  const int64_t npanels = (hi - lo + R - 1) / R;
+  int64_t c = wl;
+  if (c >= npanels) return;                       // workgroup-uniform
+  tile.template load<VEC>(Ur, ldu, r, lo + c * R, hi, wave, lane);
+  tile.raw_store(lds0, r, lo + c * R, hi, wave, lane);
+  int64_t cn = c + wpf;
+  int64_t nrow0 = (cn < npanels) ? lo + cn * R : hi;
+  tile.template load<VEC>(Ur, ldu, r, nrow0, hi, wave, lane);
+  int buf = 0;
+  const int ufrag = (lane & 15) * MP + (lane >> 4);   // B[k = lane >> 4][j = lane & 15] = panel[16 w + j][k0 + k]
+  while (c < npanels) {
+    const double *cur = buf ? lds1 : lds0;
+    double *nxt = buf ? lds0 : lds1;
+    const int64_t c2 = cn + wpf;
+    const int64_t n2row0 = (c2 < npanels) ? lo + c2 * R : hi;
+    __syncthreads();
+    const int64_t row = lo + c * R + wave * 16 + (lane & 15);   // the panel row this lane's results belong to
+    const int64_t rc = row < hi ? row : hi - 1;
+    const double mu = rowmean[rc];                               // requested before the MFMAs
+    const double rs = rowscale ? rowscale[rc] : sc;              // sampled rows carry their own scale
+    const double *p = cur + wave * 16 * MP + ufrag;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vfrag[ks], p[4 * ks], acc, 0, 0, 0);
+      if (ks == 0) {
+#pragma unroll
+        for (int it = 0; it < RT::IT; ++it) {
+          tile.raw_store_pass(it, nxt, r, nrow0, hi, wave, lane);
+          tile.template load_pass<VEC>(it, Ur, ldu, r, n2row0, hi, wave, lane);
+        }
+      }
+    }
+    // D[i = (lane >> 4) + 4 q][j = lane & 15] = a_{np0+i} . u_row
+    const double d[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pv = 4 * q + (lane >> 4);
+      if (pv < npb && row < hi) out[(int64_t)(np0 + pv) * ldo + row] = rs * d[q] + mu;
+    }
+    buf ^= 1;
+    c = cn;
+    cn = c2;
+    nrow0 = n2row0;
+  }
+}
+
+template <int MTR>
+int launch_mfma(const double *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0, int64_t n_points,
+                int32_t n_features, const double *rowmean, const double *scale, const double *rowscale,
+                const double *A, int32_t n_p, double *out, int64_t ldo, hipStream_t st) {
+  const int cus = spr_cached_cus();
+  SegPlan plan;
+  plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
+  // LDS: 2 x 64 x (16 MTR + 2) doubles per workgroup -> 6 / 4 / 3 / 2 / 1 / 1 workgroups per CU
+  constexpr int PER_CU = MTR <= 1 ? 6 : MTR == 2 ? 4 : MTR == 3 ? 3 : MTR == 4 ? 2 : 1;
+  plan.total_wg = PER_CU * (cus > 0 ? cus : 256);
+  plan.chunk_rows = 64;
+  const int grid = seg_total_wgs(plan);
+  const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(Ur) & 15) == 0);
+  const int lm = vec_ok ? ((r == 16 * MTR) ? 2 : 1) : 0;
+  for (int p0 = 0; p0 < n_p; p0 += RM_PB) {
+    const int npb = (n_p - p0 < RM_PB) ? n_p - p0 : RM_PB;
+#define RM(LM) hipLaunchKernelGGL((reconstruct_mfma_kernel<MTR, LM>), dim3(grid), dim3(RM_THREADS), 0, st, Ur, (int)r, ldu, plan, rowmean, scale, rowscale, A, p0, npb, out, ldo)
+    if (lm == 2) RM(2);
+    else if (lm == 1) RM(1);
+    else RM(0);
+#undef RM
+    SPR_LAUNCH_CHECK();
+  }
+  return SPR_OK;
+}
 
 constexpr int RC_THREADS = 256;
 constexpr int RC_UNR = 4;
@@ -110,6 +223,18 @@ extern "C" int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r
               SPR_E_INVALID, "spr_reconstruct_f64: bad feature layout");
   SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_reconstruct_f64: r=%d > %d not built", r, SPR_MAX_R);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!SPR_RECONSTRUCT_VALU) {
+#define RMF(MTV) return launch_mfma<MTV>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
+    switch (spr_round_mt(r)) {       // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
+      case 1: RMF(1);
+      case 2: RMF(2);
+      case 3: RMF(3);
+      case 4: RMF(4);
+      case 6: RMF(6);
+      default: RMF(8);
+    }
+#undef RMF
+  }
   const int half = (r + 1) / 2;
 #define RC(L) return launch<L>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
   if (half <= 1) RC(1);

@@ -421,3 +421,61 @@ def test_properties_at_scale(eng):
     spr.optimal_placement()
     np.testing.assert_array_equal(p1, spr.sensors_)
     assert len(set(p1.tolist())) == r and spr.pivot_gap_.min() > 1e-9
+
+
+def test_properties_at_config3_scale(eng):
+    """BASELINE config 3 at FULL size (10M cells x 9 features x 256 snapshots = 184 GB, 64 modes), generated on the
+    device: orthonormal basis, energy identity, best-rank-r residual of a reconstructed training column, sensors
+    distinct / reproducible and equal to the oracle's dgeqp3 pivots on the rows both can hold -- all checked in
+    10M-row slices (torch only as the checker)."""
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    from openmeasure_amd.synth import make_R
+    t = eng.torch
+    t.cuda.empty_cache()
+    free, _ = t.cuda.mem_get_info()
+    if free < 250e9:
+        pytest.skip(f'needs 250 GB of free HBM, {free / 1e9:.0f} GB available')
+    n_points, F, m, r = 10_000_000, 9, 256, 64
+    n = n_points * F
+    R = eng.to_device(make_R(m, r, seed=1234))
+    Xd = eng.synth(n, m, 0, n_points, R, 1e-3, 1234)
+    spr = SPR(DeviceMatrix(Xd), F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    Ur, mu, inv = spr._d['Ur'], spr._d['rowmean'], spr._d['inv_scale']
+    step = 5_000_000
+    gram_u = t.zeros((r, r), dtype=t.float64, device=Ur.device)
+    energy = 0.0
+    for i0 in range(0, n, step):
+        u = Ur[i0:i0 + step]
+        gram_u += u.T @ u
+        f = i0 // n_points
+        assert (i0 + step - 1) // n_points == f                         # slices never straddle a feature here
+        x0 = (Xd[i0:i0 + step] - mu[i0:i0 + step, None]) * inv[f]
+        energy += float((x0 * x0).sum())
+        del x0
+    assert np.abs(eng.to_host(gram_u) - np.eye(r)).max() < 1e-9
+    assert abs(energy - float(np.sum(spr.S_ ** 2))) <= 1e-10 * energy
+    assert spr.S_[0] / spr.S_[r - 1] < 1e4
+    rec = spr.reconstruct(spr.Ar[:1], to_host=False)                    # (1, n): training column 0
+    tail = np.sqrt(np.sum(spr.S_[r:] ** 2))
+    err2 = 0.0
+    for i0 in range(0, n, step):
+        f = i0 // n_points
+        d = (rec[0, i0:i0 + step] - Xd[i0:i0 + step, 0]) * inv[f]
+        err2 += float((d * d).sum())
+    assert np.sqrt(err2) <= 1.05 * tail
+    spr.optimal_placement()
+    p1 = spr.sensors_.copy()
+    spr.optimal_placement()
+    np.testing.assert_array_equal(p1, spr.sensors_)
+    assert len(set(p1.tolist())) == r and spr.pivot_gap_.min() > 1e-9
+    # the oracle can pivot a slab of the basis: the device picks restricted to that slab must agree with dgeqp3 on it
+    slab = slice(0, 2_000_000)
+    sub = SPR(np.zeros((2_000_000, r + 2)), 1, None, engine=eng)
+    Uh = eng.to_host(Ur[slab])
+    sub.fit(basis=(Uh, np.eye(r + 2, r)))
+    sub.optimal_placement()
+    want, _ = orc.qr_pivots(Uh)
+    np.testing.assert_array_equal(sub.sensors_, want)
+    del Xd, spr, sub, rec
+    t.cuda.empty_cache()

@@ -243,6 +243,7 @@ def main():
         }
         if extra:
             out['extra'] = extra
+        out['peak_hbm_GB'] = round(torch.cuda.max_memory_allocated() / 1e9, 2)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

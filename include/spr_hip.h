@@ -272,6 +272,66 @@ int spr_synth_gather_f64(const int64_t *d_rows, int32_t n, int64_t n_points, int
                          const double *d_R, int32_t k, int32_t ldr, double eps,
                          uint64_t seed, double *d_out, void *stream);
 
+/* ---- f32 STORAGE (BASELINE config 5: 50M cells x 16 features x 512 snapshots does not fit 8 x 288 GB in f64) ----
+ * The reference keeps X in whatever float dtype the caller passes (sparse_sensing.py:74) and its U then has that
+ * dtype too (np.linalg.svd :272).  These entry points take the snapshot shard (suffix _x32) or the basis (suffix
+ * _u32) as float, widen every element on load and do ALL arithmetic in f64 exactly like their _f64 twins -- same
+ * arguments, same outputs (row means, statistics, Gram blocks, norms, Theta, fields stay double); only
+ * spr_project_x32 writes float, the f64 result rounded once.  Two-element pieces: rows 8-byte aligned and an even
+ * m / ld take the vector path.  Parity is therefore defined on the stored values: bit-exact sensors against the
+ * oracle run on the same f32-rounded basis widened to f64. */
+int spr_stats_gram_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                       int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
+                       void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_rowstats_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                     int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
+                     void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_gram_cross_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                       int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                       double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_project_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                    int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                    const double *d_rowmean, const double *d_W, int32_t r, float *d_Ur, int64_t ldu,
+                    int32_t accumulate, void *stream);
+/* f32 shard, f64 result: for the column slices of a wide X (m > 256), whose partial sums cancel by up to
+ * sigma_1/sigma_r between the slices -- accumulate them in an f64 block of rows, round to f32 once afterwards */
+int spr_project_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                           int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                           const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                           int32_t accumulate, void *stream);
+int spr_scale_rows_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                       int64_t n_points, int32_t n_features, const double *d_rowmean,
+                       const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream);
+int spr_feature_minmax_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                           int64_t n_points, int32_t n_features, double *d_minmax,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_colsums_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                    int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_feature_digit_hist_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, const uint64_t *d_prefix, int32_t shift,
+                               int32_t bits, int32_t two_targets, uint64_t *d_hist, void *stream);
+int spr_synth_f32(float *d_X, int64_t n_rows, int32_t ncols, int64_t ldx, int64_t row0,
+                  int64_t n_points, int32_t col0, const double *d_R, int32_t k, int32_t ldr,
+                  double eps, uint64_t seed, void *stream);
+int spr_reconstruct_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                        int64_t n_points, int32_t n_features, const double *d_rowmean,
+                        const double *d_scale, const double *d_rowscale, const double *d_A, int32_t n_p,
+                        double *d_Xrec, int64_t ldo, void *stream);
+int spr_mask_rows_u32(float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                      const uint8_t *d_mask, void *stream);
+int spr_qr_init_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                    int64_t row0, double *d_nrm, double *d_rec, double *d_tau,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_refresh_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                       const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq,
+                       double *d_nrm, double *d_rec, double *d_tau,
+                       void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_measure_csr_u32(const int64_t *d_indptr, const int64_t *d_indices, const double *d_vals,
+                        int32_t s, const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                        int64_t row0, const double *d_rowmean, const double *d_scale, int64_t n_points,
+                        int32_t n_features, double *d_Theta, double *d_cnt, double *d_scl, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,18 @@ class SprError(RuntimeError):
     """A libspr_hip.so call returned a negative status."""
 
 
+# f32-storage twins: identical argument lists (the typed pointer is a void* here)
+for _f64, _x32 in (('spr_stats_gram_f64', 'spr_stats_gram_x32'), ('spr_rowstats_f64', 'spr_rowstats_x32'),
+                   ('spr_gram_cross_f64', 'spr_gram_cross_x32'), ('spr_project_f64', 'spr_project_x32'),
+                   ('spr_project_f64', 'spr_project_x32_f64out'),
+                   ('spr_scale_rows_f64', 'spr_scale_rows_x32'), ('spr_feature_minmax_f64', 'spr_feature_minmax_x32'),
+                   ('spr_colsums_f64', 'spr_colsums_x32'), ('spr_feature_digit_hist_f64', 'spr_feature_digit_hist_x32'),
+                   ('spr_synth_f64', 'spr_synth_f32'), ('spr_reconstruct_f64', 'spr_reconstruct_u32'),
+                   ('spr_mask_rows_f64', 'spr_mask_rows_u32'), ('spr_qr_init_f64', 'spr_qr_init_u32'),
+                   ('spr_qr_refresh_f64', 'spr_qr_refresh_u32'), ('spr_measure_csr_f64', 'spr_measure_csr_u32')):
+    PROTOTYPES[_x32] = PROTOTYPES[_f64]
+
+
 def load():
     """Load (once) and return the ctypes handle; raise loudly if it cannot be done."""
     global _lib

@@ -23,7 +23,8 @@ __device__ inline void chan_merge_w(double &n, double &mu, double &m2, double nb
 }
 
 // ---- row means + per-feature statistics of full rows (any m) --------------------------------
-__global__ __launch_bounds__(256) void rowstats_kernel(const double *__restrict__ X, int64_t ldx, int m, int vec_ok,
+template <typename TX>
+__global__ __launch_bounds__(256) void rowstats_kernel(const TX *__restrict__ X, int64_t ldx, int m, int vec_ok,
                                                        SegPlan plan, double *__restrict__ rowmean,
                                                        double *__restrict__ stat_part) {
   int f, wl, wpf, base;
@@ -34,15 +35,15 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const double *__restrict_
   RowStats st;
   st.init();
   for (int64_t row = lo + (int64_t)wl * 4 + wave; row < hi; row += (int64_t)wpf * 4) {
-    const double *rp = X + row * ldx;
+    const TX *rp = X + row * ldx;
     double s = 0.0;
     if (vec_ok) {
       for (int c = 2 * lane; c < m; c += 128) {
-        const f64x2 t = *reinterpret_cast<const f64x2 *>(rp + c);
+        const f64x2 t = widen(*reinterpret_cast<const typename PieceOf<TX>::type *>(rp + c));
         s += t.x + t.y;
       }
     } else {
-      for (int c = lane; c < m; c += 64) s += rp[c];
+      for (int c = lane; c < m; c += 64) s += (double)rp[c];
     }
     s = group_sum_t<64>(s);
     const double mean = s * inv_m;
@@ -82,15 +83,15 @@ constexpr int CW = 8;        // waves
 constexpr int CR = 16;       // panel rows
 constexpr int CMA = 256;     // width of A
 
-template <int NTJ, int VEC>
-__global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const double *__restrict__ X, int64_t ldx, int m,
+template <int NTJ, int VEC, typename TX>
+__global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restrict__ X, int64_t ldx, int m,
                                                             int center, SegPlan plan,
                                                             const double *__restrict__ rowmean,
                                                             double *__restrict__ slab) {
   constexpr int MTF = 16 + NTJ;                 // padded full width in tiles
   constexpr int MP = 16 * MTF + ((MTF % 2 == 0) ? 16 : 0);
   constexpr int KSTEPS = CR / 4;
-  using RT = RowTile<MTF, CR, MP, CW, 32>;
+  using RT = RowTile<MTF, CR, MP, CW, 32, TX>;
   __shared__ double lds[2][CR * MP];
 
   const int og = blockIdx.x & 1;
@@ -188,8 +189,8 @@ int plan_wgs(SegPlan &plan, int64_t n_rows, int64_t row0, int64_t n_points, int3
   return seg_total_wgs(plan);
 }
 
-template <int NTJ>
-int launch_cross(const double *X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
+template <int NTJ, typename TX>
+int launch_cross(const TX *X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
                  int32_t n_features, int center, const double *rowmean, double *gram, void *ws, size_t ws_bytes,
                  hipStream_t st) {
   SegPlan plan;
@@ -200,13 +201,13 @@ int launch_cross(const double *X, int64_t n_rows, int m, int64_t ldx, int64_t ro
   (void)pairs;
   const size_t need = (size_t)npairs * 16 * NTJ * 256 * sizeof(double);
   SPR_REQUIRE(ws_bytes >= need, SPR_E_WORKSPACE, "spr_gram_cross_f64: workspace %zu < %zu", ws_bytes, need);
-  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
   double *slab = static_cast<double *>(ws);
   if (vec_ok)
-    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 1>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
+    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 1, TX>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
                        rowmean, slab);
   else
-    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 0>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
+    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 0, TX>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
                        rowmean, slab);
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_cross_finalize_kernel<NTJ>, dim3(16 * NTJ, n_features), dim3(256), 0, st, slab, m, plan, gram);
@@ -221,26 +222,40 @@ extern "C" size_t spr_rowstats_workspace(int32_t n_features) {
   return sizeof(double) * 3 * 4 * ((size_t)8 * (cus > 0 ? cus : 256) + (size_t)n_features);
 }
 
-extern "C" int spr_rowstats_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                                int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
-                                void *d_workspace, size_t workspace_bytes, void *stream) {
-  SPR_REQUIRE(d_X && d_rowmean && d_fstats && d_workspace, SPR_E_INVALID, "spr_rowstats_f64: NULL pointer");
+template <typename TX>
+static int rowstats_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                          int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
+                          void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_fstats && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
-              SPR_E_INVALID, "spr_rowstats_f64: bad shape");
-  SPR_REQUIRE(workspace_bytes >= spr_rowstats_workspace(n_features), SPR_E_WORKSPACE,
-              "spr_rowstats_f64: workspace too small");
+              SPR_E_INVALID, "%s: bad shape", who);
+  SPR_REQUIRE(workspace_bytes >= spr_rowstats_workspace(n_features), SPR_E_WORKSPACE, "%s: workspace too small", who);
   SegPlan plan;
   const int grid = plan_wgs(plan, n_rows, row0, n_points, n_features, 4, 8);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
-  hipLaunchKernelGGL(rowstats_kernel, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, vec_ok, plan, d_rowmean,
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & (2 * sizeof(TX) - 1)) == 0);
+  hipLaunchKernelGGL(rowstats_kernel<TX>, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, vec_ok, plan, d_rowmean,
                      static_cast<double *>(d_workspace));
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(rowstats_finalize_kernel, dim3(n_features), dim3(64), 0, st,
                      static_cast<const double *>(d_workspace), plan, d_fstats);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
+}
+
+extern "C" int spr_rowstats_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
+                                void *d_workspace, size_t workspace_bytes, void *stream) {
+  return rowstats_entry("spr_rowstats_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, d_rowmean, d_fstats,
+                        d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int spr_rowstats_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
+                                void *d_workspace, size_t workspace_bytes, void *stream) {
+  return rowstats_entry("spr_rowstats_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, d_rowmean, d_fstats,
+                        d_workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t spr_gram_cross_workspace(int32_t m, int32_t n_features) {
@@ -250,21 +265,36 @@ extern "C" size_t spr_gram_cross_workspace(int32_t m, int32_t n_features) {
   return pairs * 16 * (size_t)(ntj > 0 ? ((ntj + 3) / 4) * 4 : 4) * 256 * sizeof(double);
 }
 
-extern "C" int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                                  int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
-                                  double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
-  SPR_REQUIRE(d_X && d_rowmean && d_gram && d_workspace, SPR_E_INVALID, "spr_gram_cross_f64: NULL pointer");
+template <typename TX>
+static int gram_cross_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                            int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                            double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_gram && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > CMA && m <= 512 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
-              SPR_E_INVALID, "spr_gram_cross_f64: bad shape (m must be in (256, 512])");
-  SPR_REQUIRE(center == 0 || center == 2, SPR_E_INVALID, "spr_gram_cross_f64: centre mode must be 0 or 2 (external means)");
+              SPR_E_INVALID, "%s: bad shape (m must be in (256, 512])", who);
+  SPR_REQUIRE(center == 0 || center == 2, SPR_E_INVALID, "%s: centre mode must be 0 or 2 (external means)", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntj = (m - CMA + 15) / 16;
-#define GX(N) return launch_cross<N>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_gram, \
-                                     d_workspace, workspace_bytes, st)
+#define GX(N) return launch_cross<N, TX>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_gram, \
+                                         d_workspace, workspace_bytes, st)
   if (ntj <= 4) GX(4);
   if (ntj <= 8) GX(8);
   if (ntj <= 12) GX(12);
   GX(16);
 #undef GX
+}
+
+extern "C" int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                                  double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
+  return gram_cross_entry("spr_gram_cross_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean,
+                          d_gram, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int spr_gram_cross_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                                  double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
+  return gram_cross_entry("spr_gram_cross_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean,
+                          d_gram, d_workspace, workspace_bytes, stream);
 }

@@ -13,9 +13,10 @@ namespace {
 constexpr int MS_THREADS = 256;
 constexpr int MS_WAVES = MS_THREADS / 64;
 
+template <typename TU>
 __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
     const int64_t *__restrict__ indptr, const int64_t *__restrict__ indices, const double *__restrict__ vals,
-    const double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
+    const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
     const double *__restrict__ rowmean, const double *__restrict__ scale, int64_t n_points, int n_features,
     double *__restrict__ Theta, double *__restrict__ cnt, double *__restrict__ scl) {
   __shared__ double part[MS_WAVES][SPR_MAX_R + 2];
@@ -27,9 +28,9 @@ __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
     const int64_t col = indices[e] - row0;
     if (col < 0 || col >= n_rows) continue;
     const double v = vals[e];
-    const double *u = Ur + col * ldu;
-    if (lane < r) a0 += v * u[lane];
-    if (lane + 64 < r) a1 += v * u[lane + 64];
+    const TU *u = Ur + col * ldu;
+    if (lane < r) a0 += v * (double)u[lane];
+    if (lane + 64 < r) a1 += v * (double)u[lane + 64];
     if (lane == 0) {
       ac += v * rowmean[col];
       if (scl) {                                   // X_scl of that row = scale of its feature (:110, :115)
@@ -54,21 +55,39 @@ __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
 
 }  // namespace
 
+template <typename TU>
+static int measure_entry(const char *who, const int64_t *d_indptr, const int64_t *d_indices, const double *d_vals,
+                         int32_t s, const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                         const double *d_rowmean, const double *d_scale, int64_t n_points, int32_t n_features,
+                         double *d_Theta, double *d_cnt, double *d_scl, void *stream) {
+  SPR_REQUIRE(d_indptr && d_indices && d_vals && d_Ur && d_rowmean && d_Theta && d_cnt, SPR_E_INVALID,
+              "%s: NULL pointer", who);
+  SPR_REQUIRE(s > 0 && n_rows > 0 && r > 0 && ldu >= r && row0 >= 0, SPR_E_INVALID,
+              "%s: bad shape s=%d n_rows=%lld r=%d", who, s, (long long)n_rows, r);
+  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "%s: r=%d > %d not built", who, r, SPR_MAX_R);
+  SPR_REQUIRE(!d_scl || (d_scale && n_points > 0 && n_features > 0), SPR_E_INVALID,
+              "%s: scl output needs the per-feature scale and layout", who);
+  hipLaunchKernelGGL(measure_csr_kernel<TU>, dim3(s), dim3(MS_THREADS), 0, static_cast<hipStream_t>(stream), d_indptr,
+                     d_indices, d_vals, d_Ur, n_rows, (int)r, ldu, row0, d_rowmean, d_scale, n_points, (int)n_features,
+                     d_Theta, d_cnt, d_scl);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
 extern "C" int spr_measure_csr_f64(const int64_t *d_indptr, const int64_t *d_indices, const double *d_vals,
                                    int32_t s, const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
                                    int64_t row0, const double *d_rowmean, const double *d_scale, int64_t n_points,
                                    int32_t n_features, double *d_Theta, double *d_cnt, double *d_scl,
                                    void *stream) {
-  SPR_REQUIRE(d_indptr && d_indices && d_vals && d_Ur && d_rowmean && d_Theta && d_cnt, SPR_E_INVALID,
-              "spr_measure_csr_f64: NULL pointer");
-  SPR_REQUIRE(s > 0 && n_rows > 0 && r > 0 && ldu >= r && row0 >= 0, SPR_E_INVALID,
-              "spr_measure_csr_f64: bad shape s=%d n_rows=%lld r=%d", s, (long long)n_rows, r);
-  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_measure_csr_f64: r=%d > %d not built", r, SPR_MAX_R);
-  SPR_REQUIRE(!d_scl || (d_scale && n_points > 0 && n_features > 0), SPR_E_INVALID,
-              "spr_measure_csr_f64: scl output needs the per-feature scale and layout");
-  hipLaunchKernelGGL(measure_csr_kernel, dim3(s), dim3(MS_THREADS), 0, static_cast<hipStream_t>(stream), d_indptr,
-                     d_indices, d_vals, d_Ur, n_rows, (int)r, ldu, row0, d_rowmean, d_scale, n_points, (int)n_features,
-                     d_Theta, d_cnt, d_scl);
-  SPR_LAUNCH_CHECK();
-  return SPR_OK;
+  return measure_entry("spr_measure_csr_f64", d_indptr, d_indices, d_vals, s, d_Ur, n_rows, r, ldu, row0, d_rowmean,
+                       d_scale, n_points, n_features, d_Theta, d_cnt, d_scl, stream);
+}
+
+extern "C" int spr_measure_csr_u32(const int64_t *d_indptr, const int64_t *d_indices, const double *d_vals,
+                                   int32_t s, const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
+                                   int64_t row0, const double *d_rowmean, const double *d_scale, int64_t n_points,
+                                   int32_t n_features, double *d_Theta, double *d_cnt, double *d_scl,
+                                   void *stream) {
+  return measure_entry("spr_measure_csr_u32", d_indptr, d_indices, d_vals, s, d_Ur, n_rows, r, ldu, row0, d_rowmean,
+                       d_scale, n_points, n_features, d_Theta, d_cnt, d_scl, stream);
 }

@@ -39,16 +39,18 @@ constexpr int NW = 8;
 
 template <int MT> struct ProjRows { static constexpr int R = (MT >= 12) ? 32 : 64; };
 
-template <int MT, int RTILES, int VEC>
+// TX: storage type of the snapshot shard, TU: storage type of the basis (f64, or f32 rounded from the f64 result --
+// the reference's own U has the dtype of its X); the arithmetic is f64 either way.
+template <int MT, int RTILES, int VEC, typename TX, typename TU>
 __global__ __launch_bounds__(NW * 64) void project_kernel(
-    const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
+    const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     const double *__restrict__ inv_scale, const double *__restrict__ rowmean, const double *__restrict__ W, int r,
-    double *__restrict__ Ur, int64_t ldu, int accumulate) {
+    TU *__restrict__ Ur, int64_t ldu, int accumulate) {
   constexpr int R = ProjRows<MT>::R;
   constexpr int MPAD = 16 * MT, MP = MPAD + PROJ_PAD;
   constexpr int KSTEPS = MPAD / 4;
   constexpr int CG = RTILES, RG = NW / CG, RB = R / 16;
-  using RT = RowTile<MT, R, MP, NW>;
+  using RT = RowTile<MT, R, MP, NW, 16, TX>;
 
   __shared__ double lds[2][R * MP];
 
@@ -147,15 +149,15 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
           if (PROJ_ABLATE == 3) asm volatile("" ::"v"(s0), "v"(s1), "v"(s2), "v"(s3));
           if (PROJ_ABLATE != 3) {
             if (FULLP && !accumulate) {                        // no predicates: one basic block per panel
-              Ur[row * ldu + col] = s0;
-              Ur[(row + 4) * ldu + col] = s1;
-              Ur[(row + 8) * ldu + col] = s2;
-              Ur[(row + 12) * ldu + col] = s3;
+              Ur[row * ldu + col] = (TU)s0;
+              Ur[(row + 4) * ldu + col] = (TU)s1;
+              Ur[(row + 8) * ldu + col] = (TU)s2;
+              Ur[(row + 12) * ldu + col] = (TU)s3;
             } else if (col < r) {                              // accumulate: second column slice of a wide X
-              if (row < hi) Ur[row * ldu + col] = (accumulate ? Ur[row * ldu + col] : 0.0) + s0;
-              if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (accumulate ? Ur[(row + 4) * ldu + col] : 0.0) + s1;
-              if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (accumulate ? Ur[(row + 8) * ldu + col] : 0.0) + s2;
-              if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (accumulate ? Ur[(row + 12) * ldu + col] : 0.0) + s3;
+              if (row < hi) Ur[row * ldu + col] = (TU)((accumulate ? (double)Ur[row * ldu + col] : 0.0) + s0);
+              if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (TU)((accumulate ? (double)Ur[(row + 4) * ldu + col] : 0.0) + s1);
+              if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (TU)((accumulate ? (double)Ur[(row + 8) * ldu + col] : 0.0) + s2);
+              if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (TU)((accumulate ? (double)Ur[(row + 12) * ldu + col] : 0.0) + s3);
             }
           }
         }
@@ -175,14 +177,14 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
   }
 }
 
-template <int MT, int RTILES>
-int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
+template <int MT, int RTILES, typename TX, typename TU>
+int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
            int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
-           double *Ur, int64_t ldu, int accumulate, hipStream_t st) {
+           TU *Ur, int64_t ldu, int accumulate, hipStream_t st) {
   static int total_wg = 0;
   if (!total_wg) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES, 2>, NW * 64, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES, 2, TX, TU>, NW * 64, 0) !=
             hipSuccess || per_cu < 1)
       per_cu = 1;
     if (per_cu > 4) per_cu = 4;
@@ -193,10 +195,10 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
   plan.total_wg = total_wg; plan.chunk_rows = ProjRows<MT>::R;
   const int grid = seg_total_wgs(plan);
-  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
   const int lm = vec_ok ? ((m == 16 * MT) ? 2 : 1) : 0;
 #define PJ_LAUNCH(LM)                                                                                         \
-  hipLaunchKernelGGL((project_kernel<MT, RTILES, LM>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center, \
+  hipLaunchKernelGGL((project_kernel<MT, RTILES, LM, TX, TU>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center, \
                      plan, inv_scale, rowmean, W, (int)r, Ur, ldu, accumulate)
   if (lm == 2) PJ_LAUNCH(2);
   else if (lm == 1) PJ_LAUNCH(1);
@@ -206,40 +208,42 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   return SPR_OK;
 }
 
-template <int MT>
-int launch_rt(int rt, const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
+template <int MT, typename TX, typename TU>
+int launch_rt(int rt, const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
               int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
-              double *Ur, int64_t ldu, int accumulate, hipStream_t st) {
+              TU *Ur, int64_t ldu, int accumulate, hipStream_t st) {
   switch (rt) {
-    case 1: return launch<MT, 1>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
-    case 2: return launch<MT, 2>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
-    case 4: return launch<MT, 4>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
-    case 8: return launch<MT, 8>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 1: return launch<MT, 1, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 2: return launch<MT, 2, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 4: return launch<MT, 4, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 8: return launch<MT, 8, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
   }
   spr_set_error("spr_project_f64: r tile count %d not built", rt);
   return SPR_E_UNSUPPORTED;
 }
 
-}  // namespace
-
-extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                               int64_t n_points, int32_t n_features, int32_t center,
-                               const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
-                               double *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
-  SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && (d_rowmean || !center), SPR_E_INVALID,
-              "spr_project_f64: NULL pointer");
-  if (!center) d_rowmean = d_X;   // read (clamped, in range) but multiplied by a zero column sum
-  SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "spr_project_f64: bad shape");
-  SPR_REQUIRE(r > 0 && ldu >= r, SPR_E_INVALID, "spr_project_f64: bad r=%d (m=%d ldu=%lld)", r, m,
-              (long long)ldu);
+template <typename TX, typename TU>
+int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
+                  int32_t n_features, int32_t center, const double *d_inv_scale, const double *d_rowmean,
+                  const double *d_W, int32_t r, TU *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
+  SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && (d_rowmean || !center), SPR_E_INVALID, "%s: NULL pointer", who);
+  SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "%s: bad shape", who);
+  SPR_REQUIRE(r > 0 && ldu >= r, SPR_E_INVALID, "%s: bad r=%d (m=%d ldu=%lld)", who, r, m, (long long)ldu);
+  if (!center && !d_rowmean) {
+    // the kernel reads a row mean unconditionally (clamped, in range) and multiplies it by a zero column sum:
+    // any buffer of n_rows doubles will do
+    if (ldx * sizeof(TX) >= sizeof(double)) d_rowmean = reinterpret_cast<const double *>(d_X);
+    else if (ldu * sizeof(TU) >= sizeof(double)) d_rowmean = reinterpret_cast<const double *>(d_Ur);
+    SPR_REQUIRE(d_rowmean, SPR_E_INVALID, "%s: center=0 on single-column f32 data needs a row-mean buffer", who);
+  }
   SPR_REQUIRE(n_points > 0 && n_features > 0 && row0 >= 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
-              SPR_E_INVALID, "spr_project_f64: bad feature layout");
-  SPR_REQUIRE(m <= SPR_MAX_M && r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_project_f64: m=%d r=%d not built", m, r);
+              SPR_E_INVALID, "%s: bad feature layout", who);
+  SPR_REQUIRE(m <= SPR_MAX_M && r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "%s: m=%d r=%d not built", who, m, r);
   const int need = (r + 15) / 16;
   const int rt = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define PJ(MTV) return launch_rt<MTV>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, st)
+#define PJ(MTV) return launch_rt<MTV, TX, TU>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, st)
   switch (spr_round_mt(m)) {
     case 1: PJ(1);
     case 2: PJ(2);
@@ -251,6 +255,34 @@ extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int
     case 16: PJ(16);
   }
 #undef PJ
-  spr_set_error("spr_project_f64: m=%d not built", m);
+  spr_set_error("%s: m=%d not built", who, m);
   return SPR_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, int32_t center,
+                               const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
+                               double *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
+  return project_entry("spr_project_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                       d_rowmean, d_W, r, d_Ur, ldu, accumulate, stream);
+}
+
+extern "C" int spr_project_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, int32_t center,
+                               const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
+                               float *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
+  return project_entry("spr_project_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                       d_rowmean, d_W, r, d_Ur, ldu, accumulate, stream);
+}
+
+// f32 shard, f64 result: the partial sums of a wide X (m > 256, two column slices) cancel by up to sigma_1/sigma_r
+// between the slices, so they are accumulated in an f64 scratch block and rounded to f32 once by the caller
+extern "C" int spr_project_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                      int64_t n_points, int32_t n_features, int32_t center,
+                                      const double *d_inv_scale, const double *d_rowmean, const double *d_W,
+                                      int32_t r, double *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
+  return project_entry("spr_project_x32_f64out", d_X, n_rows, m, ldx, row0, n_points, n_features, center,
+                       d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, stream);
 }

@@ -64,14 +64,16 @@ __device__ inline double downdate(double v, f64x2 u, const double (&q0)[NQ], con
   return v;
 }
 
-__device__ inline f64x2 load_row_piece(const double *__restrict__ rp, int k0, int r, bool vec_ok, bool valid) {
+// TU: storage type of the basis (f64, or f32 widened on load); every norm and dot product is f64
+template <typename TU>
+__device__ inline f64x2 load_row_piece(const TU *__restrict__ rp, int k0, int r, bool vec_ok, bool valid) {
   f64x2 t = {0.0, 0.0};
   if (valid) {
     if (vec_ok) {
-      if (k0 < r) t = *reinterpret_cast<const f64x2 *>(rp + k0);
+      if (k0 < r) t = widen(*reinterpret_cast<const typename PieceOf<TU>::type *>(rp + k0));
     } else {
-      if (k0 < r) t.x = rp[k0];
-      if (k0 + 1 < r) t.y = rp[k0 + 1];
+      if (k0 < r) t.x = (double)rp[k0];
+      if (k0 + 1 < r) t.y = (double)rp[k0 + 1];
     }
   }
   return t;
@@ -136,9 +138,9 @@ struct TopList {
 // Full sweep over the rank's rows.  MODE 0: nrm = |u|^2.  MODE 2: nrm <- nrm down-dated by nq
 // directions (rows already chosen keep -1).  Both: the block's QR_TOPT largest (value, global
 // row) pairs, sorted, to tops[block][QR_TOPT][2].
-template <int LPR, int MODE>
+template <int LPR, int MODE, typename TU>
 __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
-    const double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int vec_ok_i, int64_t row0,
+    const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int vec_ok_i, int64_t row0,
     const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
   constexpr int RPW = 64 / LPR;
   constexpr int ROWS_IT = (QR_THREADS / 64) * RPW * QR_UNR;
@@ -192,13 +194,13 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
 // HBM time of the panel, where the VALU form spends 8 x (fma + 5-step butterfly) per row pair.
 // The squared products are summed over the 16 direction lanes with a DPP butterfly; lanes 0/16/32/48
 // of a wave own rows a, a+4, a+8, a+12 of the block (increasing order, as TopList needs).
-template <int MTR, int VEC>
+template <int MTR, int VEC, typename TU>
 __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
-    const double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
+    const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
     const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
   constexpr int NW = QR_THREADS / 64, R = 64;
   constexpr int MPAD = 16 * MTR, MP = MPAD + 2, KSTEPS = MPAD / 4;
-  using RT = RowTile<MTR, R, MP, NW>;
+  using RT = RowTile<MTR, R, MP, NW, 16, TU>;
   constexpr int PANELS = 2 * R * MP, MERGE = 2 * QR_THREADS * QR_TOPT;
   __shared__ double smem[PANELS > MERGE ? PANELS : MERGE];    // panels during the sweep, merge lists afterwards
   double *const lds0 = smem, *const lds1 = smem + R * MP;
@@ -275,8 +277,9 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
 }
 
 // grid = sweep blocks: copy each block's top rows into the compact candidate arrays
+template <typename TU>
 __global__ __launch_bounds__(QR_THREADS) void qr_gather_kernel(
-    const double *__restrict__ tops, const double *__restrict__ Ur, int r, int64_t ldu, int64_t row0,
+    const double *__restrict__ tops, const TU *__restrict__ Ur, int r, int64_t ldu, int64_t row0,
     int64_t n_rows, int ldc, int64_t *__restrict__ cand_idx, double *__restrict__ cand_res,
     double *__restrict__ cand_U) {
   const int b = blockIdx.x;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_gather_kernel(
     const int64_t li = gi - row0;
     const bool ok = v >= 0.0 && li >= 0 && li < n_rows;     // -1 (already chosen) and -2 (empty) stay out
     const int64_t slot = (int64_t)b * QR_TOPT + k;
-    cand_U[slot * ldc + c] = (ok && c < r) ? Ur[li * ldu + c] : 0.0;
+    cand_U[slot * ldc + c] = (ok && c < r) ? (double)Ur[li * ldu + c] : 0.0;
     if (c == 0) { cand_idx[slot] = ok ? gi : -1; cand_res[slot] = ok ? v : -2.0; }
   }
 }
@@ -476,13 +479,14 @@ __global__ __launch_bounds__(QR_THREADS) void qr_exclude_kernel(double *__restri
   }
 }
 
-__global__ void mask_rows_kernel(double *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu,
+template <typename TU>
+__global__ void mask_rows_kernel(TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu,
                                  const uint8_t *__restrict__ mask) {
   const int64_t total = n_rows * r;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = e / r;
-    if (!mask[row]) Ur[row * ldu + (e - row * r)] = 0.0;
+    if (!mask[row]) Ur[row * ldu + (e - row * r)] = (TU)0;
   }
 }
 
@@ -521,10 +525,10 @@ struct QrWs {
   }
 };
 
-template <int MODE>
-int launch_sweep(int lpr, int grid, hipStream_t st, const double *Ur, int64_t n_rows, int r, int64_t ldu,
+template <int MODE, typename TU>
+int launch_sweep(int lpr, int grid, hipStream_t st, const TU *Ur, int64_t n_rows, int r, int64_t ldu,
                  int vec_ok, int64_t row0, const double *Q, int nq, double *nrm, double *tops) {
-#define SW(L) hipLaunchKernelGGL((qr_sweep_kernel<L, MODE>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, vec_ok, row0, Q, nq, nrm, tops); break
+#define SW(L) hipLaunchKernelGGL((qr_sweep_kernel<L, MODE, TU>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, vec_ok, row0, Q, nq, nrm, tops); break
   switch (lpr) {
     case 1: SW(1);
     case 2: SW(2);
@@ -539,7 +543,7 @@ int launch_sweep(int lpr, int grid, hipStream_t st, const double *Ur, int64_t n_
   return SPR_OK;
 }
 
-int check_ur(const char *who, const double *Ur, int64_t n_rows, int32_t r, int64_t ldu) {
+int check_ur(const char *who, const void *Ur, int64_t n_rows, int32_t r, int64_t ldu) {
   SPR_REQUIRE(Ur != nullptr, SPR_E_INVALID, "%s: Ur is NULL", who);
   SPR_REQUIRE(n_rows > 0 && r > 0 && ldu >= r, SPR_E_INVALID, "%s: bad shape n_rows=%lld r=%d ldu=%lld", who,
               (long long)n_rows, r, (long long)ldu);
@@ -548,10 +552,11 @@ int check_ur(const char *who, const double *Ur, int64_t n_rows, int32_t r, int64
 }
 
 // candidates from the last sweep's block tops + this rank's record and tau
-int build_candidates(const QrWs &w, int grid, const double *Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
+template <typename TU>
+int build_candidates(const QrWs &w, int grid, const TU *Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
                      double *rec, double *tau_out, hipStream_t st) {
   const int ldc = r + (r & 1);
-  hipLaunchKernelGGL(qr_gather_kernel, dim3(grid), dim3(QR_THREADS), 0, st, w.tops, Ur, r, ldu, row0, n_rows, ldc,
+  hipLaunchKernelGGL(qr_gather_kernel<TU>, dim3(grid), dim3(QR_THREADS), 0, st, w.tops, Ur, r, ldu, row0, n_rows, ldc,
                      w.cand_idx, w.cand_res, w.cand_U);
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, w.tops, grid, w.cand_idx, w.cand_res,
@@ -569,34 +574,60 @@ extern "C" size_t spr_qr_workspace(int64_t n_rows) {
 
 extern "C" int32_t spr_qr_batch(void) { return QR_BATCH; }
 
-extern "C" int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, const uint8_t *d_mask,
-                                 void *stream) {
-  int rc = check_ur("spr_mask_rows_f64", d_Ur, n_rows, r, ldu);
+template <typename TU>
+static int mask_rows_entry(const char *who, TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, const uint8_t *d_mask,
+                           void *stream) {
+  int rc = check_ur(who, d_Ur, n_rows, r, ldu);
   if (rc != SPR_OK) return rc;
-  SPR_REQUIRE(d_mask != nullptr, SPR_E_INVALID, "spr_mask_rows_f64: mask is NULL");
+  SPR_REQUIRE(d_mask != nullptr, SPR_E_INVALID, "%s: mask is NULL", who);
   const int64_t total = n_rows * r;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(mask_rows_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_Ur,
+  hipLaunchKernelGGL(mask_rows_kernel<TU>, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_Ur,
                      n_rows, (int)r, ldu, d_mask);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
 
+extern "C" int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, const uint8_t *d_mask,
+                                 void *stream) {
+  return mask_rows_entry("spr_mask_rows_f64", d_Ur, n_rows, r, ldu, d_mask, stream);
+}
+
+extern "C" int spr_mask_rows_u32(float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, const uint8_t *d_mask,
+                                 void *stream) {
+  return mask_rows_entry("spr_mask_rows_u32", d_Ur, n_rows, r, ldu, d_mask, stream);
+}
+
+template <typename TU>
+static int qr_init_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                         double *d_nrm, double *d_rec, double *d_tau, void *d_workspace, size_t workspace_bytes,
+                         void *stream) {
+  int rc = check_ur(who, d_Ur, n_rows, r, ldu);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "%s: workspace too small", who);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
+  const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
+  QrWs w(d_workspace);
+  rc = launch_sweep<0, TU>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, 0, d_nrm, w.tops);
+  if (rc != SPR_OK) return rc;
+  return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
+}
+
 extern "C" int spr_qr_init_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
                                double *d_nrm, double *d_rec, double *d_tau, void *d_workspace,
                                size_t workspace_bytes, void *stream) {
-  int rc = check_ur("spr_qr_init_f64", d_Ur, n_rows, r, ldu);
-  if (rc != SPR_OK) return rc;
-  SPR_REQUIRE(d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "spr_qr_init_f64: NULL pointer");
-  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "spr_qr_init_f64: workspace too small");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
-  const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & 15) == 0);
-  QrWs w(d_workspace);
-  rc = launch_sweep<0>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, 0, d_nrm, w.tops);
-  if (rc != SPR_OK) return rc;
-  return build_candidates(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
+  return qr_init_entry("spr_qr_init_f64", d_Ur, n_rows, r, ldu, row0, d_nrm, d_rec, d_tau, d_workspace, workspace_bytes,
+                       stream);
+}
+
+extern "C" int spr_qr_init_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                               double *d_nrm, double *d_rec, double *d_tau, void *d_workspace,
+                               size_t workspace_bytes, void *stream) {
+  return qr_init_entry("spr_qr_init_u32", d_Ur, n_rows, r, ldu, row0, d_nrm, d_rec, d_tau, d_workspace, workspace_bytes,
+                       stream);
 }
 
 extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_recs, int32_t n_rec,
@@ -655,19 +686,18 @@ extern "C" int spr_qr_exclude_f64(double *d_nrm, int64_t n_rows, int64_t row0, i
   return SPR_OK;
 }
 
-extern "C" int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
-                                  const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq, double *d_nrm,
-                                  double *d_rec, double *d_tau, void *d_workspace, size_t workspace_bytes,
-                                  void *stream) {
-  int rc = check_ur("spr_qr_refresh_f64", d_Ur, n_rows, r, ldu);
+template <typename TU>
+static int qr_refresh_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                            const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq, double *d_nrm,
+                            double *d_rec, double *d_tau, void *d_workspace, size_t workspace_bytes, void *stream) {
+  int rc = check_ur(who, d_Ur, n_rows, r, ldu);
   if (rc != SPR_OK) return rc;
-  SPR_REQUIRE(d_Q && d_piv && d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "spr_qr_refresh_f64: NULL pointer");
-  SPR_REQUIRE(j0 >= 0 && nq >= 1 && nq <= QR_BATCH && j0 + nq <= r, SPR_E_INVALID,
-              "spr_qr_refresh_f64: bad j0=%d nq=%d", j0, nq);
-  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "spr_qr_refresh_f64: workspace too small");
+  SPR_REQUIRE(d_Q && d_piv && d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
+  SPR_REQUIRE(j0 >= 0 && nq >= 1 && nq <= QR_BATCH && j0 + nq <= r, SPR_E_INVALID, "%s: bad j0=%d nq=%d", who, j0, nq);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
-  const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & 15) == 0);
+  const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
   QrWs w(d_workspace);
   hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + j0, (int)nq, row0, n_rows, d_nrm);
   SPR_LAUNCH_CHECK();
@@ -675,7 +705,7 @@ extern "C" int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r,
     const double *Qj = d_Q + (int64_t)j0 * r;
     const int mtr = spr_round_mt(r);      // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
     const int lm = vec_ok ? ((r == 16 * mtr) ? 2 : 1) : 0;
-#define RF(MTV, LM) hipLaunchKernelGGL((qr_refresh_mfma_kernel<MTV, LM>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows, (int)r, ldu, row0, Qj, (int)nq, d_nrm, w.tops)
+#define RF(MTV, LM) hipLaunchKernelGGL((qr_refresh_mfma_kernel<MTV, LM, TU>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows, (int)r, ldu, row0, Qj, (int)nq, d_nrm, w.tops)
 #define RFV(MTV) do { if (lm == 2) RF(MTV, 2); else if (lm == 1) RF(MTV, 1); else RF(MTV, 0); } while (0)
     switch (mtr) {
       case 1: RFV(1); break;
@@ -689,5 +719,21 @@ extern "C" int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r,
 #undef RF
     SPR_LAUNCH_CHECK();
   }
-  return build_candidates(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
+  return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
+}
+
+extern "C" int spr_qr_refresh_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                  const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq, double *d_nrm,
+                                  double *d_rec, double *d_tau, void *d_workspace, size_t workspace_bytes,
+                                  void *stream) {
+  return qr_refresh_entry("spr_qr_refresh_f64", d_Ur, n_rows, r, ldu, row0, d_Q, d_piv, j0, nq, d_nrm, d_rec, d_tau,
+                          d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int spr_qr_refresh_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                  const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq, double *d_nrm,
+                                  double *d_rec, double *d_tau, void *d_workspace, size_t workspace_bytes,
+                                  void *stream) {
+  return qr_refresh_entry("spr_qr_refresh_u32", d_Ur, n_rows, r, ldu, row0, d_Q, d_piv, j0, nq, d_nrm, d_rec, d_tau,
+                          d_workspace, workspace_bytes, stream);
 }

@@ -26,14 +26,14 @@ namespace {
 constexpr int RM_THREADS = 256;
 constexpr int RM_PB = 16;   // coefficient vectors per pass (one MFMA tile of rows)
 
-template <int MTR, int VEC>
+template <int MTR, int VEC, typename TU>
 __global__ __launch_bounds__(RM_THREADS) void reconstruct_mfma_kernel(
-    const double *__restrict__ Ur, int r, int64_t ldu, SegPlan plan, const double *__restrict__ rowmean,
+    const TU *__restrict__ Ur, int r, int64_t ldu, SegPlan plan, const double *__restrict__ rowmean,
     const double *__restrict__ scale, const double *__restrict__ rowscale, const double *__restrict__ A, int np0,
     int npb, double *__restrict__ out, int64_t ldo) {
   constexpr int NW = RM_THREADS / 64, R = 64;
   constexpr int MPAD = 16 * MTR, MP = MPAD + 2, KSTEPS = MPAD / 4;
-  using RT = RowTile<MTR, R, MP, NW>;
+  using RT = RowTile<MTR, R, MP, NW, 16, TU>;
   __shared__ double smem[2 * R * MP];
   double *const lds0 = smem, *const lds1 = smem + R * MP;
   int f, wl, wpf, base;
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(RM_THREADS) void reconstruct_mfma_kernel(
   }
 }
 
-template <int MTR>
-int launch_mfma(const double *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0, int64_t n_points,
+template <int MTR, typename TU>
+int launch_mfma(const TU *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0, int64_t n_points,
                 int32_t n_features, const double *rowmean, const double *scale, const double *rowscale,
                 const double *A, int32_t n_p, double *out, int64_t ldo, hipStream_t st) {
   const int cus = spr_cached_cus();
@@ -109,11 +109,11 @@ int launch_mfma(const double *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_
   plan.total_wg = PER_CU * (cus > 0 ? cus : 256);
   plan.chunk_rows = 64;
   const int grid = seg_total_wgs(plan);
-  const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(Ur) & 15) == 0);
+  const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(Ur) & (2 * sizeof(TU) - 1)) == 0);
   const int lm = vec_ok ? ((r == 16 * MTR) ? 2 : 1) : 0;
   for (int p0 = 0; p0 < n_p; p0 += RM_PB) {
     const int npb = (n_p - p0 < RM_PB) ? n_p - p0 : RM_PB;
-#define RM(LM) hipLaunchKernelGGL((reconstruct_mfma_kernel<MTR, LM>), dim3(grid), dim3(RM_THREADS), 0, st, Ur, (int)r, ldu, plan, rowmean, scale, rowscale, A, p0, npb, out, ldo)
+#define RM(LM) hipLaunchKernelGGL((reconstruct_mfma_kernel<MTR, LM, TU>), dim3(grid), dim3(RM_THREADS), 0, st, Ur, (int)r, ldu, plan, rowmean, scale, rowscale, A, p0, npb, out, ldo)
     if (lm == 2) RM(2);
     else if (lm == 1) RM(1);
     else RM(0);
@@ -224,7 +224,7 @@ extern "C" int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r
   SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_reconstruct_f64: r=%d > %d not built", r, SPR_MAX_R);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!SPR_RECONSTRUCT_VALU) {
-#define RMF(MTV) return launch_mfma<MTV>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
+#define RMF(MTV) return launch_mfma<MTV, double>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
     switch (spr_round_mt(r)) {       // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
       case 1: RMF(1);
       case 2: RMF(2);
@@ -245,4 +245,30 @@ extern "C" int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r
   if (half <= 32) RC(32);
   RC(64);
 #undef RC
+}
+
+// basis stored as f32 (the dtype of an f32 snapshot shard's U), arithmetic and output f64
+extern "C" int spr_reconstruct_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                   int64_t n_points, int32_t n_features, const double *d_rowmean,
+                                   const double *d_scale, const double *d_rowscale, const double *d_A, int32_t n_p,
+                                   double *d_Xrec, int64_t ldo, void *stream) {
+  SPR_REQUIRE(d_Ur && d_rowmean && d_scale && d_A && d_Xrec, SPR_E_INVALID, "spr_reconstruct_u32: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && r > 0 && ldu >= r && n_p > 0 && ldo >= n_rows, SPR_E_INVALID,
+              "spr_reconstruct_u32: bad shape n_rows=%lld r=%d ldu=%lld n_p=%d ldo=%lld", (long long)n_rows, r,
+              (long long)ldu, n_p, (long long)ldo);
+  SPR_REQUIRE(n_points > 0 && n_features > 0 && row0 >= 0 &&
+                  row0 + n_rows <= n_points * (int64_t)n_features,
+              SPR_E_INVALID, "spr_reconstruct_u32: bad feature layout");
+  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_reconstruct_u32: r=%d > %d not built", r, SPR_MAX_R);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define RMF(MTV) return launch_mfma<MTV, float>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
+  switch (spr_round_mt(r)) {
+    case 1: RMF(1);
+    case 2: RMF(2);
+    case 3: RMF(3);
+    case 4: RMF(4);
+    case 6: RMF(6);
+    default: RMF(8);
+  }
+#undef RMF
 }

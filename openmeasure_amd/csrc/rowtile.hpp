@@ -17,6 +17,15 @@
 #pragma once
 #include "common.hpp"
 
+// Storage type of the streamed matrix: f64, or f32 widened to f64 when a piece is consumed (all arithmetic stays
+// f64; the raw piece is what waits in registers, so an f32 shard also halves the prefetch registers).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename TX> struct PieceOf;
+template <> struct PieceOf<double> { using type = f64x2; };
+template <> struct PieceOf<float> { using type = f32x2; };
+__device__ inline f64x2 widen(f64x2 p) { return p; }
+__device__ inline f64x2 widen(f32x2 p) { return (f64x2){(double)p.x, (double)p.y}; }
+
 // Wave-uniform "no selects needed" fast paths.  Measured: the extra branch costs more than the selects it
 // saves in the projection staging (basic-block split -> conservative waits), so it is off there.
 #ifndef ROWTILE_RAW_FAST
@@ -50,8 +59,9 @@ struct RowStats {  // running statistics of the row means seen by one lane group
 // four DPP steps (no ds_bpermute) and one wave instruction handles four rows at once.  This
 // matters because VALU work does not hide behind v_mfma_f64_16x16x4_f64 on gfx950 (measured:
 // kernel time = MFMA time + VALU time), so the centring pass is kept as short as possible.
-template <int MT, int R, int MP, int NWAVES, int LPRMAX = 16>
+template <int MT, int R, int MP, int NWAVES, int LPRMAX = 16, typename TX = double>
 struct RowTile {
+  using Piece = typename PieceOf<TX>::type;
   static constexpr int MPAD = 16 * MT;
   static constexpr int NV = MPAD / 2;                       // 16-byte pieces per padded row
   static constexpr int LPR0 = spr_pow2_divisor_le64(NV);
@@ -63,7 +73,7 @@ struct RowTile {
   static_assert(R % ROWS_PER_IT == 0, "panel rows must be a multiple of rows per pass");
   static constexpr bool WIDE_STORE = (MP % 2 == 0);   // odd stride: rows are only 8-byte aligned in LDS
 
-  f64x2 pre[IT][VPL];
+  Piece pre[IT][VPL];
   double pmean[IT];   // centre mode 2: the caller-supplied row mean of each staged row (loaded with the row)
 
   // Pass `it` (a constant after unrolling) of the panel whose first local row is crow0.
@@ -71,21 +81,21 @@ struct RowTile {
   // (no column clamp, constant offsets).  Rows >= seg_hi re-read the last valid row
   // and columns >= m re-read column 0; center_store_pass discards both.
   template <int VEC>
-  __device__ inline void load_pass(int it, const double *__restrict__ X, int64_t ldx, int m, int64_t crow0,
+  __device__ inline void load_pass(int it, const TX *__restrict__ X, int64_t ldx, int m, int64_t crow0,
                                    int64_t seg_hi, int wave, int lane, const double *__restrict__ mean_in = nullptr) {
     const int grp = lane / LPR, lig = lane % LPR;
     int64_t lrow = crow0 + it * ROWS_PER_IT + wave * RPW + grp;
     lrow = lrow < seg_hi ? lrow : seg_hi - 1;
-    const double *rp = X + lrow * ldx;
+    const TX *rp = X + lrow * ldx;
     if (mean_in) pmean[it] = mean_in[lrow];   // callers pass either nullptr at compile time or a pointer that is always valid
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int col = 2 * (lig + v * LPR);
-      f64x2 t;
+      Piece t;
       if (VEC == 2) {
-        t = *reinterpret_cast<const f64x2 *>(rp + col);               // m == MPAD: constant offsets
+        t = *reinterpret_cast<const Piece *>(rp + col);               // m == MPAD: constant offsets
       } else if (VEC == 1) {
-        t = *reinterpret_cast<const f64x2 *>(rp + (col < m ? col : 0));
+        t = *reinterpret_cast<const Piece *>(rp + (col < m ? col : 0));
       } else {
         t.x = rp[col < m ? col : 0];
         t.y = rp[col + 1 < m ? col + 1 : 0];
@@ -97,18 +107,18 @@ struct RowTile {
   // one 16-byte piece (it, v) of a pass: lets a consumer spread the HBM requests of the next
   // panel over its whole MFMA phase instead of issuing them in one burst
   template <int VEC>
-  __device__ inline void load_piece(int it, int v, const double *__restrict__ X, int64_t ldx, int m, int64_t crow0,
+  __device__ inline void load_piece(int it, int v, const TX *__restrict__ X, int64_t ldx, int m, int64_t crow0,
                                     int64_t seg_hi, int wave, int lane) {
     const int grp = lane / LPR, lig = lane % LPR;
     int64_t lrow = crow0 + it * ROWS_PER_IT + wave * RPW + grp;
     lrow = lrow < seg_hi ? lrow : seg_hi - 1;
-    const double *rp = X + lrow * ldx;
+    const TX *rp = X + lrow * ldx;
     const int col = 2 * (lig + v * LPR);
-    f64x2 t;
+    Piece t;
     if (VEC == 2) {
-      t = *reinterpret_cast<const f64x2 *>(rp + col);
+      t = *reinterpret_cast<const Piece *>(rp + col);
     } else if (VEC == 1) {
-      t = *reinterpret_cast<const f64x2 *>(rp + (col < m ? col : 0));
+      t = *reinterpret_cast<const Piece *>(rp + (col < m ? col : 0));
     } else {
       t.x = rp[col < m ? col : 0];
       t.y = rp[col + 1 < m ? col + 1 : 0];
@@ -122,7 +132,7 @@ struct RowTile {
     const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
     const bool rv = crow0 + rloc < seg_hi;
     const int col = 2 * (lig + v * LPR);
-    f64x2 c = pre[it][v];
+    f64x2 c = widen(pre[it][v]);
     // wave-uniform fast path: whole pass inside the segment and no padded columns -> no selects
     const bool fast = ROWTILE_RAW_FAST && (crow0 + (it + 1) * ROWS_PER_IT <= seg_hi) && (m == MPAD);
     if (!fast) {
@@ -138,7 +148,7 @@ struct RowTile {
   }
 
   template <int VEC>
-  __device__ inline void load(const double *__restrict__ X, int64_t ldx, int m, int64_t crow0, int64_t seg_hi,
+  __device__ inline void load(const TX *__restrict__ X, int64_t ldx, int m, int64_t crow0, int64_t seg_hi,
                               int wave, int lane, const double *__restrict__ mean_in = nullptr) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) load_pass<VEC>(it, X, ldx, m, crow0, seg_hi, wave, lane, mean_in);
@@ -161,7 +171,7 @@ struct RowTile {
     if (fast) {
       double s = 0.0;
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) s += pre[it][v].x + pre[it][v].y;
+      for (int v = 0; v < VPL; ++v) { const f64x2 w = widen(pre[it][v]); s += w.x + w.y; }
       s = group_sum_t<LPR>(s);
       const double mean = center == 2 ? pmean[it] : (center ? s * inv_m : 0.0);
       if (WRITE_MEAN) {
@@ -171,7 +181,8 @@ struct RowTile {
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int col = 2 * (lig + v * LPR);
-        f64x2 c = {pre[it][v].x - mean, pre[it][v].y - mean};
+        const f64x2 w = widen(pre[it][v]);
+        f64x2 c = {w.x - mean, w.y - mean};
         if constexpr (WIDE_STORE) {
           *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
         } else {
@@ -185,7 +196,8 @@ struct RowTile {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int col = 2 * (lig + v * LPR);
-      s += (col < m ? pre[it][v].x : 0.0) + (col + 1 < m ? pre[it][v].y : 0.0);
+      const f64x2 w = widen(pre[it][v]);
+      s += (col < m ? w.x : 0.0) + (col + 1 < m ? w.y : 0.0);
     }
     s = group_sum_t<LPR>(s);
     const double mean = center == 2 ? pmean[it] : (center ? s * inv_m : 0.0);
@@ -196,9 +208,10 @@ struct RowTile {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int col = 2 * (lig + v * LPR);
+      const f64x2 w = widen(pre[it][v]);
       f64x2 c;
-      c.x = (rv && col < m) ? pre[it][v].x - mean : 0.0;
-      c.y = (rv && col + 1 < m) ? pre[it][v].y - mean : 0.0;
+      c.x = (rv && col < m) ? w.x - mean : 0.0;
+      c.y = (rv && col + 1 < m) ? w.y - mean : 0.0;
       if constexpr (WIDE_STORE) {
         *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
       } else {
@@ -219,7 +232,7 @@ struct RowTile {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int col = 2 * (lig + v * LPR);
-      f64x2 c = pre[it][v];
+      f64x2 c = widen(pre[it][v]);
       if (!fast) {
         c.x = (rv && col < m) ? c.x : 0.0;
         c.y = (rv && col + 1 < m) ? c.y : 0.0;

@@ -7,8 +7,9 @@
 
 namespace {
 
+template <typename TX>
 __global__ __launch_bounds__(256) void scale_rows_kernel(
-    const double *__restrict__ X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
+    const TX *__restrict__ X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
     int n_features, const double *__restrict__ rowmean, const double *__restrict__ inv_scale,
     double *__restrict__ X0, int64_t ldo) {
   // one wave per row at a time: the feature lookup is a wave-uniform division
@@ -18,7 +19,7 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(
     int64_t f = (row0 + row) / n_points;
     if (f > n_features - 1) f = n_features - 1;
     const double mu = rowmean[row], is = inv_scale[f];
-    for (int c = lane; c < m; c += 64) X0[row * ldo + c] = (X[row * ldx + c] - mu) * is;
+    for (int c = lane; c < m; c += 64) X0[row * ldo + c] = ((double)X[row * ldx + c] - mu) * is;
   }
 }
 
@@ -45,16 +46,31 @@ int grid_for(int64_t work_items, int per_block) {
 
 }  // namespace
 
-extern "C" int spr_scale_rows_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                                  int64_t n_points, int32_t n_features, const double *d_rowmean,
-                                  const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream) {
-  SPR_REQUIRE(d_X && d_rowmean && d_inv_scale && d_X0, SPR_E_INVALID, "spr_scale_rows_f64: NULL pointer");
+template <typename TX>
+static int scale_rows_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                            int64_t n_points, int32_t n_features, const double *d_rowmean, const double *d_inv_scale,
+                            double *d_X0, int64_t ldo, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_inv_scale && d_X0, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && ldo >= m && row0 >= 0 && n_points > 0 && n_features > 0,
-              SPR_E_INVALID, "spr_scale_rows_f64: bad shape");
-  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(n_rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+              SPR_E_INVALID, "%s: bad shape", who);
+  hipLaunchKernelGGL(scale_rows_kernel<TX>, dim3(grid_for(n_rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      d_X, n_rows, (int)m, ldx, row0, n_points, (int)n_features, d_rowmean, d_inv_scale, d_X0, ldo);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
+}
+
+extern "C" int spr_scale_rows_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, const double *d_rowmean,
+                                  const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream) {
+  return scale_rows_entry("spr_scale_rows_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, d_rowmean, d_inv_scale,
+                          d_X0, ldo, stream);
+}
+
+extern "C" int spr_scale_rows_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, const double *d_rowmean,
+                                  const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream) {
+  return scale_rows_entry("spr_scale_rows_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, d_rowmean, d_inv_scale,
+                          d_X0, ldo, stream);
 }
 
 extern "C" int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0, int64_t n_points,
@@ -73,7 +89,8 @@ extern "C" int spr_unscale_f64(const double *d_x0, int64_t n_rows, int64_t row0,
 // A separate streaming pass, only run for those two scalings, so the fused Gram pass stays lean.
 namespace {
 
-__global__ __launch_bounds__(256) void minmax_kernel(const double *__restrict__ X, int64_t ldx, int m, SegPlan plan,
+template <typename TX>
+__global__ __launch_bounds__(256) void minmax_kernel(const TX *__restrict__ X, int64_t ldx, int m, SegPlan plan,
                                                      double *__restrict__ part) {
   __shared__ double smin[4], smax[4];
   int f, wl, wpf, base;
@@ -82,9 +99,9 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double *__restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double mn = INFINITY, mx = -INFINITY;
   for (int64_t row = lo + (int64_t)wl * 4 + wave; row < hi; row += (int64_t)wpf * 4) {
-    const double *rp = X + row * ldx;
+    const TX *rp = X + row * ldx;
     for (int c = lane; c < m; c += 64) {
-      const double v = rp[c];
+      const double v = (double)rp[c];
       mn = v < mn ? v : mn;
       mx = v > mx ? v : mx;
     }
@@ -134,28 +151,42 @@ extern "C" size_t spr_feature_minmax_workspace(int32_t n_features) {
   return sizeof(double) * 2 * ((size_t)8 * (cus > 0 ? cus : 256) + (size_t)n_features);
 }
 
-extern "C" int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                                      int64_t n_points, int32_t n_features, double *d_minmax, void *d_workspace,
-                                      size_t workspace_bytes, void *stream) {
-  SPR_REQUIRE(d_X && d_minmax && d_workspace, SPR_E_INVALID, "spr_feature_minmax_f64: NULL pointer");
+template <typename TX>
+static int minmax_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                        int64_t n_points, int32_t n_features, double *d_minmax, void *d_workspace,
+                        size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_minmax && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
-              SPR_E_INVALID, "spr_feature_minmax_f64: bad shape");
-  SPR_REQUIRE(workspace_bytes >= spr_feature_minmax_workspace(n_features), SPR_E_WORKSPACE,
-              "spr_feature_minmax_f64: workspace too small");
+              SPR_E_INVALID, "%s: bad shape", who);
+  SPR_REQUIRE(workspace_bytes >= spr_feature_minmax_workspace(n_features), SPR_E_WORKSPACE, "%s: workspace too small", who);
   const int cus = spr_cached_cus();
   SegPlan plan;
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
   plan.total_wg = 8 * (cus > 0 ? cus : 256); plan.chunk_rows = 4;
   const int grid = seg_total_wgs(plan);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, plan,
+  hipLaunchKernelGGL(minmax_kernel<TX>, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, plan,
                      static_cast<double *>(d_workspace));
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(minmax_finalize_kernel, dim3(n_features), dim3(64), 0, st,
                      static_cast<const double *>(d_workspace), plan, d_minmax);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
+}
+
+extern "C" int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                      int64_t n_points, int32_t n_features, double *d_minmax, void *d_workspace,
+                                      size_t workspace_bytes, void *stream) {
+  return minmax_entry("spr_feature_minmax_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, d_minmax, d_workspace,
+                      workspace_bytes, stream);
+}
+
+extern "C" int spr_feature_minmax_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                      int64_t n_points, int32_t n_features, double *d_minmax, void *d_workspace,
+                                      size_t workspace_bytes, void *stream) {
+  return minmax_entry("spr_feature_minmax_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, d_minmax, d_workspace,
+                      workspace_bytes, stream);
 }
 
 // ---- axis_cnt=None support (scalar centring per feature, sparse_sensing.py:112 with axis=None) ----
@@ -166,7 +197,8 @@ extern "C" int spr_feature_minmax_f64(const double *d_X, int64_t n_rows, int32_t
 // spr_fill_feature_f64 expands a per-feature scalar to a per-row vector (the new X_cnt).
 namespace {
 
-__global__ __launch_bounds__(256) void colsums_kernel(const double *__restrict__ X, int64_t ldx, int m, SegPlan plan,
+template <typename TX>
+__global__ __launch_bounds__(256) void colsums_kernel(const TX *__restrict__ X, int64_t ldx, int m, SegPlan plan,
                                                       const double *__restrict__ rowmean, double *__restrict__ part) {
   int f, wl, wpf, base;
   int64_t lo, hi;
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(256) void colsums_kernel(const double *__restrict__
     for (int q = 0; q < 2; ++q) {
       const int c = threadIdx.x + 256 * q;
       if (c < m) {
-        const double d = X[row * ldx + c] - mu;
+        const double d = (double)X[row * ldx + c] - mu;
         z[q] += d;
         w[q] += mu * d;
       }
@@ -228,28 +260,42 @@ extern "C" size_t spr_colsums_workspace(int32_t m, int32_t n_features) {
   return sizeof(double) * 2 * (size_t)(m > 0 ? m : 1) * ((size_t)4 * (cus > 0 ? cus : 256) + (size_t)n_features);
 }
 
-extern "C" int spr_colsums_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                               int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
-                               void *d_workspace, size_t workspace_bytes, void *stream) {
-  SPR_REQUIRE(d_X && d_rowmean && d_out && d_workspace, SPR_E_INVALID, "spr_colsums_f64: NULL pointer");
+template <typename TX>
+static int colsums_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                         int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
+                         void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_X && d_rowmean && d_out && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && m <= 512 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
-              SPR_E_INVALID, "spr_colsums_f64: bad shape");
-  SPR_REQUIRE(workspace_bytes >= spr_colsums_workspace(m, n_features), SPR_E_WORKSPACE,
-              "spr_colsums_f64: workspace too small");
+              SPR_E_INVALID, "%s: bad shape", who);
+  SPR_REQUIRE(workspace_bytes >= spr_colsums_workspace(m, n_features), SPR_E_WORKSPACE, "%s: workspace too small", who);
   const int cus = spr_cached_cus();
   SegPlan plan;
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
   plan.total_wg = 4 * (cus > 0 ? cus : 256); plan.chunk_rows = 1;
   const int grid = seg_total_wgs(plan);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(colsums_kernel, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, plan, d_rowmean,
+  hipLaunchKernelGGL(colsums_kernel<TX>, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, plan, d_rowmean,
                      static_cast<double *>(d_workspace));
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsums_finalize_kernel, dim3(n_features), dim3(256), 0, st,
                      static_cast<const double *>(d_workspace), (int)m, plan, d_out);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
+}
+
+extern "C" int spr_colsums_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
+                               void *d_workspace, size_t workspace_bytes, void *stream) {
+  return colsums_entry("spr_colsums_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, d_rowmean, d_out,
+                       d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int spr_colsums_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
+                               void *d_workspace, size_t workspace_bytes, void *stream) {
+  return colsums_entry("spr_colsums_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, d_rowmean, d_out,
+                       d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int spr_fill_feature_f64(double *d_out, int64_t n_rows, int64_t row0, int64_t n_points, int32_t n_features,

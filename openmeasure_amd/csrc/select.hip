@@ -21,8 +21,8 @@ __device__ __forceinline__ uint64_t order_key(double x) {
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-template <bool TWO>
-__global__ __launch_bounds__(SEL_THREADS) void digit_hist_kernel(const double *__restrict__ X, int64_t ldx, int m,
+template <bool TWO, typename TX>
+__global__ __launch_bounds__(SEL_THREADS) void digit_hist_kernel(const TX *__restrict__ X, int64_t ldx, int m,
                                                                  SegPlan plan, const uint64_t *__restrict__ prefix,
                                                                  int shift, int bits,
                                                                  unsigned long long *__restrict__ hist) {
@@ -40,9 +40,9 @@ __global__ __launch_bounds__(SEL_THREADS) void digit_hist_kernel(const double *_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int WAVES = SEL_THREADS / 64;
   for (int64_t row = lo + (int64_t)wl * WAVES + wave; row < hi; row += (int64_t)wpf * WAVES) {
-    const double *rp = X + row * ldx;
+    const TX *rp = X + row * ldx;
     for (int c = lane; c < m; c += 64) {
-      const uint64_t k = order_key(rp[c]);
+      const uint64_t k = order_key((double)rp[c]);   // f32 -> f64 is monotone: same order statistics
       const uint64_t up = all ? 0 : (k >> top);
       const uint32_t d = (uint32_t)(k >> shift) & mask;
       if (up == pa) atomicAdd(&lh[d], 1u);
@@ -61,16 +61,16 @@ __global__ __launch_bounds__(SEL_THREADS) void digit_hist_kernel(const double *_
 
 }  // namespace
 
-extern "C" int spr_feature_digit_hist_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                                          int64_t n_points, int32_t n_features, const uint64_t *d_prefix,
-                                          int32_t shift, int32_t bits, int32_t two_targets, uint64_t *d_hist,
-                                          void *stream) {
-  SPR_REQUIRE(d_X && d_prefix && d_hist, SPR_E_INVALID, "spr_feature_digit_hist_f64: NULL pointer");
+template <typename TX>
+static int digit_hist_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                            int64_t n_points, int32_t n_features, const uint64_t *d_prefix, int32_t shift, int32_t bits,
+                            int32_t two_targets, uint64_t *d_hist, void *stream) {
+  SPR_REQUIRE(d_X && d_prefix && d_hist, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
-              SPR_E_INVALID, "spr_feature_digit_hist_f64: bad shape");
+              SPR_E_INVALID, "%s: bad shape", who);
   SPR_REQUIRE(bits >= 1 && bits <= SEL_MAX_BITS && shift >= 0 && shift + bits <= 64, SPR_E_INVALID,
-              "spr_feature_digit_hist_f64: digit shift=%d bits=%d outside [0,64), width 1..%d", shift, bits, SEL_MAX_BITS);
+              "%s: digit shift=%d bits=%d outside [0,64), width 1..%d", who, shift, bits, SEL_MAX_BITS);
   const int cus = spr_cached_cus();
   SegPlan plan;
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
@@ -79,11 +79,27 @@ extern "C" int spr_feature_digit_hist_f64(const double *d_X, int64_t n_rows, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lds = sizeof(uint32_t) * ((size_t)1 << bits) * (two_targets ? 2 : 1);
   if (two_targets)
-    hipLaunchKernelGGL(digit_hist_kernel<true>, dim3(grid), dim3(SEL_THREADS), lds, st, d_X, ldx, (int)m, plan,
+    hipLaunchKernelGGL((digit_hist_kernel<true, TX>), dim3(grid), dim3(SEL_THREADS), lds, st, d_X, ldx, (int)m, plan,
                        d_prefix, (int)shift, (int)bits, reinterpret_cast<unsigned long long *>(d_hist));
   else
-    hipLaunchKernelGGL(digit_hist_kernel<false>, dim3(grid), dim3(SEL_THREADS), lds, st, d_X, ldx, (int)m, plan,
+    hipLaunchKernelGGL((digit_hist_kernel<false, TX>), dim3(grid), dim3(SEL_THREADS), lds, st, d_X, ldx, (int)m, plan,
                        d_prefix, (int)shift, (int)bits, reinterpret_cast<unsigned long long *>(d_hist));
   SPR_LAUNCH_CHECK();
   return SPR_OK;
+}
+
+extern "C" int spr_feature_digit_hist_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                          int64_t n_points, int32_t n_features, const uint64_t *d_prefix,
+                                          int32_t shift, int32_t bits, int32_t two_targets, uint64_t *d_hist,
+                                          void *stream) {
+  return digit_hist_entry("spr_feature_digit_hist_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, d_prefix,
+                          shift, bits, two_targets, d_hist, stream);
+}
+
+extern "C" int spr_feature_digit_hist_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                          int64_t n_points, int32_t n_features, const uint64_t *d_prefix,
+                                          int32_t shift, int32_t bits, int32_t two_targets, uint64_t *d_hist,
+                                          void *stream) {
+  return digit_hist_entry("spr_feature_digit_hist_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, d_prefix,
+                          shift, bits, two_targets, d_hist, stream);
 }

@@ -65,8 +65,8 @@ __device__ inline void tile_coords(int idx, int &ti, int &tj) {
 // reads the MT-RA operand fragments of column blocks RA..MT-1 once (every fragment is both
 // an A and a B operand) and issues its MFMAs from registers; the fragments of step k+1 are
 // requested before the MFMAs of step k so LDS latency hides behind the 64-cycle MFMAs.
-template <int MT, int U, int VEC>
-__device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int m, int center,
+template <int MT, int U, int VEC, typename TX>
+__device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, int center,
                                  int64_t lo, int64_t hi, int wl, int wpf, int ks, int wave, int lane,
                                  double *__restrict__ lds0, double *__restrict__ lds1,
                                  double *__restrict__ rowmean, double *__restrict__ stat_part,
@@ -79,7 +79,7 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
   constexpr int NA = MT - RA;                 // tiles in row RA == operand fragments per k step
   constexpr int NB = (RB != RA) ? MT - RB : 0;
   static_assert(KROWS % 4 == 0, "k slice must be a multiple of the MFMA depth");
-  using RT = RowTile<MT, R, MP, NW, C::LPRMAX>;
+  using RT = RowTile<MT, R, MP, NW, C::LPRMAX, TX>;
 
   f64x4 accA[NA];
   f64x4 accB[NB > 0 ? NB : 1];
@@ -183,9 +183,9 @@ __device__ inline void gram_wave(const double *__restrict__ X, int64_t ldx, int 
   }
 }
 
-template <int MT, int VEC>
+template <int MT, int VEC, typename TX>
 __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
-    const double *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
+    const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab) {
   using S = GramShape<MT>;
   using C = GramCfg<MT>;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
 #define GRAM_UNIT(UV)                                                                                        \
   case UV:                                                                                                   \
     if constexpr (UV < NU)                                                                                   \
-      gram_wave<MT, UV, VEC>(X, ldx, m, center_i, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
+      gram_wave<MT, UV, VEC, TX>(X, ldx, m, center_i, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
                         lds[1], rowmean, stat_part, slab);                                                   \
     break;
   switch (unit) {
@@ -302,7 +302,7 @@ int occupancy_wgs() {
   static int cached = 0;
   if (cached) return cached;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT, 2>, GramCfg<MT>::NW * 64, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stats_gram_kernel<MT, 2, double>, GramCfg<MT>::NW * 64, 0) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -328,8 +328,8 @@ size_t workspace_bytes(int32_t n_features) {
          (size_t)max_grid * RT::ROWS_PER_IT * 3 * sizeof(double);
 }
 
-template <int MT>
-int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
+template <int MT, typename TX>
+int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
            int32_t n_features, int center, double *rowmean, void *ws, size_t ws_bytes, hipStream_t st) {
   SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
               "spr_stats_gram_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
@@ -339,10 +339,11 @@ int launch(const double *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0
   SPR_REQUIRE(grid >= 1 && grid <= max_grid, SPR_E_INVALID, "spr_stats_gram_f64: bad grid %d", grid);
   double *slab = static_cast<double *>(ws);
   double *stat_part = slab + (size_t)max_grid * GramCfg<MT>::KS * GramShape<MT>::T * 256;
-  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  // two-element pieces: 16-byte aligned rows for f64, 8-byte aligned rows for f32
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
   const int lm = vec_ok ? ((m == 16 * MT) ? 2 : 1) : 0;
 #define SG_LAUNCH(LM)                                                                                         \
-  hipLaunchKernelGGL((stats_gram_kernel<MT, LM>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m, \
+  hipLaunchKernelGGL((stats_gram_kernel<MT, LM, TX>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m, \
                      center, plan, rowmean, stat_part, slab)
   if (lm == 2) SG_LAUNCH(2);
   else if (lm == 1) SG_LAUNCH(1);
@@ -412,6 +413,21 @@ extern "C" int spr_stats_gram_f64(const double *d_X, int64_t n_rows, int32_t m, 
   int rc = check_args("spr_stats_gram_f64", d_X, n_rows, m, ldx, row0, n_points, n_features);
   if (rc != SPR_OK) return rc;
   SPR_REQUIRE(d_rowmean && d_workspace, SPR_E_INVALID, "spr_stats_gram_f64: NULL output/workspace");
+  rc = SPR_E_UNSUPPORTED;
+#define RUN_CALL(MTV)                                                                                \
+  rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_workspace, \
+                   workspace_bytes_, static_cast<hipStream_t>(stream))
+  SPR_DISPATCH_MT(spr_round_mt(m), RUN_CALL)
+#undef RUN_CALL
+  return rc;
+}
+
+extern "C" int spr_stats_gram_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
+                                  void *d_workspace, size_t workspace_bytes_, void *stream) {
+  int rc = check_args("spr_stats_gram_x32", d_X, n_rows, m, ldx, row0, n_points, n_features);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_rowmean && d_workspace, SPR_E_INVALID, "spr_stats_gram_x32: NULL output/workspace");
   rc = SPR_E_UNSUPPORTED;
 #define RUN_CALL(MTV)                                                                                \
   rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_workspace, \

@@ -32,8 +32,9 @@ __device__ inline double normal_at(uint64_t seed, int64_t row, int32_t col, uint
   return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
 
+template <typename TX>
 __global__ __launch_bounds__(SY_THREADS) void synth_kernel(
-    double *__restrict__ X, int64_t n_rows, int ncols, int64_t ldx, int64_t row0, int64_t n_points,
+    TX *__restrict__ X, int64_t n_rows, int ncols, int64_t ldx, int64_t row0, int64_t n_points,
     int col0, const double *__restrict__ R, int k, int ldr, double eps, uint64_t seed) {
   const int lane = threadIdx.x & 63;
   const int64_t wave_id = (int64_t)blockIdx.x * (SY_THREADS / 64) + (threadIdx.x >> 6);
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(SY_THREADS) void synth_kernel(
           const int64_t li = g * SY_ROWS + a;
           if (li < n_rows) {
             const double nz = normal_at(seed, row0 + li, cg, 1u);
-            X[li * ldx + c] = fa[a] * (acc[a] + eps * nz) + fb[a];
+            X[li * ldx + c] = (TX)(fa[a] * (acc[a] + eps * nz) + fb[a]);   // f32 storage: the f64 value rounded once
           }
         }
       }
@@ -96,22 +97,35 @@ __global__ void synth_gather_kernel(const int64_t *__restrict__ rows, int n, int
 
 }  // namespace
 
-extern "C" int spr_synth_f64(double *d_X, int64_t n_rows, int32_t ncols, int64_t ldx, int64_t row0,
-                             int64_t n_points, int32_t col0, const double *d_R, int32_t k, int32_t ldr, double eps,
-                             uint64_t seed, void *stream) {
-  SPR_REQUIRE(d_X && d_R, SPR_E_INVALID, "spr_synth_f64: NULL pointer");
+template <typename TX>
+static int synth_entry(const char *who, TX *d_X, int64_t n_rows, int32_t ncols, int64_t ldx, int64_t row0,
+                       int64_t n_points, int32_t col0, const double *d_R, int32_t k, int32_t ldr, double eps,
+                       uint64_t seed, void *stream) {
+  SPR_REQUIRE(d_X && d_R, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && ncols > 0 && ldx >= ncols && row0 >= 0 && n_points > 0 && col0 >= 0, SPR_E_INVALID,
-              "spr_synth_f64: bad shape");
-  SPR_REQUIRE(k > 0 && k <= SY_MAXK && ldr >= col0 + ncols, SPR_E_INVALID, "spr_synth_f64: bad k=%d ldr=%d", k, ldr);
+              "%s: bad shape", who);
+  SPR_REQUIRE(k > 0 && k <= SY_MAXK && ldr >= col0 + ncols, SPR_E_INVALID, "%s: bad k=%d ldr=%d", who, k, ldr);
   const int64_t groups = (n_rows + SY_ROWS - 1) / SY_ROWS;
   int64_t blocks = (groups + (SY_THREADS / 64) - 1) / (SY_THREADS / 64);
   const int cus = spr_cached_cus();
   const int64_t cap = 8LL * (cus > 0 ? cus : 256);
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(synth_kernel, dim3((int)blocks), dim3(SY_THREADS), 0, static_cast<hipStream_t>(stream), d_X,
+  hipLaunchKernelGGL(synth_kernel<TX>, dim3((int)blocks), dim3(SY_THREADS), 0, static_cast<hipStream_t>(stream), d_X,
                      n_rows, (int)ncols, ldx, row0, n_points, (int)col0, d_R, (int)k, (int)ldr, eps, seed);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
+}
+
+extern "C" int spr_synth_f64(double *d_X, int64_t n_rows, int32_t ncols, int64_t ldx, int64_t row0,
+                             int64_t n_points, int32_t col0, const double *d_R, int32_t k, int32_t ldr, double eps,
+                             uint64_t seed, void *stream) {
+  return synth_entry("spr_synth_f64", d_X, n_rows, ncols, ldx, row0, n_points, col0, d_R, k, ldr, eps, seed, stream);
+}
+
+extern "C" int spr_synth_f32(float *d_X, int64_t n_rows, int32_t ncols, int64_t ldx, int64_t row0,
+                             int64_t n_points, int32_t col0, const double *d_R, int32_t k, int32_t ldr, double eps,
+                             uint64_t seed, void *stream) {
+  return synth_entry("spr_synth_f32", d_X, n_rows, ncols, ldx, row0, n_points, col0, d_R, k, ldr, eps, seed, stream);
 }
 
 extern "C" int spr_synth_gather_f64(const int64_t *d_rows, int32_t n, int64_t n_points, int32_t col,

@@ -115,10 +115,18 @@ class HipEngine:
 
     def _check_matrix(self, X):
         t = self.torch
-        if not (isinstance(X, t.Tensor) and X.is_cuda and X.dtype == t.float64 and X.dim() == 2
+        if not (isinstance(X, t.Tensor) and X.is_cuda and X.dtype in (t.float64, t.float32) and X.dim() == 2
                 and X.stride(1) == 1):
-            raise TypeError('device snapshot matrix must be a 2-D float64 CUDA tensor with unit column stride')
+            raise TypeError('device matrix must be a 2-D float64 / float32 CUDA tensor with unit column stride')
         return X.shape[0], X.shape[1], X.stride(0)
+
+    def _x(self, base, X):
+        """entry point reading the snapshot shard X: <base>_f64, or <base>_x32 for an f32-stored shard"""
+        return getattr(self.lib, base + ('_f64' if X.dtype == self.torch.float64 else '_x32'))
+
+    def _u(self, base, Ur):
+        """entry point reading the basis Ur: <base>_f64, or <base>_u32 for an f32-stored basis"""
+        return getattr(self.lib, base + ('_f64' if Ur.dtype == self.torch.float64 else '_u32'))
 
     def time_next(self, kernel):
         """Bracket the next launch of `kernel` ('stats_gram' | 'project' | 'reconstruct') with a pair of
@@ -151,7 +159,7 @@ class HipEngine:
         ws = self._workspace('gram', nbytes)
         tic, toc = self._timed('stats_gram')
         tic()
-        _lib.check(self.lib.spr_stats_gram_f64(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
+        _lib.check(self._x('spr_stats_gram', X)(_ptr(X), n, m, ld, row0, n_points, n_features, int(bool(center)),
                                                _ptr(rowmean), _ptr(ws), ws.numel(), self._stream()),
                    'spr_stats_gram_f64')
         toc()
@@ -175,7 +183,7 @@ class HipEngine:
         if center:
             rowmean = self.empty((n,))
             ws = self._workspace('rowstats', self.lib.spr_rowstats_workspace(F))
-            _lib.check(self.lib.spr_rowstats_f64(_ptr(X), n, m, ld, row0, n_points, F, _ptr(rowmean), _ptr(fstats),
+            _lib.check(self._x('spr_rowstats', X)(_ptr(X), n, m, ld, row0, n_points, F, _ptr(rowmean), _ptr(fstats),
                                                  _ptr(ws), ws.numel(), st), 'spr_rowstats_f64')
         else:
             rowmean = self.zeros((n,))
@@ -185,13 +193,13 @@ class HipEngine:
         for origin, width in ((0, mA), (mA, mB)):
             ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(width, F))
             xp = X.data_ptr() + origin * esz
-            _lib.check(self.lib.spr_stats_gram_f64(xp, n, width, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(ws),
+            _lib.check(self._x('spr_stats_gram', X)(xp, n, width, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(ws),
                                                    ws.numel(), st), 'spr_stats_gram_f64')
             _lib.check(self.lib.spr_stats_gram_finalize_f64(n, width, row0, n_points, F, _ptr(ws), ws.numel(),
                                                             _ptr(scratch), _ptr(gram), m, origin, st),
                        'spr_stats_gram_finalize_f64')
         ws = self._workspace('cross', self.lib.spr_gram_cross_workspace(m, F))
-        _lib.check(self.lib.spr_gram_cross_f64(_ptr(X), n, m, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(gram),
+        _lib.check(self._x('spr_gram_cross', X)(_ptr(X), n, m, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(gram),
                                                _ptr(ws), ws.numel(), st), 'spr_gram_cross_f64')
         toc()
         return rowmean, fstats, gram
@@ -218,6 +226,8 @@ class HipEngine:
         return out
 
     # ---- K4 --------------------------------------------------------------------------------
+    _PROJECT_BLOCK_ROWS = 4_000_000
+
     def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
         """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even.
         ``out``: a previous result of the same shape to overwrite (keeps one basis buffer alive).
@@ -227,11 +237,12 @@ class HipEngine:
         n, m, ld = self._check_matrix(X)
         r = W.shape[1]
         ldu = r + (r & 1)
-        if out is not None and tuple(out.shape) == (n, r) and out.stride(0) == ldu and out.stride(1) == 1:
+        if (out is not None and tuple(out.shape) == (n, r) and out.stride(0) == ldu and out.stride(1) == 1
+                and out.dtype == X.dtype):
             buf = out
         else:
             del out
-            buf = self.empty((n, ldu))
+            buf = self.empty((n, ldu), dtype=X.dtype)        # the basis is stored like the shard (f64 or f32)
         tic, toc = self._timed('project')
         tic()
         Wc = W.contiguous()
@@ -239,12 +250,28 @@ class HipEngine:
         slices = ((0, m),) if m <= mA else ((0, mA), (mA, m - mA))     # a wide X goes as two column slices
         if m > _lib.SPR_MAX_M_WIDE:
             raise NotImplementedError(f'project: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
-        for k, (c0, width) in enumerate(slices):
-            _lib.check(self.lib.spr_project_f64(X.data_ptr() + c0 * X.element_size(), n, width, ld, row0, n_points,
-                                                n_features, int(bool(center)), _ptr(inv_scale),
-                                                _ptr(rowmean) if center else None,
-                                                Wc.data_ptr() + c0 * r * Wc.element_size(), r, _ptr(buf), ldu,
-                                                int(k > 0), self._stream()), 'spr_project_f64')
+        if len(slices) > 1 and X.dtype == self.torch.float32:
+            # f32 basis of a wide X: the slices' partial sums cancel by up to sigma_1/sigma_r, so they meet in an
+            # f64 block of rows and are rounded to f32 once (a dtype-converting copy)
+            block = self._PROJECT_BLOCK_ROWS
+            scratch = self.empty((min(block, n), ldu))
+            esz, fn = X.element_size(), self.lib.spr_project_x32_f64out
+            for i0 in range(0, n, block):
+                rows = min(block, n - i0)
+                for k, (c0, width) in enumerate(slices):
+                    _lib.check(fn(X.data_ptr() + (i0 * ld + c0) * esz, rows, width, ld, row0 + i0, n_points, n_features,
+                                  int(bool(center)), _ptr(inv_scale),
+                                  rowmean.data_ptr() + i0 * rowmean.element_size() if center else None,
+                                  Wc.data_ptr() + c0 * r * Wc.element_size(), r, _ptr(scratch), ldu, int(k > 0),
+                                  self._stream()), 'spr_project_x32_f64out')
+                buf[i0:i0 + rows].copy_(scratch[:rows, :buf.shape[1]])
+        else:
+            for k, (c0, width) in enumerate(slices):
+                _lib.check(self._x('spr_project', X)(X.data_ptr() + c0 * X.element_size(), n, width, ld, row0, n_points,
+                                                     n_features, int(bool(center)), _ptr(inv_scale),
+                                                     _ptr(rowmean) if center else None,
+                                                     Wc.data_ptr() + c0 * r * Wc.element_size(), r, _ptr(buf), ldu,
+                                                     int(k > 0), self._stream()), 'spr_project')
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf
 
@@ -253,7 +280,7 @@ class HipEngine:
         n, m, ld = self._check_matrix(X)
         out = self.empty((n_features, 2))
         ws = self._workspace('minmax', self.lib.spr_feature_minmax_workspace(n_features))
-        _lib.check(self.lib.spr_feature_minmax_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(out), _ptr(ws),
+        _lib.check(self._x('spr_feature_minmax', X)(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(out), _ptr(ws),
                                                    ws.numel(), self._stream()), 'spr_feature_minmax_f64')
         return out
 
@@ -262,7 +289,7 @@ class HipEngine:
         prefixes; -> (F, 2, 1 << bits) int64 counts over the local rows."""
         n, m, ld = self._check_matrix(X)
         hist = self.zeros((n_features, 2, 1 << bits), dtype=self.torch.int64)
-        _lib.check(self.lib.spr_feature_digit_hist_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(prefix),
+        _lib.check(self._x('spr_feature_digit_hist', X)(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(prefix),
                                                        shift, bits, int(bool(two_targets)), _ptr(hist),
                                                        self._stream()), 'spr_feature_digit_hist_f64')
         return hist
@@ -272,7 +299,7 @@ class HipEngine:
         n, m, ld = self._check_matrix(X)
         out = self.empty((n_features, 2, m))
         ws = self._workspace('colsums', self.lib.spr_colsums_workspace(m, n_features))
-        _lib.check(self.lib.spr_colsums_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(rowmean), _ptr(out),
+        _lib.check(self._x('spr_colsums', X)(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(rowmean), _ptr(out),
                                             _ptr(ws), ws.numel(), self._stream()), 'spr_colsums_f64')
         return out
 
@@ -287,7 +314,7 @@ class HipEngine:
     def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
         n, m, ld = self._check_matrix(X)
         out = self.empty((n, m))
-        _lib.check(self.lib.spr_scale_rows_f64(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(rowmean),
+        _lib.check(self._x('spr_scale_rows', X)(_ptr(X), n, m, ld, row0, n_points, n_features, _ptr(rowmean),
                                                _ptr(inv_scale), _ptr(out), m, self._stream()),
                    'spr_scale_rows_f64')
         return out
@@ -309,7 +336,7 @@ class HipEngine:
             out = self.empty((n_p, n))
         tic, toc = self._timed('reconstruct')
         tic()
-        _lib.check(self.lib.spr_reconstruct_f64(_ptr(Ur), n, r, ldu, row0, n_points, n_features, _ptr(rowmean),
+        _lib.check(self._u('spr_reconstruct', Ur)(_ptr(Ur), n, r, ldu, row0, n_points, n_features, _ptr(rowmean),
                                                 _ptr(scale), _ptr(rowscale), _ptr(A.contiguous()), n_p, _ptr(out),
                                                 out.stride(0),
                                                 self._stream()), 'spr_reconstruct_f64')
@@ -319,7 +346,7 @@ class HipEngine:
     # ---- K6 ----------------------------------------------------------------------------------
     def mask_rows(self, Ur, mask_u8):
         n, r, ldu = self._check_matrix(Ur)
-        _lib.check(self.lib.spr_mask_rows_f64(_ptr(Ur), n, r, ldu, _ptr(mask_u8), self._stream()),
+        _lib.check(self._u('spr_mask_rows', Ur)(_ptr(Ur), n, r, ldu, _ptr(mask_u8), self._stream()),
                    'spr_mask_rows_f64')
 
     @property
@@ -335,7 +362,7 @@ class HipEngine:
                   Q=self.zeros((n_steps, r)), piv=self.zeros((n_steps,), dtype=t.int64),
                   gap=self.zeros((n_steps,)), ok=self.zeros((n_steps,)),
                   ws=self._workspace('qr', self.lib.spr_qr_workspace(n)))
-        _lib.check(self.lib.spr_qr_init_f64(_ptr(Ur), n, r, ldu, row0, _ptr(st['nrm']), _ptr(st['rec']),
+        _lib.check(self._u('spr_qr_init', Ur)(_ptr(Ur), n, r, ldu, row0, _ptr(st['nrm']), _ptr(st['rec']),
                                             _ptr(st['tau']), _ptr(st['ws']), st['ws'].numel(), self._stream()),
                    'spr_qr_init_f64')
         return st
@@ -359,7 +386,7 @@ class HipEngine:
 
     def qr_refresh(self, st, j0, nq):
         """Apply the accepted directions Q[j0:j0+nq] to every row, redraw candidates / record / tau."""
-        _lib.check(self.lib.spr_qr_refresh_f64(_ptr(st['Ur']), st['n'], st['r'], st['ldu'], st['row0'],
+        _lib.check(self._u('spr_qr_refresh', st['Ur'])(_ptr(st['Ur']), st['n'], st['r'], st['ldu'], st['row0'],
                                                _ptr(st['Q']), _ptr(st['piv']), j0, nq, _ptr(st['nrm']),
                                                _ptr(st['rec']), _ptr(st['tau']), _ptr(st['ws']),
                                                st['ws'].numel(), self._stream()), 'spr_qr_refresh_f64')
@@ -372,7 +399,7 @@ class HipEngine:
         Theta = self.empty((s, r))
         cnt = self.empty((s,))
         scl = self.empty((s,)) if scale is not None else None
-        _lib.check(self.lib.spr_measure_csr_f64(_ptr(indptr), _ptr(indices), _ptr(vals), s, _ptr(Ur), n, r, ldu,
+        _lib.check(self._u('spr_measure_csr', Ur)(_ptr(indptr), _ptr(indices), _ptr(vals), s, _ptr(Ur), n, r, ldu,
                                                 row0, _ptr(rowmean), _ptr(scale), n_points,
                                                 scale.shape[0] if scale is not None else 0, _ptr(Theta), _ptr(cnt),
                                                 _ptr(scl), self._stream()), 'spr_measure_csr_f64')
@@ -393,12 +420,14 @@ class HipEngine:
         return Ar, Ar_sigma, y0, info
 
     # ---- synthetic data ---------------------------------------------------------------------------
-    def synth(self, n_rows, m, row0, n_points, R, eps, seed, out=None):
-        """Rows [row0, row0+n_rows) of the synthetic matrix; R is (k, >=m) on the device."""
+    def synth(self, n_rows, m, row0, n_points, R, eps, seed, out=None, dtype=None):
+        """Rows [row0, row0+n_rows) of the synthetic matrix; R is (k, >=m) on the device.  dtype float32 stores
+        the same f64 values rounded once."""
         if out is None:
-            out = self.empty((n_rows, m))
+            out = self.empty((n_rows, m), dtype=dtype)
         k, ldr = R.shape[0], R.stride(0)
-        _lib.check(self.lib.spr_synth_f64(_ptr(out), n_rows, m, out.stride(0), row0, n_points, 0, _ptr(R), k, ldr,
+        fn = self.lib.spr_synth_f64 if out.dtype == self.torch.float64 else self.lib.spr_synth_f32
+        _lib.check(fn(_ptr(out), n_rows, m, out.stride(0), row0, n_points, 0, _ptr(R), k, ldr,
                                           float(eps), int(seed), self._stream()), 'spr_synth_f64')
         return out
 

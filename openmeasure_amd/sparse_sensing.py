@@ -79,7 +79,9 @@ class RowShard:
 
 
 class DeviceMatrix:
-    """A snapshot block that already lives in HBM (2-D float64 CUDA tensor, rows contiguous)."""
+    """A snapshot block that already lives in HBM (2-D float64 or float32 CUDA tensor, rows contiguous).
+    float32 = storage precision only: every kernel widens on load and computes in f64; the basis Ur is then
+    stored in float32 as well (the reference's U has the dtype of its X, np.linalg.svd :272)."""
 
     def __init__(self, tensor):
         self.tensor = tensor
@@ -277,7 +279,8 @@ class ROM:
             else:
                 if self.X.ndim != 2:
                     raise ValueError('X must be a 2-D array.')
-                self._d['X'] = eng.to_device(self.X)
+                # a float32 snapshot matrix stays float32 in HBM (storage only, see DeviceMatrix)
+                self._d['X'] = eng.to_device(self.X, dtype=eng.torch.float32 if self.X.dtype == np.float32 else None)
         return self._d['X']
 
     def _all_reduce(self, t):

@@ -32,12 +32,17 @@ class NumpyEngine:
         return t.detach().numpy()
 
     @staticmethod
+    def _w(t):
+        """float64 view of a stored matrix (f32 storage is widened, like the kernels do on load)"""
+        return t.numpy().astype(np.float64, copy=False)
+
+    @staticmethod
     def _feat(n, row0, n_points, F):
         return np.minimum((row0 + np.arange(n)) // n_points, F - 1)
 
     # K1 + K3a
     def stats_gram(self, X, row0, n_points, n_features, center=True):
-        x = X.numpy()
+        x = self._w(X)
         n, m = x.shape
         mean = x.mean(axis=1) if center else np.zeros(n)
         c = x - mean[:, None]
@@ -54,15 +59,15 @@ class NumpyEngine:
 
     # K4
     def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
-        x = X.numpy()
+        x = self._w(X)
         n = x.shape[0]
         mean = (rowmean.numpy() if rowmean is not None else x.mean(axis=1)) if center else np.zeros(n)
         feat = self._feat(n, row0, n_points, n_features)
         U = ((x - mean[:, None]) @ W.numpy()) * inv_scale.numpy()[feat][:, None]
-        return torch.from_numpy(np.ascontiguousarray(U))
+        return torch.from_numpy(np.ascontiguousarray(U)).to(X.dtype)     # stored like the shard
 
     def feature_minmax(self, X, row0, n_points, n_features):
-        x = X.numpy()
+        x = self._w(X)
         feat = self._feat(x.shape[0], row0, n_points, n_features)
         out = np.empty((n_features, 2))
         for f in range(n_features):
@@ -71,7 +76,7 @@ class NumpyEngine:
         return torch.from_numpy(out)
 
     def feature_digit_hist(self, X, row0, n_points, n_features, prefix, shift, bits, two_targets):
-        x = X.numpy()
+        x = np.ascontiguousarray(self._w(X))
         feat = self._feat(x.shape[0], row0, n_points, n_features)
         u = x.view(np.uint64)
         sign = np.uint64(1) << np.uint64(63)
@@ -88,7 +93,7 @@ class NumpyEngine:
         return torch.from_numpy(out)
 
     def colsums(self, X, row0, n_points, n_features, rowmean):
-        x, mu = X.numpy(), rowmean.numpy()
+        x, mu = self._w(X), rowmean.numpy()
         c = x - mu[:, None]
         feat = self._feat(x.shape[0], row0, n_points, n_features)
         out = np.zeros((n_features, 2, x.shape[1]))
@@ -103,7 +108,7 @@ class NumpyEngine:
 
     def scale_rows(self, X, row0, n_points, n_features, rowmean, inv_scale):
         feat = self._feat(X.shape[0], row0, n_points, n_features)
-        return torch.from_numpy((X.numpy() - rowmean.numpy()[:, None]) * inv_scale.numpy()[feat][:, None])
+        return torch.from_numpy((self._w(X) - rowmean.numpy()[:, None]) * inv_scale.numpy()[feat][:, None])
 
     def unscale(self, x0, row0, n_points, n_features, rowmean, scale, rowscale=None):
         feat = self._feat(x0.shape[0], row0, n_points, n_features)
@@ -114,7 +119,7 @@ class NumpyEngine:
     def reconstruct(self, Ur, row0, n_points, n_features, rowmean, scale, A, out=None, rowscale=None):
         feat = self._feat(Ur.shape[0], row0, n_points, n_features)
         sc = scale.numpy()[feat] if rowscale is None else rowscale.numpy()
-        x = (Ur.numpy() @ A.numpy().T) * sc[:, None] + rowmean.numpy()[:, None]
+        x = (self._w(Ur) @ A.numpy().T) * sc[:, None] + rowmean.numpy()[:, None]
         return torch.from_numpy(np.ascontiguousarray(x.T))
 
     # K6
@@ -127,11 +132,11 @@ class NumpyEngine:
         nrm = st['nrm'].numpy()
         i = int(np.argmax(nrm))                      # first index on ties
         second = np.partition(nrm, -2)[-2] if nrm.size > 1 else -2.0
-        st['rec'] = torch.from_numpy(np.concatenate([[nrm[i], st['row0'] + i, second], st['Ur'].numpy()[i]]))
+        st['rec'] = torch.from_numpy(np.concatenate([[nrm[i], st['row0'] + i, second], self._w(st['Ur'])[i]]))
 
     def qr_begin(self, Ur, row0, n_steps):
         n, r = Ur.shape
-        st = dict(Ur=Ur, n=n, r=r, row0=row0, nrm=torch.from_numpy((Ur.numpy() ** 2).sum(axis=1)),
+        st = dict(Ur=Ur, n=n, r=r, row0=row0, nrm=torch.from_numpy((self._w(Ur) ** 2).sum(axis=1)),
                   Q=torch.zeros((n_steps, r), dtype=torch.float64),
                   piv=torch.zeros((n_steps,), dtype=torch.int64),
                   gap=torch.zeros((n_steps,), dtype=torch.float64),
@@ -173,7 +178,7 @@ class NumpyEngine:
         q = v / nn if nn > 0 else np.zeros_like(v)
         Q[step] = q
         nrm = st['nrm'].numpy()
-        d = st['Ur'].numpy() @ q
+        d = self._w(st['Ur']) @ q
         new = np.maximum(nrm - d * d, 0.0)
         new[nrm < 0] = -1.0
         li = piv - st['row0']
@@ -190,7 +195,7 @@ class NumpyEngine:
         if st['piv'][j0] < 0:
             q = st['Q'].numpy()[j0]
             nrm = st['nrm'].numpy()
-            d = st['Ur'].numpy() @ q
+            d = self._w(st['Ur']) @ q
             new = np.maximum(nrm - d * d, 0.0)
             new[nrm < 0] = -1.0
             nrm[:] = new
@@ -203,7 +208,7 @@ class NumpyEngine:
         Theta = np.zeros((s, r))
         cnt = np.zeros(s)
         scl = np.zeros(s)
-        U, mu = Ur.numpy(), rowmean.numpy()
+        U, mu = self._w(Ur), rowmean.numpy()
         for i in range(s):
             for e in range(ip[i], ip[i + 1]):
                 col = ix[e] - row0

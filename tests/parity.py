@@ -167,3 +167,51 @@ def run_gem_fixture(g, engine):
     spr.train(C)                                              # the placement feeds train/predict like the QR one
     assert spr.Theta.shape == (g['n_sensors'], spr.r)
     return spr
+
+
+def run_f32_storage(engine, n_points, F, m, r, seed, synth):
+    """f32 STORAGE of the snapshot matrix (and therefore of the basis), f64 arithmetic: everything is compared with
+    the oracle run in f64 on the same f32-rounded values -- statistics and spectrum to f64 accuracy, the basis to
+    f32 rounding, the sensors EXACTLY against dgeqp3 on the stored basis widened to f64, the field within 1e-6."""
+    from oracle import spr_oracle as orc
+    X32 = synth(n_points, F, m, min(m, 2 * r), 0.8, 1e-3, seed).astype(np.float32)
+    Xw = X32.astype(np.float64)
+    n = n_points * F
+    st = orc.fit(Xw, F, 'number', r)
+    spr = SPR(X32, F, None, engine=engine)
+    spr.fit(select_modes='number', n_modes=r)
+    assert spr.Ur.dtype == np.float32 and spr.Ur.shape == (n, r)
+    np.testing.assert_allclose(spr.X_cnt, st['X_cnt'], rtol=1e-12, atol=1e-12 * np.abs(st['X_cnt']).max())
+    np.testing.assert_allclose(spr.X_scl, st['X_scl'], rtol=1e-11)
+    np.testing.assert_allclose(spr.Sigma_r, st['Sigma_r'], rtol=1e-8)
+    sg = align_signs(spr.Ar, st['Ar'])
+    scale_u = np.abs(st['Ur']).max()
+    # the stored basis is the f64 basis of the same path rounded to f32 (twice for m > 256: two column slices);
+    # against the oracle's SVD route only up to the conditioning of the noise-level modes (clustered singular values)
+    ref64 = SPR(Xw, F, None, engine=engine)
+    ref64.fit(select_modes='number', n_modes=r)
+    s64 = align_signs(ref64.Ar, spr.Ar)
+    np.testing.assert_allclose(spr.Ur, ref64.Ur * s64, rtol=0, atol=2e-7 * scale_u)
+    z = np.random.default_rng(seed).standard_normal(n)
+    U32 = spr.Ur.astype(np.float64)
+    assert rel_fro(U32 @ (U32.T @ z), st['Ur'] @ (st['Ur'].T @ z)) < 1e-5      # same subspace as the SVD route
+    C = spr.optimal_placement()
+    want, _ = orc.qr_pivots(spr.Ur.astype(np.float64))
+    np.testing.assert_array_equal(spr.sensors_, want)
+    spr.train(C)
+    Cd = np.zeros((r, n)); Cd[np.arange(r), spr.sensors_] = 1.0
+    ys = []
+    for j in (0, 1):
+        y = np.zeros((r, 3)); y[:, 0] = Xw[spr.sensors_, j]; y[:, 2] = spr.sensors_ // n_points
+        if j == 1:
+            y[:, 1] = 0.01 * (1.0 + np.arange(r) % 3)
+        ys.append(y)
+    Ar, Ar_sigma = spr.predict(ys)
+    Ur_ref = st['Ur'] * sg                                    # oracle basis in the device's sign convention
+    Theta_ref = orc.train_theta(Cd, Ur_ref, n)
+    A_ref, S_ref = orc.predict_ols(ys, Theta_ref, Cd, st['X_cnt'], st['X_scl'], n_points)
+    X_ref = orc.reconstruct(A_ref, Ur_ref, st['X_cnt'], st['X_scl'])
+    X_rec = spr.reconstruct(Ar)
+    assert X_rec.shape == (n, 2)
+    assert rel_fro(X_rec, X_ref) <= REL_FRO
+    return spr

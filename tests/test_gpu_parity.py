@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import spr_oracle as orc
-from tests.parity import REL_FRO, align_signs, rel_fro, run_fixture, run_gem_fixture, run_gpr_style
+from tests.parity import REL_FRO, align_signs, rel_fro, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,49 @@ def test_native_library_is_loaded(eng):
 
 def test_golden_fixture(golden, eng):
     run_fixture(golden, eng)
+
+
+@pytest.mark.parametrize('n_points,F,m,r', [(400, 3, 12, 4), (3000, 4, 64, 32), (1500, 9, 41, 14), (700, 3, 256, 64),
+                                            (777, 2, 255, 33), (500, 5, 300, 40), (1000, 16, 512, 128)])
+def test_f32_storage_end_to_end(eng, n_points, F, m, r):
+    """f32-stored shard and basis (BASELINE config 5's storage), f64 arithmetic: _x32 / _u32 entry points."""
+    run_f32_storage(eng, n_points, F, m, r, 33, synth_host)
+
+
+def test_f32_storage_kernels_vs_f64_twins(eng):
+    """Kernel by kernel: the f32-storage entry points on X32 equal the f64 ones on X32 widened (same arithmetic),
+    up to the one rounding of the stored basis."""
+    import torch
+    rng = np.random.default_rng(7)
+    n_points, F, m, r = 2001, 3, 96, 24
+    X32 = (rng.standard_normal((n_points * F, m)) * 3 + 1).astype(np.float32)
+    Xs, Xw = eng.to_device(X32, dtype=torch.float32), eng.to_device(X32.astype(np.float64))
+    ms, fs, gs = eng.stats_gram(Xs, 0, n_points, F)
+    mw, fw, gw = eng.stats_gram(Xw, 0, n_points, F)
+    np.testing.assert_array_equal(eng.to_host(ms), eng.to_host(mw))
+    np.testing.assert_array_equal(eng.to_host(gs), eng.to_host(gw))
+    np.testing.assert_array_equal(eng.to_host(fs), eng.to_host(fw))
+    np.testing.assert_array_equal(eng.to_host(eng.feature_minmax(Xs, 0, n_points, F)), eng.to_host(eng.feature_minmax(Xw, 0, n_points, F)))
+    np.testing.assert_array_equal(eng.to_host(eng.colsums(Xs, 0, n_points, F, ms)), eng.to_host(eng.colsums(Xw, 0, n_points, F, mw)))
+    W = eng.to_device(rng.standard_normal((m, r)))
+    inv = eng.to_device(np.ones(F))
+    Us = eng.project(Xs, 0, n_points, F, inv, W, rowmean=ms)
+    Uw = eng.project(Xw, 0, n_points, F, inv, W, rowmean=mw)
+    assert Us.dtype == torch.float32 and Uw.dtype == torch.float64
+    np.testing.assert_array_equal(eng.to_host(Us), eng.to_host(Uw).astype(np.float32))
+    Uq = eng.to_device(eng.to_host(Us).astype(np.float64))            # the stored basis, widened
+    a = eng.to_device(rng.standard_normal((5, r)))
+    sc = eng.to_device(np.array([1.0, 2.0, 0.5]))
+    np.testing.assert_array_equal(eng.to_host(eng.reconstruct(Us, 0, n_points, F, ms, sc, a)),
+                                  eng.to_host(eng.reconstruct(Uq, 0, n_points, F, ms, sc, a)))
+    s1, s2 = eng.qr_begin(Us, 0, 4), eng.qr_begin(Uq, 0, 4)
+    np.testing.assert_array_equal(eng.to_host(s1['nrm']), eng.to_host(s2['nrm']))
+    np.testing.assert_array_equal(eng.to_host(s1['rec']), eng.to_host(s2['rec']))
+    for st in (s1, s2):
+        eng.qr_step(st, 0, st['rec'][None], st['tau'][None], True)
+        eng.qr_refresh(st, 0, 1)
+    np.testing.assert_array_equal(eng.to_host(s1['nrm']), eng.to_host(s2['nrm']))
+    np.testing.assert_array_equal(eng.to_host(s1['piv'][:1]), eng.to_host(s2['piv'][:1]))
 
 
 def test_gem_fixture(golden_gem, eng):                    # calc_type='gem', picks pinned by the reference

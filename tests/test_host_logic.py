@@ -7,7 +7,7 @@ import scipy.sparse as sp
 
 from openmeasure_amd.sparse_sensing import ROM, SPR
 from tests.numpy_engine import NumpyEngine
-from tests.parity import run_fixture, run_gem_fixture, run_gpr_style
+from tests.parity import run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style
 
 
 def test_fixture_through_host_logic(golden):
@@ -22,6 +22,21 @@ def test_gpr_style_subclass(golden, foreign):           # gpr.py:379-402: a ROM 
 
 def test_gem_fixture_through_host_logic(golden_gem):   # :586-698
     run_gem_fixture(golden_gem, NumpyEngine())
+
+
+def _synth(n_points, F, m, k, rho, eps, seed):
+    rng = np.random.default_rng(seed)
+    n = n_points * F
+    X = rng.standard_normal((n, k)) @ ((rho ** np.arange(k))[:, None] * rng.standard_normal((k, m)))
+    X += eps * rng.standard_normal((n, m))
+    for f in range(F):
+        X[f * n_points:(f + 1) * n_points] = (f + 1) * X[f * n_points:(f + 1) * n_points] + 10.0 * f
+    return np.ascontiguousarray(X)
+
+
+@pytest.mark.parametrize('n_points,F,m,r', [(400, 3, 12, 4), (300, 2, 41, 14)])
+def test_f32_storage_through_host_logic(n_points, F, m, r):      # float32 X: stored as given, arithmetic in f64
+    run_f32_storage(NumpyEngine(), n_points, F, m, r, 21, _synth)
 
 
 @pytest.fixture

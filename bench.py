@@ -38,6 +38,11 @@ WORKLOADS = {
     'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000),   # c3 at 1/10 of the rows
     # config-5 shape (16 features x 512 snapshots, 128 sensors) in f64 at 1M cells/GPU (65.5 GB): the column-split path
     'c5s': dict(cells=1_000_000, features=16, m=512, s=128, cpu_cells=15_000),
+    # config 5 as BASELINE.json states it: 50M cells x 16 features x 512 snapshots over 8 GPUs = 6.25M cells (100M
+    # rows) per GPU, which only fits in f32 STORAGE (204.8 GB shard + 51.2 GB basis); arithmetic stays f64
+    'c5': dict(cells=6_250_000, features=16, m=512, s=128, cpu_cells=15_000, storage='f32'),
+    'c5s32': dict(cells=1_000_000, features=16, m=512, s=128, cpu_cells=15_000, storage='f32'),
+    'c3s32': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000, storage='f32'),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F64_PEAK_TF = 78.6     # AMD public spec for MI355X FP64 matrix; tools/mfma_probe measures 73.6 on the box
@@ -81,6 +86,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     F, m, s = wl['features'], wl['m'], wl['s']
+    f32 = wl.get('storage') == 'f32'
+    B = 4 if f32 else 8                           # bytes per stored element of X and Ur
     cells_loc = wl['cells']                       # cells added per rank (weak scaling)
     n_points = cells_loc * world                  # global cells
     n_glob = n_points * F
@@ -91,9 +98,9 @@ def main():
     eng = HipEngine(f'cuda:{local_rank}')
     R = eng.to_device(make_R(m, s, seed=seed))
     t0 = time.time()
-    Xd = eng.synth(n_loc, m, row0, n_points, R, eps, seed)
+    Xd = eng.synth(n_loc, m, row0, n_points, R, eps, seed, dtype=torch.float32 if f32 else None)
     torch.cuda.synchronize()
-    log(f'[rank {rank}] generated {n_loc} x {m} f64 shard ({n_loc * m * 8 / 1e9:.2f} GB) in {time.time() - t0:.2f}s')
+    log(f'[rank {rank}] generated {n_loc} x {m} {"f32" if f32 else "f64"} shard ({n_loc * m * B / 1e9:.2f} GB) in {time.time() - t0:.2f}s')
 
     shard = RowShard(row0, n_glob, force_collectives=force_dist) if (world > 1 or force_dist) else None
     spr = SPR(DeviceMatrix(Xd), F, None, shard=shard, engine=eng)
@@ -131,7 +138,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = 1e3 * dt / args.steps
-    x_bytes = float(n_glob) * m * 8
+    x_bytes = float(n_glob) * m * B
     value = x_bytes / (dt / args.steps) / 1e9
 
     k_ms = {k: float(np.mean([tm[i][0].elapsed_time(tm[i][1]) for tm in timers]))
@@ -139,9 +146,9 @@ def main():
     r = spr.r
     # per-launch algorithmic work of each kernel on THIS rank's shard
     alg = {
-        'stats_gram': dict(bytes=n_loc * m * 8 + n_loc * 8, flops=float(n_loc) * m * m),
-        'project': dict(bytes=n_loc * m * 8 + n_loc * r * 8, flops=2.0 * n_loc * m * r),
-        'reconstruct': dict(bytes=n_loc * r * 8 + 2 * n_loc * 8, flops=2.0 * n_loc * r),
+        'stats_gram': dict(bytes=n_loc * m * B + n_loc * 8, flops=float(n_loc) * m * m),
+        'project': dict(bytes=n_loc * m * B + n_loc * r * B, flops=2.0 * n_loc * m * r),
+        'reconstruct': dict(bytes=n_loc * r * B + 2 * n_loc * 8, flops=2.0 * n_loc * r),
     }
     phases = {k: dict(ms=round(k_ms[k], 4), GBs=round(alg[k]['bytes'] / k_ms[k] / 1e6, 1),
                       TFLOPs=round(alg[k]['flops'] / k_ms[k] / 1e9, 3)) for k in k_ms}
@@ -165,8 +172,8 @@ def main():
     except (OSError, ValueError):
         pass
     roof['ms'] = round(k_ms[dom], 4)
-    # whole-step algorithmic bytes: (2m + 2r + 1) n B + 16 n
-    step_bytes = (2 * m + 2 * r + 1) * float(n_glob) * 8 + 16.0 * n_glob
+    # whole-step algorithmic bytes: (2m + 2r) n B for X and Ur + 8 n (field, f64) + 16 n (row means)
+    step_bytes = (2 * m + 2 * r) * float(n_glob) * B + 24.0 * n_glob
     hbm_frac = step_bytes / (dt / args.steps) / (world * HBM_PEAK_GBS * 1e9)
 
     extra = {}
@@ -206,7 +213,9 @@ def main():
         idx = torch.cat([torch.arange(f * n_points, f * n_points + cc, device=eng.device) for f in range(F)])
         Xs = eng.to_host(Xd[idx])                   # first cc cells of every feature: a valid (cc*F) x m problem
         t1 = time.perf_counter()
-        xr_cpu, st_cpu = orc.fit_reconstruct_timed(Xs, F, s)
+        # an f32-stored sample goes to the oracle widened: the reference itself would run in f32 on it
+        Xo = Xs.astype(np.float64) if f32 else Xs
+        xr_cpu, st_cpu = orc.fit_reconstruct_timed(Xo, F, s)
         t_cpu = time.perf_counter() - t1
         try:
             import threadpoolctl
@@ -223,7 +232,8 @@ def main():
         sg = np.sign(np.sum(sp2.Ur * st_cpu['Ur'], axis=0))
         xr_gpu = sp2.reconstruct(st_cpu['Ar'][0] * sg)
         sp2.optimal_placement()
-        piv_cpu, _ = orc.qr_pivots(st_cpu['Ur'])
+        # f32 storage: the sensors are those of the STORED basis (oracle's dgeqp3 on it, widened to f64)
+        piv_cpu, _ = orc.qr_pivots(sp2.Ur.astype(np.float64) if f32 else st_cpu['Ur'])
         parity = dict(sensors_equal=bool(np.array_equal(sp2.sensors_, piv_cpu)),
                       field_rel_fro=float(np.linalg.norm(xr_gpu - xr_cpu) / np.linalg.norm(xr_cpu)),
                       sigma_rel=float(np.max(np.abs(sp2.Sigma_r - st_cpu['Sigma_r']) / st_cpu['Sigma_r'])),
@@ -236,8 +246,8 @@ def main():
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f"{args.workload}: {cells_loc} cells/GPU x {F} features x {m} snapshots, "
-                                   f"{s} modes/sensors, f64, rows sharded over {world} GPU(s)",
-                       'rows_per_gpu': n_loc, 'snapshot_GB_per_gpu': round(n_loc * m * 8 / 1e9, 3)},
+                                   f"{s} modes/sensors, {'f32 storage / f64 arithmetic' if f32 else 'f64'}, rows sharded over {world} GPU(s)",
+                       'rows_per_gpu': n_loc, 'snapshot_GB_per_gpu': round(n_loc * m * B / 1e9, 3), 'storage': 'f32' if f32 else 'f64'},
             'hbm_roofline_frac_step': round(hbm_frac, 4),
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
         }

@@ -139,3 +139,52 @@ def test_sharded_gem_matches_reference(tmp_path, fixture, world):
         o = np.load(tmp_path / f'rank{r}.npz')
         np.testing.assert_array_equal(o['piv'], g['gem_piv'])
         assert tuple(o['C_shape']) == tuple(g['C_shape'])
+
+
+def _f32_worker(rank, world, port, fixture, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden
+        from tests.numpy_engine import NumpyEngine
+        g = load_golden(fixture)
+        X32 = g['X'].astype(np.float32)
+        n = X32.shape[0]
+        n_loc = n // world
+        row0 = rank * n_loc
+        spr = SPR(np.ascontiguousarray(X32[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
+                  engine=NumpyEngine())
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        assert spr.Ur.dtype == np.float32
+        spr.train(spr.optimal_placement())
+        A3, _ = spr.predict(list(g['ys']))
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, X3=spr.reconstruct(A3), Ur=spr.Ur)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_f32_storage(tmp_path):
+    """float32 shards (config 5's storage) over two ranks: same sensors and fields as one process on the whole
+    float32 matrix -- the collectives only ever carry f64 statistics, Gram blocks and records."""
+    from openmeasure_amd.sparse_sensing import SPR
+    from tests.conftest import load_golden
+    from tests.numpy_engine import NumpyEngine
+    from tests.parity import REL_FRO, rel_fro
+    fixture, world = 'g3_num8', 2
+    g = load_golden(fixture)
+    mp.spawn(_f32_worker, args=(world, _free_port(), fixture, str(tmp_path)), nprocs=world, join=True)
+    one = SPR(g['X'].astype(np.float32), g['n_features'], None, engine=NumpyEngine())
+    one.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+    one.train(one.optimal_placement())
+    A3, _ = one.predict(list(g['ys']))
+    X3 = one.reconstruct(A3)
+    outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+    n_loc = g['X'].shape[0] // world
+    for r, o in enumerate(outs):
+        np.testing.assert_array_equal(o['piv'], one.sensors_)
+        assert rel_fro(o['X3'], X3) <= REL_FRO and rel_fro(o['X3'], g['X_rec3']) <= 1e-5
+        sgn = np.sign(np.sum(o['Ur'].astype(np.float64) * one.Ur[r * n_loc:(r + 1) * n_loc], axis=0))
+        np.testing.assert_allclose(o['Ur'] * sgn, one.Ur[r * n_loc:(r + 1) * n_loc], atol=2e-7)

@@ -27,8 +27,12 @@ namespace {
 
 constexpr int QR_THREADS = 256;
 constexpr int QR_UNR = 4;
-constexpr int QR_TOPT = 8;          // rows kept per sweep block
-constexpr int QR_MAX_BLOCKS = 1024; // sweep grid cap -> at most 8192 candidates
+#ifndef QR_TOPT_N
+#define QR_TOPT_N 16   // 16 instead of 8: 5 sweeps instead of 6 at config 3 (55.6 -> 49.7 ms, tools/topt_ab.sh); a batch of
+                       // 32 directions on top of that certified [18,16,14,10,6]: still 5 sweeps, each slower
+#endif
+constexpr int QR_TOPT = QR_TOPT_N;  // rows kept per sweep block
+constexpr int QR_MAX_BLOCKS = 1024; // sweep grid cap -> at most 16384 candidates
 constexpr int QR_BATCH = 16;        // directions applied per refresh sweep (one MFMA tile of columns)
 constexpr int QR_VBATCH = 8;        // ... by the VALU form of the sweep (kept for reference / cross-checks)
 

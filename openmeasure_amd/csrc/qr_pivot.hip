@@ -34,7 +34,6 @@ constexpr int QR_UNR = 4;
 constexpr int QR_TOPT = QR_TOPT_N;  // rows kept per sweep block
 constexpr int QR_MAX_BLOCKS = 1024; // sweep grid cap -> at most 16384 candidates
 constexpr int QR_BATCH = 16;        // directions applied per refresh sweep (one MFMA tile of columns)
-constexpr int QR_VBATCH = 8;        // ... by the VALU form of the sweep (kept for reference / cross-checks)
 
 struct Best {
   double v1; int64_t i1; double v2;
@@ -139,13 +138,12 @@ struct TopList {
   }
 };
 
-// Full sweep over the rank's rows.  MODE 0: nrm = |u|^2.  MODE 2: nrm <- nrm down-dated by nq
-// directions (rows already chosen keep -1).  Both: the block's QR_TOPT largest (value, global
-// row) pairs, sorted, to tops[block][QR_TOPT][2].
-template <int LPR, int MODE, typename TU>
+// Norm sweep over the rank's rows: nrm = |u|^2 and the block's QR_TOPT largest (value, global row) pairs, sorted,
+// to tops[block][QR_TOPT][2].  (The down-dating sweeps are the MFMA kernel below.)
+template <int LPR, typename TU>
 __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int vec_ok_i, int64_t row0,
-    const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
+    double *__restrict__ nrm, double *__restrict__ tops) {
   constexpr int RPW = 64 / LPR;
   constexpr int ROWS_IT = (QR_THREADS / 64) * RPW * QR_UNR;
   __shared__ double sval[QR_THREADS * QR_TOPT];
@@ -154,12 +152,6 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
   const int grp = lane / LPR, lig = lane % LPR;
   const bool vec_ok = vec_ok_i != 0;
   const int k0 = 2 * lig;
-  double q0[QR_VBATCH], q1[QR_VBATCH];
-#pragma unroll
-  for (int t = 0; t < QR_VBATCH; ++t) {
-    q0[t] = (MODE == 2 && t < nq && k0 < r) ? Q[(int64_t)t * r + k0] : 0.0;
-    q1[t] = (MODE == 2 && t < nq && k0 + 1 < r) ? Q[(int64_t)t * r + k0 + 1] : 0.0;
-  }
   TopList top;
   top.init();
 
@@ -176,14 +168,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
     for (int j = 0; j < QR_UNR; ++j) {
       const int64_t row = rbase + j * RPW;
       const bool mine = (lig == 0) && (row < n_rows);
-      double v;
-      if (MODE == 0) {
-        v = group_sum_t<LPR>(u[j].x * u[j].x + u[j].y * u[j].y);
-      } else {
-        const double old = mine ? nrm[row] : 0.0;
-        v = downdate<LPR, QR_VBATCH>(old, u[j], q0, q1, nq);
-        v = old < 0.0 ? -1.0 : v;
-      }
+      const double v = group_sum_t<LPR>(u[j].x * u[j].x + u[j].y * u[j].y);
       if (mine) nrm[row] = v;
       top.insert(v, row0 + row, mine);
     }
@@ -529,10 +514,10 @@ struct QrWs {
   }
 };
 
-template <int MODE, typename TU>
+template <typename TU>
 int launch_sweep(int lpr, int grid, hipStream_t st, const TU *Ur, int64_t n_rows, int r, int64_t ldu,
-                 int vec_ok, int64_t row0, const double *Q, int nq, double *nrm, double *tops) {
-#define SW(L) hipLaunchKernelGGL((qr_sweep_kernel<L, MODE, TU>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, vec_ok, row0, Q, nq, nrm, tops); break
+                 int vec_ok, int64_t row0, double *nrm, double *tops) {
+#define SW(L) hipLaunchKernelGGL((qr_sweep_kernel<L, TU>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, vec_ok, row0, nrm, tops); break
   switch (lpr) {
     case 1: SW(1);
     case 2: SW(2);
@@ -615,7 +600,7 @@ static int qr_init_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_
   const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
   QrWs w(d_workspace);
-  rc = launch_sweep<0, TU>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, 0, d_nrm, w.tops);
+  rc = launch_sweep<TU>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, d_nrm, w.tops);
   if (rc != SPR_OK) return rc;
   return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
 }

@@ -169,6 +169,7 @@ def main():
         if pm and dom == 'stats_gram' and world == 1:
             roof['traffic'] = pm['hbm_bytes']
             roof['algorithmic_bytes'] = int(alg[dom]['bytes'])
+            roof['traffic_source'] = 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes'
     except (OSError, ValueError):
         pass
     roof['ms'] = round(k_ms[dom], 4)

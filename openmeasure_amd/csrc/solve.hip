@@ -7,8 +7,11 @@
 // solution, so the kernel forms the augmented Gram matrix of [W Theta | W y0 | y0_sigma]
 // (s x (r+2)) with v_mfma_f64_16x16x4_f64 -- the same 16x16-tile scheme as the snapshot
 // Gram kernel, with the sensors as the contraction index -- equilibrates it to unit
-// diagonal, factors N' = L L^T in LDS and solves both right-hand sides.  info[1] = (max L_jj / min L_jj)^2 is returned so the
-// caller can refuse an ill-conditioned system instead of losing digits silently.
+// diagonal, factors N' = L L^T in LDS and solves both right-hand sides, then takes ONE step of iterative refinement
+// with the residual formed from W Theta itself (corrected semi-normal equations: x += N^-1 A^T (b - A x)), which
+// brings the error from cond(A)^2 eps back to the cond(A) eps of a QR solve as long as cond(A)^2 eps < 1.
+// info[1] = (max L_jj / min L_jj)^2 is returned so the caller can refuse a system beyond that range instead of
+// losing digits silently.
 #include "common.hpp"
 
 namespace {
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(SV_THREADS) void solve_ols_kernel(
   __shared__ double rhs[2][C::RMAX];
   __shared__ double sol[2][C::RMAX];
   __shared__ double dsc[C::RMAX];
+  __shared__ double xs[2][C::RMAX];
   __shared__ double sw[SC], sv[SC], ss[SC];
   __shared__ int flags[2];  // [0] any sigma != 0, [1] Cholesky breakdown
 
@@ -180,27 +184,89 @@ __global__ __launch_bounds__(SV_THREADS) void solve_ols_kernel(
     }
     __syncthreads();
   }
-  // forward substitution L z = rhs (both right-hand sides), then L^T x = z
-  for (int j = 0; j < r; ++j) {
-    if (tid < 2) sol[tid][j] = rhs[tid][j] / N[j * LDN + j];
+  // forward substitution L z = rhs (both right-hand sides), then L^T x = z; the solution ends up in rhs
+  auto chol_solve = [&]() {
+    for (int j = 0; j < r; ++j) {
+      if (tid < 2) sol[tid][j] = rhs[tid][j] / N[j * LDN + j];
+      __syncthreads();
+      for (int i = j + 1 + tid; i < r; i += SV_THREADS) {
+        const double l = N[i * LDN + j];
+        rhs[0][i] -= l * sol[0][j];
+        rhs[1][i] -= l * sol[1][j];
+      }
+      __syncthreads();
+    }
+    for (int j = r - 1; j >= 0; --j) {
+      if (tid < 2) rhs[tid][j] = sol[tid][j] / N[j * LDN + j];
+      __syncthreads();
+      for (int i = tid; i < j; i += SV_THREADS) {
+        const double l = N[j * LDN + i];
+        sol[0][i] -= l * rhs[0][j];
+        sol[1][i] -= l * rhs[1][j];
+      }
+      __syncthreads();
+    }
+  };
+  chol_solve();
+  // x = D x' so far; one refinement step: e = b - A x per sensor, g = A^T e, x' += N'^-1 (D g)
+  if (tid < r) { xs[0][tid] = rhs[0][tid]; xs[1][tid] = rhs[1][tid]; rhs[0][tid] = 0.0; rhs[1][tid] = 0.0; }
+  __syncthreads();
+  for (int c0 = 0; c0 < s; c0 += SC) {
+    if (tid < SC) {
+      const int k = c0 + tid;
+      double w = 0.0, v0 = 0.0, s0 = 0.0;
+      if (k < s) {
+        int f = (int)y[3 * k + 2];
+        if (f < 0) f = 0;
+        if (f > n_features - 1) f = n_features - 1;
+        const double scl = scale[f];
+        v0 = (y[3 * k] - cnt[k]) / scl;
+        s0 = y[3 * k + 1] / scl;
+        w = weighted ? 1.0 / s0 : 1.0;
+      }
+      sw[tid] = w; sv[tid] = v0; ss[tid] = s0;
+    }
     __syncthreads();
-    for (int i = j + 1 + tid; i < r; i += SV_THREADS) {
-      const double l = N[i * LDN + j];
-      rhs[0][i] -= l * sol[0][j];
-      rhs[1][i] -= l * sol[1][j];
+    for (int e = tid; e < SC * NAP; e += SV_THREADS) {
+      const int kk = e / NAP, c = e - kk * NAP;
+      const int k = c0 + kk;
+      panel[kk * CP + c] = (k < s && c < r) ? sw[kk] * Theta[(int64_t)k * r + c] : 0.0;
+    }
+    __syncthreads();
+    // residuals of the panel's sensors: wave w takes sensors w, w+4, ...
+    for (int kk = wave; kk < SC; kk += SV_WAVES) {
+      double d0 = 0.0, d1 = 0.0;
+      for (int c = lane; c < r; c += 64) {
+        const double a = panel[kk * CP + c];
+        d0 += a * xs[0][c] * dsc[c];
+        d1 += a * xs[1][c] * dsc[c];
+      }
+      d0 = group_sum(d0, 64);
+      d1 = group_sum(d1, 64);
+      if (lane == 0) {
+        const bool live = c0 + kk < s;
+        sv[kk] = live ? sw[kk] * sv[kk] - d0 : 0.0;            // b = W y0
+        ss[kk] = (live && weighted) ? ss[kk] - d1 : 0.0;       // b = y0_sigma
+      }
+    }
+    __syncthreads();
+    if (tid < r) {
+      double g0 = 0.0, g1 = 0.0;
+      for (int kk = 0; kk < SC; ++kk) {
+        const double a = panel[kk * CP + tid];
+        g0 += a * sv[kk];
+        g1 += a * ss[kk];
+      }
+      rhs[0][tid] += g0;
+      rhs[1][tid] += g1;
     }
     __syncthreads();
   }
-  for (int j = r - 1; j >= 0; --j) {
-    if (tid < 2) rhs[tid][j] = sol[tid][j] / N[j * LDN + j];
-    __syncthreads();
-    for (int i = tid; i < j; i += SV_THREADS) {
-      const double l = N[j * LDN + i];
-      sol[0][i] -= l * rhs[0][j];
-      sol[1][i] -= l * rhs[1][j];
-    }
-    __syncthreads();
-  }
+  if (tid < r) { rhs[0][tid] *= dsc[tid]; rhs[1][tid] *= dsc[tid]; }
+  __syncthreads();
+  chol_solve();
+  if (tid < r) { rhs[0][tid] += xs[0][tid]; rhs[1][tid] += xs[1][tid]; }
+  __syncthreads();
   for (int k = tid; k < r; k += SV_THREADS) {
     Ar[(int64_t)p * r + k] = rhs[0][k] * dsc[k];
     Ar_sigma[(int64_t)p * r + k] = weighted ? fabs(rhs[1][k] * dsc[k]) : 0.0;

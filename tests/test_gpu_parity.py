@@ -330,6 +330,35 @@ def test_weighted_predict_batch_vs_oracle(eng):
     assert not eng.to_host(info)[:, 0].any()
 
 
+@pytest.mark.parametrize('cond,tol', [(1e2, 1e-12), (1e4, 1e-10), (1e5, 1e-9), (1e6, 1e-7)])
+def test_predict_moderately_ill_conditioned_theta(eng, cond, tol):
+    """Normal equations alone lose cond^2 eps; with the refinement step of solve.hip the coefficients agree with the
+    oracle's SVD pseudo-inverse to about cond eps (weighted and unweighted right-hand sides)."""
+    import torch
+    rng = np.random.default_rng(11)
+    s_, r = 48, 24
+    Uq, _ = np.linalg.qr(rng.standard_normal((s_, r)))
+    Vq, _ = np.linalg.qr(rng.standard_normal((r, r)))
+    Theta = (Uq * np.logspace(0, -np.log10(cond), r)) @ Vq.T
+    a_true = rng.standard_normal(r)
+    ys = []
+    for weighted in (False, True):
+        y = np.zeros((s_, 3))
+        y[:, 0] = Theta @ a_true + 1e-3 * rng.standard_normal(s_)
+        if weighted:
+            y[:, 1] = 0.05 * (1.0 + rng.random(s_))
+        ys.append(y)
+    Y = eng.to_device(np.stack(ys))
+    Ar, As, _, info = eng.solve_ols(eng.to_device(Theta), eng.to_device(np.zeros(s_)), eng.to_device(np.ones(1)), Y)
+    Ar, As, info = eng.to_host(Ar), eng.to_host(As), eng.to_host(info)
+    assert not info[:, 0].any()
+    C = np.eye(s_)                                             # identity measurement: cnt = 0, scl = 1, feature 0
+    A_ref, S_ref = orc.predict_ols(ys, Theta, C, np.zeros((s_, 1)), np.ones((s_, 1)), s_)
+    for k in range(2):
+        assert np.linalg.norm(Ar[k] - A_ref[k]) <= tol * np.linalg.norm(A_ref[k]), (k, info[k])
+    assert np.linalg.norm(As[1] - S_ref[1]) <= tol * np.linalg.norm(S_ref[1])
+
+
 def test_general_csr_measurement_matrix(eng):
     import scipy.sparse as sp
     rng = np.random.default_rng(12)

@@ -138,44 +138,6 @@ struct TopList {
   }
 };
 
-// Norm sweep over the rank's rows: nrm = |u|^2 and the block's QR_TOPT largest (value, global row) pairs, sorted,
-// to tops[block][QR_TOPT][2].  (The down-dating sweeps are the MFMA kernel below.)
-template <int LPR, typename TU>
-__global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
-    const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int vec_ok_i, int64_t row0,
-    double *__restrict__ nrm, double *__restrict__ tops) {
-  constexpr int RPW = 64 / LPR;
-  constexpr int ROWS_IT = (QR_THREADS / 64) * RPW * QR_UNR;
-  __shared__ double sval[QR_THREADS * QR_TOPT];
-  __shared__ long long sidx[QR_THREADS * QR_TOPT];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int grp = lane / LPR, lig = lane % LPR;
-  const bool vec_ok = vec_ok_i != 0;
-  const int k0 = 2 * lig;
-  TopList top;
-  top.init();
-
-  const int64_t nsteps = (n_rows + ROWS_IT - 1) / ROWS_IT;
-  for (int64_t s = blockIdx.x; s < nsteps; s += gridDim.x) {
-    const int64_t rbase = s * ROWS_IT + (wave * QR_UNR) * RPW + grp;
-    f64x2 u[QR_UNR];
-#pragma unroll
-    for (int j = 0; j < QR_UNR; ++j) {
-      const int64_t row = rbase + j * RPW;
-      u[j] = load_row_piece(Ur + row * ldu, k0, r, vec_ok, row < n_rows);
-    }
-#pragma unroll
-    for (int j = 0; j < QR_UNR; ++j) {
-      const int64_t row = rbase + j * RPW;
-      const bool mine = (lig == 0) && (row < n_rows);
-      const double v = group_sum_t<LPR>(u[j].x * u[j].x + u[j].y * u[j].y);
-      if (mine) nrm[row] = v;
-      top.insert(v, row0 + row, mine);
-    }
-  }
-  top.block_merge(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2);
-}
-
 // Refresh sweep, MFMA form: nrm <- nrm - sum_t (u_i . q_t)^2 for up to 16 directions at once.
 // Panels of 64 rows of Ur go to LDS raw (rowtile.hpp staging, double-buffered, loads of the panel
 // after next issued behind the stores); wave w multiplies its 16-row block with Q^T (directions as
@@ -183,7 +145,9 @@ __global__ __launch_bounds__(QR_THREADS) void qr_sweep_kernel(
 // HBM time of the panel, where the VALU form spends 8 x (fma + 5-step butterfly) per row pair.
 // The squared products are summed over the 16 direction lanes with a DPP butterfly; lanes 0/16/32/48
 // of a wave own rows a, a+4, a+8, a+12 of the block (increasing order, as TopList needs).
-template <int MTR, int VEC, typename TU>
+// INIT (first sweep of a placement): the same pass with the block itself as the second operand -- the diagonal of
+// U_blk U_blk^T are the squared row norms -- so the initial norms stream at the same rate as the refreshes.
+template <int MTR, int VEC, typename TU, bool INIT>
 __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
     const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
@@ -202,7 +166,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     const int k = 4 * ks + (lane >> 4), j = lane & 15;
-    bfrag[ks] = (j < nq && k < r) ? Q[(int64_t)j * r + k] : 0.0;
+    bfrag[ks] = (!INIT && j < nq && k < r) ? Q[(int64_t)j * r + k] : 0.0;
   }
   TopList top;
   top.init();
@@ -228,13 +192,14 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t rr = brow + 4 * i;
-        old[i] = nrm[rr < n_rows ? rr : n_rows - 1];               // requested before the MFMAs
+        old[i] = INIT ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];  // requested before the MFMAs
       }
       const double *p = cur + wave * 16 * MP + afrag;
       f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[4 * ks], bfrag[ks], acc, 0, 0, 0);
+        const double a = p[4 * ks];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, INIT ? a : bfrag[ks], acc, 0, 0, 0);
         if (ks == 0) {
 #pragma unroll
           for (int it = 0; it < RT::IT; ++it) {
@@ -243,17 +208,30 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
           }
         }
       }
-      const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
-                            group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
+      if (INIT) {
+        // D[i][j] = u_i . u_j of the block: lane (g = lane >> 4, c = lane & 15) holds D[g + 4 q][c]; the diagonal
+        // entry of row c sits in the lane with g == (c & 3), register q = c >> 2
+        const double dv[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t rr = brow + 4 * i;
-        const bool mine = ((lane & 15) == 0) && (rr < n_rows);
-        double v = old[i] - d2[i];
-        v = v < 0.0 ? 0.0 : v;
-        v = old[i] < 0.0 ? -1.0 : v;
-        if (mine) nrm[rr] = v;
-        top.insert(v, row0 + rr, mine);
+        for (int i = 0; i < 4; ++i) {
+          const int64_t rr = brow + 4 * i;
+          const bool mine = ((lane & 15) == (lane >> 4) + 4 * i) && (rr < n_rows);
+          if (mine) nrm[rr] = dv[i];
+          top.insert(dv[i], row0 + rr, mine);
+        }
+      } else {
+        const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
+                              group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t rr = brow + 4 * i;
+          const bool mine = ((lane & 15) == 0) && (rr < n_rows);
+          double v = old[i] - d2[i];
+          v = v < 0.0 ? 0.0 : v;
+          v = old[i] < 0.0 ? -1.0 : v;
+          if (mine) nrm[rr] = v;
+          top.insert(v, row0 + rr, mine);
+        }
       }
       buf ^= 1;
       c = cn;
@@ -514,20 +492,23 @@ struct QrWs {
   }
 };
 
-template <typename TU>
-int launch_sweep(int lpr, int grid, hipStream_t st, const TU *Ur, int64_t n_rows, int r, int64_t ldu,
-                 int vec_ok, int64_t row0, double *nrm, double *tops) {
-#define SW(L) hipLaunchKernelGGL((qr_sweep_kernel<L, TU>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, vec_ok, row0, nrm, tops); break
-  switch (lpr) {
-    case 1: SW(1);
-    case 2: SW(2);
-    case 4: SW(4);
-    case 8: SW(8);
-    case 16: SW(16);
-    case 32: SW(32);
-    default: SW(64);
+template <typename TU, bool INIT>
+int launch_refresh(int grid, hipStream_t st, const TU *Ur, int64_t n_rows, int r, int64_t ldu, int vec_ok, int64_t row0,
+                   const double *Qj, int nq, double *nrm, double *tops) {
+  const int mtr = spr_round_mt(r);      // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
+  const int lm = vec_ok ? ((r == 16 * mtr) ? 2 : 1) : 0;
+#define RF(MTV, LM) hipLaunchKernelGGL((qr_refresh_mfma_kernel<MTV, LM, TU, INIT>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, row0, Qj, nq, nrm, tops)
+#define RFV(MTV) do { if (lm == 2) RF(MTV, 2); else if (lm == 1) RF(MTV, 1); else RF(MTV, 0); } while (0)
+  switch (mtr) {
+    case 1: RFV(1); break;
+    case 2: RFV(2); break;
+    case 3: RFV(3); break;
+    case 4: RFV(4); break;
+    case 6: RFV(6); break;
+    default: RFV(8); break;
   }
-#undef SW
+#undef RFV
+#undef RF
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
@@ -600,7 +581,7 @@ static int qr_init_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_
   const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
   QrWs w(d_workspace);
-  rc = launch_sweep<TU>(lpr, grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, d_nrm, w.tops);
+  rc = launch_refresh<TU, true>(grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, 0, d_nrm, w.tops);
   if (rc != SPR_OK) return rc;
   return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
 }
@@ -690,24 +671,8 @@ static int qr_refresh_entry(const char *who, const TU *d_Ur, int64_t n_rows, int
   QrWs w(d_workspace);
   hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + j0, (int)nq, row0, n_rows, d_nrm);
   SPR_LAUNCH_CHECK();
-  {
-    const double *Qj = d_Q + (int64_t)j0 * r;
-    const int mtr = spr_round_mt(r);      // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
-    const int lm = vec_ok ? ((r == 16 * mtr) ? 2 : 1) : 0;
-#define RF(MTV, LM) hipLaunchKernelGGL((qr_refresh_mfma_kernel<MTV, LM, TU>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows, (int)r, ldu, row0, Qj, (int)nq, d_nrm, w.tops)
-#define RFV(MTV) do { if (lm == 2) RF(MTV, 2); else if (lm == 1) RF(MTV, 1); else RF(MTV, 0); } while (0)
-    switch (mtr) {
-      case 1: RFV(1); break;
-      case 2: RFV(2); break;
-      case 3: RFV(3); break;
-      case 4: RFV(4); break;
-      case 6: RFV(6); break;
-      default: RFV(8); break;
-    }
-#undef RFV
-#undef RF
-    SPR_LAUNCH_CHECK();
-  }
+  rc = launch_refresh<TU, false>(grid, st, d_Ur, n_rows, (int)r, ldu, vec_ok, row0, d_Q + (int64_t)j0 * r, (int)nq, d_nrm, w.tops);
+  if (rc != SPR_OK) return rc;
   return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
 }
 

@@ -113,23 +113,27 @@ def main():
     spr.fit(select_modes='number', n_modes=s)     # first call: allocations, RCCL warm-up
     a_d = eng.to_device(spr.Ar[:1].copy())        # (1, r) coefficient vector, resident
 
-    def step(timers=None):
-        if timers is not None:
-            timers.append((eng.time_next('stats_gram'), eng.time_next('project'), eng.time_next('reconstruct')))
-        spr.fit(select_modes='number', n_modes=s)
-        # field all-gather left in flight: it overlaps the next step's (MFMA-bound) Gram pass
-        return spr.reconstruct(a_d, to_host=False, wait=args.sync_gather)
-
     def done(f):
         return f.wait() if hasattr(f, 'wait') else f
 
+    def step(prev=None, timers=None):
+        if timers is not None:
+            timers.append((eng.time_next('stats_gram'), eng.time_next('project'), eng.time_next('reconstruct')))
+        spr.fit(select_modes='number', n_modes=s)
+        done(prev)                                # the previous field's all-gather ran under this fit: join it now
+        # field all-gather left in flight: it overlaps the next step's (MFMA-bound) Gram pass
+        return spr.reconstruct(a_d, to_host=False, wait=args.sync_gather)
+
+    field = None
     for _ in range(args.warmup):
-        done(step())
+        field = step(field)
+    done(field)
+    field = None
     timers = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        field = step(timers)
+        field = step(field, timers)
     field = done(field)                           # the last gather joins the compute stream inside the timed region
     barrier()
     dt = time.perf_counter() - t0

@@ -96,9 +96,10 @@ class PendingField:
     ranks may still be in flight on the communication stream.  ``wait()`` makes the current stream wait for it and
     returns the tensor; nothing else may read the tensor before that."""
 
-    def __init__(self, tensor, works=()):
+    def __init__(self, tensor, works=(), keep=()):
         self._tensor = tensor
         self._works = list(works)
+        self._keep = keep                      # the gather's source buffers stay alive until it has been joined
 
     @property
     def shape(self):
@@ -108,6 +109,7 @@ class PendingField:
         for w in self._works:
             w.wait()
         self._works = []
+        self._keep = ()
         return self._tensor
 
 
@@ -729,7 +731,7 @@ class ROM:
             works = [dist.all_gather_into_tensor(out[p], loc[p], group=self._shard.group, async_op=True)
                      for p in range(n_p)]                     # one contiguous all-gather per column
             if not to_host and not wait:
-                return PendingField(out, works)
+                return PendingField(out, works, keep=(loc,))
             for w in works:
                 w.wait()
         if not to_host:

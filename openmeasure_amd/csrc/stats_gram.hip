@@ -16,7 +16,7 @@
 #include "rowtile.hpp"
 
 #ifndef GRAM_ABLATE
-#define GRAM_ABLATE 0   // diagnostic builds: 1 = no MFMAs, 2 = no centring/loads in the loop
+#define GRAM_ABLATE 0   // diagnostic builds: 1 = no MFMAs, 2 = no centring/loads in the loop, 3 = loads + raw LDS stores, no centring arithmetic
 #endif
 #if GRAM_ABLATE == 1
 #define GRAM_MFMA(a, b, c) ({ asm volatile("" ::"v"(a), "v"(b)); (c); })
@@ -134,7 +134,8 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
 #pragma unroll
         for (int it = 0; it < RT::IT; ++it)
           if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
-            tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
+            if (GRAM_ABLATE == 3) tile.raw_store_pass(it, nxt, m, nrow0, hi, wave, lane);
+            else tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
             tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane, mean_in);   // panel c+2 into the freed registers
           }
       }
@@ -153,7 +154,8 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
 #pragma unroll
         for (int it = 0; it < RT::IT; ++it)
           if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
-            tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
+            if (GRAM_ABLATE == 3) tile.raw_store_pass(it, nxt, m, nrow0, hi, wave, lane);
+            else tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
             tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane, mean_in);   // panel c+2 into the freed registers
           }
       }

@@ -214,4 +214,20 @@ def run_f32_storage(engine, n_points, F, m, r, seed, synth):
     X_rec = spr.reconstruct(Ar)
     assert X_rec.shape == (n, 2)
     assert rel_fro(X_rec, X_ref) <= REL_FRO
+    # partial-field reconstruction through a sampling matrix (:365-368) on the f32-stored basis
+    rng = np.random.default_rng(seed + 1)
+    S = np.zeros((6, n))
+    S[np.arange(3), rng.integers(0, n, 3)] = 1.0
+    for k in range(3, 6):
+        S[k, rng.integers(0, n, 4)] = rng.random(4)
+    Xs = spr.reconstruct(Ar, sampling=S)
+    Xs_ref = orc.reconstruct_sampled(A_ref, Ur_ref, st['X_cnt'], st['X_scl'], S)
+    assert Xs.shape == Xs_ref.shape and rel_fro(Xs, Xs_ref) <= REL_FRO
+    # masked placement zeroes the stored rows in place (:737-738) and pivots what is left
+    mask = rng.random(n) < 0.5
+    U_before = spr.Ur.astype(np.float64)
+    spr.optimal_placement(mask=mask)
+    want_m, U_masked = orc.qr_pivots(U_before, mask)
+    np.testing.assert_array_equal(spr.sensors_, want_m)
+    np.testing.assert_array_equal(spr.Ur.astype(np.float64), U_masked)
     return spr

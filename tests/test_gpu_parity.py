@@ -551,3 +551,41 @@ def test_properties_at_config3_scale(eng):
     np.testing.assert_array_equal(sub.sensors_, want)
     del Xd, spr, sub, rec
     t.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+@pytest.mark.parametrize('scale_type,axis_cnt', [('std', None), ('pareto', 1), ('range', None), ('median', 1), ('l2-norm', 1),
+                                                 ('max', None), ('level', 1)])
+@pytest.mark.parametrize('n_points,F,m,r', [(700, 3, 40, 9), (300, 4, 300, 12)])
+def test_option_matrix_vs_oracle(eng, dtype, scale_type, axis_cnt, n_points, F, m, r):
+    """Scalings x centring modes x storage precision x (narrow | column-split wide) snapshot counts, end to end
+    against the oracle on the same stored values: statistics tight, sensors of the stored basis exact, fields 1e-6."""
+    from openmeasure_amd.sparse_sensing import SPR
+    X = synth_host(n_points, F, m, min(m, 2 * r), 0.75, 1e-3, 91) * 0.05 + 5.0       # positive: 'level' etc. well defined
+    if dtype == 'f32':
+        X = X.astype(np.float32)
+    Xw = X.astype(np.float64)
+    n = n_points * F
+    st = orc.fit(Xw, F, 'number', r, scale_type=scale_type, axis_cnt=axis_cnt)
+    spr = SPR(X, F, None, engine=eng)
+    spr.fit(scale_type=scale_type, axis_cnt=axis_cnt, select_modes='number', n_modes=r)
+    np.testing.assert_allclose(spr.X_cnt, st['X_cnt'], rtol=1e-12, atol=1e-12 * np.abs(st['X_cnt']).max())
+    np.testing.assert_allclose(spr.X_scl, st['X_scl'], rtol=1e-10)
+    np.testing.assert_allclose(spr.Sigma_r, st['Sigma_r'], rtol=1e-7)
+    C = spr.optimal_placement()
+    want, _ = orc.qr_pivots(spr.Ur.astype(np.float64))
+    np.testing.assert_array_equal(spr.sensors_, want)
+    spr.train(C)
+    y = np.zeros((r, 3)); y[:, 0] = Xw[spr.sensors_, 1]; y[:, 2] = spr.sensors_ // n_points
+    a, _ = spr.predict(y)
+    x_rec = spr.reconstruct(a)
+    # the training column is reproduced up to the truncation error of the rank-r basis
+    x0_err = (x_rec[:, 0] - Xw[:, 1]) / st['X_scl'][:, 0]
+    tail = np.sqrt(np.sum(st['S'][r:] ** 2))
+    assert np.linalg.norm(x0_err) <= 1.5 * tail + 1e-6 * np.linalg.norm((Xw[:, 1] - st['X_cnt'][:, 0]) / st['X_scl'][:, 0])
+    # and agrees with the oracle's reconstruction from the same sensors
+    sg = align_signs(spr.Ar, st['Ar'])
+    Cd = np.zeros((r, n)); Cd[np.arange(r), spr.sensors_] = 1.0
+    Ur_ref = st['Ur'] * sg
+    A_ref, _ = orc.predict_ols([y], orc.train_theta(Cd, Ur_ref, n), Cd, st['X_cnt'], st['X_scl'], n_points)
+    assert rel_fro(x_rec, orc.reconstruct(A_ref, Ur_ref, st['X_cnt'], st['X_scl'])) <= REL_FRO

@@ -225,6 +225,11 @@ int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_rec
                     int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
                     const double *d_xyz, int32_t xyz_dim, int64_t n_points, double d_min,
                     void *d_workspace, size_t workspace_bytes, void *stream);
+/* single GPU: n_steps consecutive steps in one call (d_recs = d_rec, n_rec = 1, first = the call's first step) */
+int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_t n_steps, const double *d_tau,
+                     double *d_Q, int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
+                     const double *d_xyz, int32_t xyz_dim, int64_t n_points, double d_min,
+                     void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_qr_exclude_f64(double *d_nrm, int64_t n_rows, int64_t row0, int64_t n_points,
                        const uint8_t *d_mask, const double *d_xyz, int32_t xyz_dim,
                        const int64_t *d_piv, int32_t nq, double d_min, void *stream);

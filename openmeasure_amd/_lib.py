@@ -56,6 +56,7 @@ PROTOTYPES = {
     'spr_mask_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     'spr_qr_init_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     'spr_qr_step_f64': (C.c_int, [_i64, _i32, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _i64, _dbl, _p, _sz, _p]),
+    'spr_qr_steps_f64': (C.c_int, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _dbl, _p, _sz, _p]),
     'spr_qr_exclude_f64': (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _i32, _p, _i32, _dbl, _p]),
     'spr_qr_refresh_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'spr_measure_csr_f64': (C.c_int, [_p, _p, _p, _i32, _p, _i64, _i32, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p]),

@@ -640,6 +640,23 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   return SPR_OK;
 }
 
+// Single-GPU convenience: n_steps candidate-set steps (step0, step0+1, ...) in one call, the rank's own record and tau
+// feeding every step -- the same launches as n_steps calls of spr_qr_step_f64 with d_recs = d_rec, n_rec = 1, first =
+// (t == 0), without the per-call host overhead that dominates small placements.
+extern "C" int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_t n_steps, const double *d_tau,
+                                double *d_Q, int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
+                                const double *d_xyz, int32_t xyz_dim, int64_t n_points, double d_min,
+                                void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(n_steps >= 1 && step0 >= 0 && step0 + n_steps <= r, SPR_E_INVALID,
+              "spr_qr_steps_f64: steps [%d, %d) outside [0, %d)", step0, step0 + n_steps, r);
+  for (int t = 0; t < n_steps; ++t) {
+    const int rc = spr_qr_step_f64(n_rows, r, step0 + t, d_rec, 1, d_tau, 1, t == 0, d_Q, d_piv, d_gap, d_ok, d_rec,
+                                   d_xyz, xyz_dim, n_points, d_min, d_workspace, workspace_bytes, stream);
+    if (rc != SPR_OK) return rc;
+  }
+  return SPR_OK;
+}
+
 extern "C" int spr_qr_exclude_f64(double *d_nrm, int64_t n_rows, int64_t row0, int64_t n_points,
                                   const uint8_t *d_mask, const double *d_xyz, int32_t xyz_dim,
                                   const int64_t *d_piv, int32_t nq, double d_min, void *stream) {

@@ -376,6 +376,13 @@ class HipEngine:
                                             xyz.shape[1] if xyz is not None else 0, n_points, float(d_min),
                                             _ptr(st['ws']), st['ws'].numel(), self._stream()), 'spr_qr_step_f64')
 
+    def qr_steps(self, st, step0, n_steps, xyz=None, n_points=0, d_min=0.0):
+        """Single GPU: n_steps consecutive candidate-set steps in one library call (spr_qr_steps_f64)."""
+        _lib.check(self.lib.spr_qr_steps_f64(st['n'], st['r'], step0, n_steps, _ptr(st['tau']), _ptr(st['Q']),
+                                             _ptr(st['piv']), _ptr(st['gap']), _ptr(st['ok']), _ptr(st['rec']), _ptr(xyz),
+                                             xyz.shape[1] if xyz is not None else 0, n_points, float(d_min),
+                                             _ptr(st['ws']), st['ws'].numel(), self._stream()), 'spr_qr_steps_f64')
+
     def qr_exclude(self, st, mask=None, xyz=None, n_points=1, j0=0, nq=0, d_min=0.0):
         """Rows outside `mask` (uint8 per local row) and rows closer than d_min to the picks piv[j0:j0+nq] leave
         the pool (spr_qr_exclude_f64)."""

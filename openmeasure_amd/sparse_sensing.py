@@ -165,7 +165,7 @@ def _eigh_small(G):
         return np.linalg.eigh(G)
 
 
-def pivot_loop(eng, st, s, all_gather=lambda t: t[None], start=0, near=None):
+def pivot_loop(eng, st, s, all_gather=None, start=0, near=None):
     """Host driver of the candidate-set pivoting (include/spr_hip.h, K6): batches of certified
     steps on the candidate set, one full sweep per batch.  Returns the number of sweeps over Ur.
     start: first step index (GEM keeps its centring direction in slot 0); near = (xyz, n_points, d_min):
@@ -174,9 +174,13 @@ def pivot_loop(eng, st, s, all_gather=lambda t: t[None], start=0, near=None):
     j, sweeps = start, 1
     while j < s:
         nb = min(eng.qr_batch, s - j)
-        taus = all_gather(st['tau'])
-        for t in range(nb):                                   # steps on the candidate set, no host sync
-            eng.qr_step(st, j + t, all_gather(st['rec']), taus, first=(t == 0), **kw)
+        if all_gather is None and hasattr(eng, 'qr_steps'):   # one rank: the whole batch in one library call
+            eng.qr_steps(st, j, nb, **kw)
+        else:
+            gather = all_gather if all_gather is not None else (lambda t: t[None])
+            taus = gather(st['tau'])
+            for t in range(nb):                               # steps on the candidate set, no host sync
+                eng.qr_step(st, j + t, gather(st['rec']), taus, first=(t == 0), **kw)
         ok = eng.to_host(st['ok'][j:j + nb])                   # one sync per batch
         k = nb if ok.all() else int(np.argmin(ok))             # certified prefix (>= 1 by construction)
         if k < 1:
@@ -765,7 +769,7 @@ class SPR(ROM):
             self._host.pop('Ur', None)
         s = self.r
         st = eng.qr_begin(Ur_d, self._row0, s)
-        sweeps = pivot_loop(eng, st, s, self._all_gather)
+        sweeps = pivot_loop(eng, st, s, self._all_gather if self._dist() else None)
         self.pivot_sweeps_ = sweeps
         piv = eng.to_host(st['piv']).astype(np.int64)
         self.sensors_ = piv
@@ -813,7 +817,7 @@ class SPR(ROM):
         if mask_d is not None:
             eng.qr_exclude(st, mask=mask_d, n_points=self.n_points)
         eng.qr_refresh(st, 0, 1)
-        sweeps = 1 + pivot_loop(eng, st, s + 1, self._all_gather, start=1, near=near)
+        sweeps = 1 + pivot_loop(eng, st, s + 1, self._all_gather if self._dist() else None, start=1, near=near)
         self.pivot_sweeps_ = sweeps
         piv = eng.to_host(st['piv'])[1:].astype(np.int64)
         self.sensors_ = piv

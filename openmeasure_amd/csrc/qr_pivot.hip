@@ -105,34 +105,60 @@ struct TopList {
       }
     }
   }
-  // QR_TOPT rounds of arg-max over the 256 x QR_TOPT list entries (wave 0), result sorted to out[QR_TOPT][2]
-  __device__ inline void block_merge(double *sval, long long *sidx, double *out) {
+  // Block-level merge, two levels: every wave extracts the QR_TOPT best of its own 64 x QR_TOPT entries (QR_TOPT
+  // rounds of arg-max, all waves in parallel), then wave 0 merges the waves' short lists; result sorted to
+  // out[QR_TOPT][2].  Order: value descending, lowest global row first among equals.
+  __device__ static inline void argmax_round(const double *sval, const long long *sidx, int first, int count, int lane,
+                                             double &bv, long long &bi, int &bp) {
+    bv = -3.0; bi = INT64_MAX; bp = -1;
+    for (int e = first + lane; e < first + count; e += 64) {
+      const double v = sval[e]; const long long i = sidx[e];
+      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bp = e; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(bv, o, 64);
+      const long long oi = __shfl_xor(bi, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = op; }
+    }
+  }
+  // Only `owner` lanes ever inserted rows (SPW of them per wave, numbered slot = 0..SPW-1): the staging area is
+  // QR_THREADS/64 x SPW x QR_TOPT entries, not one list per thread.
+  template <int SPW>
+  __device__ inline void block_merge(double *sval, long long *sidx, double *out, bool owner, int slot) {
+    constexpr int NWV = QR_THREADS / 64;
+    __shared__ double wv[NWV * QR_TOPT];
+    __shared__ long long wi[NWV * QR_TOPT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (owner) {
 #pragma unroll
-    for (int k = 0; k < QR_TOPT; ++k) {
-      sval[threadIdx.x * QR_TOPT + k] = tv[k];
-      sidx[threadIdx.x * QR_TOPT + k] = ti[k];
+      for (int k = 0; k < QR_TOPT; ++k) {
+        sval[(wave * SPW + slot) * QR_TOPT + k] = tv[k];
+        sidx[(wave * SPW + slot) * QR_TOPT + k] = ti[k];
+      }
     }
     __syncthreads();
-    if (wave == 0) {
+    for (int round = 0; round < QR_TOPT; ++round) {       // level 1: this wave's own SPW x QR_TOPT entries
+      double bv; long long bi; int bp;
+      argmax_round(sval, sidx, wave * SPW * QR_TOPT, SPW * QR_TOPT, lane, bv, bi, bp);
+      if (lane == 0) {
+        wv[wave * QR_TOPT + round] = bv;
+        wi[wave * QR_TOPT + round] = bi;
+        if (bp >= 0) sval[bp] = -3.0;
+      }
+      __builtin_amdgcn_wave_barrier();   // one wave per region: LDS accesses of a wave are issued and serviced in order
+    }
+    __syncthreads();
+    if (wave == 0) {                                      // level 2: NWV short lists
       for (int round = 0; round < QR_TOPT; ++round) {
-        double bv = -3.0; long long bi = INT64_MAX; int bp = -1;
-        for (int e = lane; e < QR_THREADS * QR_TOPT; e += 64) {
-          const double v = sval[e]; const long long i = sidx[e];
-          if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bp = e; }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-          const double ov = __shfl_xor(bv, o, 64);
-          const long long oi = __shfl_xor(bi, o, 64);
-          const int op = __shfl_xor(bp, o, 64);
-          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = op; }
-        }
+        double bv; long long bi; int bp;
+        argmax_round(wv, wi, 0, NWV * QR_TOPT, lane, bv, bi, bp);
         if (lane == 0) {
           out[2 * round] = bv > -2.5 ? bv : -2.0;
           out[2 * round + 1] = (double)(bv > -2.5 ? bi : -1);
-          if (bp >= 0) sval[bp] = -3.0;
+          if (bp >= 0) wv[bp] = -3.0;
         }
-        __builtin_amdgcn_wave_barrier();   // one wave only: LDS accesses of a wave are issued and serviced in order
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
@@ -154,11 +180,12 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
   constexpr int NW = QR_THREADS / 64, R = 64;
   constexpr int MPAD = 16 * MTR, MP = MPAD + 2, KSTEPS = MPAD / 4;
   using RT = RowTile<MTR, R, MP, NW, 16, TU>;
-  constexpr int PANELS = 2 * R * MP, MERGE = 2 * QR_THREADS * QR_TOPT;
+  constexpr int SPW = INIT ? 16 : 4;                       // lanes of a wave that own rows (and so a top list)
+  constexpr int PANELS = 2 * R * MP, MERGE = 2 * (QR_THREADS / 64) * SPW * QR_TOPT;
   __shared__ double smem[PANELS > MERGE ? PANELS : MERGE];    // panels during the sweep, merge lists afterwards
   double *const lds0 = smem, *const lds1 = smem + R * MP;
   double *const sval = smem;
-  long long *const sidx = reinterpret_cast<long long *>(smem + QR_THREADS * QR_TOPT);
+  long long *const sidx = reinterpret_cast<long long *>(smem + (QR_THREADS / 64) * SPW * QR_TOPT);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -240,7 +267,11 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
     }
   }
   __syncthreads();   // the panels are dead from here on: their LDS is reused for the merge
-  top.block_merge(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2);
+  // owners: refresh -- lanes 0/16/32/48 (rows a, a+4, a+8, a+12 of the block); init -- the lane holding the diagonal
+  // entry of its row, (lane & 15) = (lane >> 4) + 4 i
+  const bool owner = INIT ? (((lane & 15) & 3) == (lane >> 4)) : ((lane & 15) == 0);
+  const int slot = INIT ? ((lane >> 4) * 4 + ((lane & 15) >> 2)) : (lane >> 4);
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
 }
 
 // grid = sweep blocks: copy each block's top rows into the compact candidate arrays

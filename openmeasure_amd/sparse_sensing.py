@@ -490,6 +490,26 @@ class ROM:
         self._stats_pass(scale_type, axis_cnt)
         return self.X0
 
+    def scale_limits(self, limits):
+        """Reference :173-210 (the method GPR users call on the base class, tests/test_gpr_data.py:95): per-feature
+        limits -> per-row scaled limits [(limit_f - X_cnt)/X_scl], with the reference's +-1000 block clamps.
+        Host arithmetic on the (n_local,) centring vector; X_scl is one scalar per feature."""
+        X_cnt = self.X_cnt[:, 0]
+        feat = self._feature_rows()
+        out = []
+        for limit in limits:
+            limit = np.asarray(limit, dtype=np.float64)
+            limit0 = (limit[feat] - X_cnt) / self._scl_f[feat]
+            for f in range(self.n_features):                  # :200-203, per feature block (local rows of it)
+                sel = feat == f
+                if sel.any():
+                    if limit0[sel].min() < -1000:
+                        limit0[sel] = -1000
+                    elif limit0[sel].max() > 1000:
+                        limit0[sel] = 1000
+            out.append(limit0)
+        return out
+
     def _csr_device(self, C, known=None):
         """(indptr, indices, vals) device tensors of a dense / scipy.sparse matrix with n columns."""
         import scipy.sparse as sp

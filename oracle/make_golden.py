@@ -166,6 +166,27 @@ def run_gem_case(sps, name, X, n_features, n_modes, n_sensors, seed, d_min=0.0, 
     print(f'{name}: n={n} r={spr.r} gem picks={picks[0]} -> {os.path.getsize(path)/1e6:.2f} MB')
 
 
+def run_limits_case(sps, name, X, n_features, seed):
+    """ROM.scale_limits (:173-210), the method GPR users call on the base class (tests/test_gpr_data.py:95): one
+    ordinary pair of limits and one that trips the +-1000 clamps."""
+    if ONLY and name not in ONLY:
+        return
+    rng = np.random.default_rng(seed)
+    spr = sps.SPR(X.copy(), n_features, None)
+    spr.fit(select_modes='number', n_modes=3)
+    n_points = X.shape[0] // n_features
+    lo = np.array([X[f * n_points:(f + 1) * n_points].min() for f in range(n_features)]) - rng.random(n_features)
+    hi = np.array([X[f * n_points:(f + 1) * n_points].max() for f in range(n_features)]) + rng.random(n_features)
+    out = dict(X=X, n_features=np.int64(n_features), lo=lo, hi=hi, lo_far=lo - 1e4 * spr.X_scl[::n_points, 0],
+               hi_far=hi + 1e4 * spr.X_scl[::n_points, 0])
+    l0 = spr.scale_limits([lo, hi])
+    l1 = spr.scale_limits([out['lo_far'], out['hi_far']])
+    out.update(lim0_lo=l0[0], lim0_hi=l0[1], lim1_lo=l1[0], lim1_hi=l1[1])
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: limits0 range [{l0[0].min():.3g}, {l0[1].max():.3g}] clamped [{l1[0].min():.3g}, {l1[1].max():.3g}]')
+
+
 def main():
     sps = _import_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -194,6 +215,7 @@ def main():
     # scalar centring per feature (axis_cnt=None, tests/test_rom.py:23-29)
     run_case(sps, 'g6_axisnone', X, 3, 'number', 4, 600, axis_cnt=None)
     run_case(sps, 'g6_axisnone_pareto', X, 3, 'number', 5, 601, axis_cnt=None, scale_type='pareto')
+    run_limits_case(sps, 'lim_small', synth(40, 3, 8, 8, 0.7, 1e-3, 808), 3, 809)
     # GEM placement: distance exclusion, search mask, 2-D coordinates, the full r-1 sensors
     X = synth(300, 3, 12, 12, 0.7, 1e-3, 707)
     run_gem_case(sps, 'gem_dmin', X, 3, 8, 6, 701, d_min=0.15)

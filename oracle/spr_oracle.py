@@ -109,6 +109,26 @@ def scale_data_std(X, n_features, axis_cnt=1):
 # ----------------------------------------------------------------------------
 # a4  ROM.reduction                                sparse_sensing.py:314-338
 # ----------------------------------------------------------------------------
+def scale_limits(limits, X_cnt, X_scl, n_features):
+    """ROM.scale_limits (:173-210): per feature (limit_f - X_cnt)/X_scl on that feature's rows; a block whose
+    minimum falls below -1000 becomes the scalar -1000, else one whose maximum exceeds 1000 the scalar 1000 (:200-203)."""
+    n = X_cnt.shape[0]
+    n_points = n // n_features
+    out = []
+    for limit in limits:
+        limit0 = np.zeros((n,))
+        for i in range(n_features):
+            sl = slice(i * n_points, (i + 1) * n_points)
+            temp = (limit[i] - X_cnt[sl, 0]) / X_scl[sl, 0]
+            if np.min(temp) < -1000:
+                temp = -1000
+            elif np.max(temp) > 1000:
+                temp = 1000
+            limit0[sl] = temp
+        out.append(limit0)
+    return out
+
+
 def select_rank(exp_variance, n_cols, select_modes, n_modes):
     """How many modes survive -- the integer logic of ``ROM.reduction``.
 

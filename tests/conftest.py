@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 _ALL = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
-GOLDEN = [n for n in _ALL if not n.startswith('gem_')]       # fit -> qr placement -> train -> predict -> reconstruct
+GOLDEN = [n for n in _ALL if not n.startswith(('gem_', 'lim_'))]       # fit -> qr placement -> train -> predict -> reconstruct
 GOLDEN_GEM = [n for n in _ALL if n.startswith('gem_')]       # calc_type='gem' placement cases
 
 

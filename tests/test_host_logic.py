@@ -108,6 +108,19 @@ def test_median_scaling_by_radix_selection(n_points, F, m, seed):   # :140-141, 
     np.testing.assert_array_equal(rom.X_scl[:, 0], np.repeat(want, n_points))
 
 
+def test_scale_limits_matches_reference_fixture():      # :173-210
+    import os
+    from tests.conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'lim_small.npz'))
+    rom = ROM(g['X'].copy(), int(g['n_features']), None, engine=NumpyEngine())
+    rom.fit(select_modes='number', n_modes=3)
+    for (lo, hi, want_lo, want_hi) in ((g['lo'], g['hi'], g['lim0_lo'], g['lim0_hi']),
+                                       (g['lo_far'], g['hi_far'], g['lim1_lo'], g['lim1_hi'])):
+        got = rom.scale_limits([lo, hi])
+        np.testing.assert_allclose(got[0], want_lo, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(got[1], want_hi, rtol=1e-12, atol=1e-12)
+
+
 def test_empty_batches(small):                          # :863-864, :362-373 with n_p = 0
     X, F, xyz = small
     spr = SPR(X, F, xyz, engine=NumpyEngine())

@@ -161,3 +161,15 @@ def test_gem_pivots(golden_gem):                       # :586-698, noise-free li
     piv_n, _ = orc.gem_pivots(st['Ur'], g['n_sensors'], g['xyz'], g['n_features'], g.get('mask'), g['d_min'],
                               noise=lambda k: 1e-5 * rng.standard_normal(k))
     np.testing.assert_array_equal(piv_n, g['gem_piv'])
+
+
+def test_scale_limits():                               # :173-210, both the ordinary and the clamped branch
+    import os
+    from tests.conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'lim_small.npz'))
+    F = int(g['n_features'])
+    X_cnt, X_scl, _ = orc.scale_data(g['X'], F)
+    l0 = orc.scale_limits([g['lo'], g['hi']], X_cnt, X_scl, F)
+    l1 = orc.scale_limits([g['lo_far'], g['hi_far']], X_cnt, X_scl, F)
+    np.testing.assert_array_equal(l0[0], g['lim0_lo']); np.testing.assert_array_equal(l0[1], g['lim0_hi'])
+    np.testing.assert_array_equal(l1[0], g['lim1_lo']); np.testing.assert_array_equal(l1[1], g['lim1_hi'])

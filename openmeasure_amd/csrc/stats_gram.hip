@@ -39,7 +39,14 @@ template <int MT> struct GramCfg;
 template <> struct GramCfg<1>  { static constexpr int NW = 8,  R = 64, KS = 8; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
 template <> struct GramCfg<2>  { static constexpr int NW = 8,  R = 32, KS = 8; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
 template <> struct GramCfg<3>  { static constexpr int NW = 8,  R = 64, KS = 4; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
-template <> struct GramCfg<4>  { static constexpr int NW = 8,  R = 32, KS = 4; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
+// m in 49..64: 8 lanes per row (3 butterfly steps, 8 rows per wave instruction) on 64-row panels -- the centring pass is
+// what the short rows pay for (4 adds + 12 butterfly instructions + 4 subs per 4 rows with 16 lanes): 0.53 -> 0.46 ms
+// per 2.05 GB (4.0 -> 4.5 TB/s)
+#ifndef GRAM4_R
+#define GRAM4_R 64
+#define GRAM4_LPR 8
+#endif
+template <> struct GramCfg<4>  { static constexpr int NW = 8,  R = GRAM4_R, KS = 4; static constexpr bool DBUF = true; static constexpr int LPRMAX = GRAM4_LPR; };
 template <> struct GramCfg<6>  { static constexpr int NW = 12, R = 48, KS = 4; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
 template <> struct GramCfg<8>  { static constexpr int NW = 8,  R = 32, KS = 2; static constexpr bool DBUF = true; static constexpr int LPRMAX = 16; };
 template <> struct GramCfg<12> { static constexpr int NW = 12, R = 24, KS = 2; static constexpr bool DBUF = false; static constexpr int LPRMAX = 32; };

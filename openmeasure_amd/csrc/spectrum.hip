@@ -5,9 +5,10 @@
 // reference is actually used with (its own data set has m = 41) the host LAPACK call plus the
 // device->host->device round trip around it costs more than all the kernels of fit() together.
 // This kernel keeps the whole step on the device so that fit() issues no host synchronisation.
-// Measured on MI355X: 0.08 ms at m = 12, 0.64 ms at m = 41, 1.9 ms at m = 64 (11-14 sweeps of m-1
-// rounds with three workgroup barriers each: latency-bound) against ~0.3-0.5 ms for LAPACK dsyevd on the
-// host, so the Python layer only takes this path for m <= 24 and keeps dsyevd above that:
+// Measured on MI355X: 0.07 ms at m = 12, 0.39 ms at m = 41, 0.98 ms at m = 64 (11-14 sweeps of m-1
+// rounds, two workgroup barriers each: latency-bound, ~1.1 us per round) against ~0.3-0.5 ms for LAPACK dsyevd on
+// the host plus its round trip: fit() is faster through this kernel up to m = 24-28 (tools/spectrum_crossover.py),
+// so the Python layer takes this path for m <= 24 and keeps dsyevd above that:
 //   1. Chan-merge the per-rank feature statistics (rank order), block variance from trace(G_f) and
 //      M2, the per-feature scale of the chosen scale_type (:114-161);
 //   2. G = sum_f G_f / scl_f^2 in LDS;
@@ -36,6 +37,47 @@ __device__ inline double block_sum_all(double v, double *red) {
   double s = 0.0;
   for (int w = 0; w < SP_THREADS / 64; ++w) s += red[w];
   return s;
+}
+
+// pair k of round rd in the round-robin tournament over mp (even) indices, p < q
+__device__ inline void pair_of(int k, int rd, int mp, int &p, int &q) {
+  int a, b;
+  if (k == 0) { a = mp - 1; b = rd % (mp - 1); }
+  else { a = (rd + k) % (mp - 1); b = (rd - k + (mp - 1)) % (mp - 1); }
+  p = a < b ? a : b;
+  q = a < b ? b : a;
+}
+
+// 1/x and 1/sqrt(x) from the hardware approximations (v_rcp_f64 / v_rsq_f64) plus Newton steps: full double
+// accuracy without the long division / square-root sequences
+__device__ inline double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ inline double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+// Jacobi rotation that annihilates a_pq:  J = [[c, s], [-s, c]],  t = sign(tau) / (|tau| + sqrt(1 + tau^2)).
+// With u = 2 a_pq and w = a_qq - a_pp (tau = w / u):  t = sign(w u) |u| / (|w| + sqrt(w^2 + u^2)) -- no division
+// by the possibly tiny a_pq.
+__device__ inline void rotation(double app, double aqq, double apq, double &c, double &s) {
+  c = 1.0; s = 0.0;
+  if (fabs(apq) > 1e-300) {
+    const double u = 2.0 * apq, w = aqq - app;
+    const double h2 = fma(w, w, u * u);
+    const double h = h2 * fast_rsqrt(h2);                   // sqrt(w^2 + u^2)
+    double t = fabs(u) * fast_rcp(fabs(w) + h);
+    t = ((w >= 0.0) == (u >= 0.0)) ? t : -t;
+    c = fast_rsqrt(fma(t, t, 1.0));
+    s = t * c;
+  }
 }
 
 __global__ __launch_bounds__(SP_THREADS) void spectrum_kernel(
@@ -108,7 +150,15 @@ __global__ __launch_bounds__(SP_THREADS) void spectrum_kernel(
   for (int i = tid; i < m; i += SP_THREADS) V[i * LD + i] = 1.0;
   __syncthreads();
 
-  // ---- 3: cyclic Jacobi, round-robin pairing -------------------------------------------------
+  // ---- 3: cyclic Jacobi, round-robin pairing, two short phases per round ------------------------
+  // The mp/2 rotations of a round act on disjoint index pairs, so A' = J^T A J splits into (mp/2)^2 independent
+  // 2x2 blocks: block (a, b) = rows {p_a, q_a} x columns {p_b, q_b} needs only its own four entries and the two
+  // rotations (c_a, s_a), (c_b, s_b).  Phase A: P lanes of wave 0 compute the rotations (reciprocal / reciprocal
+  // square root instructions + Newton steps instead of the division and square-root sequences: this chain is the
+  // critical path of a round).  Phase B: thread t = a P + b updates its block of A and two rows of V in place.
+  const int P = mp / 2;
+  const int ba = tid / P, bb = tid - ba * P;               // this thread's block (a, b); idle when tid >= P * P
+  const bool active = tid < P * P;
   int sweeps = 0;
   double off2 = 0.0, diag2 = 0.0;
   for (; sweeps < SP_MAX_SWEEPS; ++sweeps) {
@@ -122,41 +172,30 @@ __global__ __launch_bounds__(SP_THREADS) void spectrum_kernel(
     diag2 = block_sum_all(d, red);
     if (off2 <= 1e-31 * diag2) break;
     for (int rd = 0; rd < mp - 1; ++rd) {
-      if (tid < mp / 2) {
-        int a, b;
-        if (tid == 0) { a = mp - 1; b = rd % (mp - 1); }
-        else { a = (rd + tid) % (mp - 1); b = (rd - tid + (mp - 1)) % (mp - 1); }
-        const int p = a < b ? a : b, q = a < b ? b : a;
-        const double apq = A[p * LD + q];
-        double c = 1.0, s = 0.0;
-        if (fabs(apq) > 1e-300) {
-          const double tau = (A[q * LD + q] - A[p * LD + p]) / (2.0 * apq);
-          const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + t * t);
-          s = t * c;
+      if (tid < P) {
+        int p, q;
+        pair_of(tid, rd, mp, p, q);
+        double c, sv;
+        rotation(A[p * LD + p], A[q * LD + q], A[p * LD + q], c, sv);
+        cs[tid] = c; sn[tid] = sv; pp[tid] = p; qq[tid] = q;
+      }
+      __syncthreads();
+      if (active) {
+        const int pa = pp[ba], qa = qq[ba], pb = pp[bb], qb = qq[bb];
+        const double ca = cs[ba], sa = sn[ba], cb = cs[bb], sb = sn[bb];
+        // B = [[x00, x01], [x10, x11]] on rows (pa, qa), columns (pb, qb);  B' = Ja^T B Jb,  J = [[c, s], [-s, c]]
+        const double x00 = A[pa * LD + pb], x01 = A[pa * LD + qb], x10 = A[qa * LD + pb], x11 = A[qa * LD + qb];
+        const double y00 = ca * x00 - sa * x10, y01 = ca * x01 - sa * x11;     // rows: J^T from the left
+        const double y10 = sa * x00 + ca * x10, y11 = sa * x01 + ca * x11;
+        A[pa * LD + pb] = cb * y00 - sb * y01;  A[pa * LD + qb] = sb * y00 + cb * y01;   // columns: J from the right
+        A[qa * LD + pb] = cb * y10 - sb * y11;  A[qa * LD + qb] = sb * y10 + cb * y11;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                            // V <- V Jb on rows 2a, 2a+1
+          const int i = 2 * ba + h;
+          const double vp = V[i * LD + pb], vq = V[i * LD + qb];
+          V[i * LD + pb] = cb * vp - sb * vq;
+          V[i * LD + qb] = sb * vp + cb * vq;
         }
-        cs[tid] = c; sn[tid] = s; pp[tid] = p; qq[tid] = q;
-      }
-      __syncthreads();
-      for (int e = tid; e < (mp / 2) * mp; e += SP_THREADS) {          // rows p, q:  A <- J^T A
-        const int k = e / mp, j = e - k * mp;
-        const int p = pp[k], q = qq[k];
-        const double c = cs[k], s = sn[k];
-        const double ap = A[p * LD + j], aq = A[q * LD + j];
-        A[p * LD + j] = c * ap - s * aq;
-        A[q * LD + j] = s * ap + c * aq;
-      }
-      __syncthreads();
-      for (int e = tid; e < (mp / 2) * mp; e += SP_THREADS) {          // columns p, q:  A <- A J,  V <- V J
-        const int k = e / mp, i = e - k * mp;
-        const int p = pp[k], q = qq[k];
-        const double c = cs[k], s = sn[k];
-        const double ap = A[i * LD + p], aq = A[i * LD + q];
-        A[i * LD + p] = c * ap - s * aq;
-        A[i * LD + q] = s * ap + c * aq;
-        const double vp = V[i * LD + p], vq = V[i * LD + q];
-        V[i * LD + p] = c * vp - s * vq;
-        V[i * LD + q] = s * vp + c * vq;
       }
       __syncthreads();
     }

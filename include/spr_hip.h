@@ -304,6 +304,11 @@ int spr_project_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t 
                            int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
                            const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
                            int32_t accumulate, void *stream);
+/* ... and its last slice: adds the f64 partial sums d_acc_in (row stride lda) and stores the f32 total in d_Ur */
+int spr_project_x32_acc(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                        int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                        const double *d_rowmean, const double *d_W, int32_t r, const double *d_acc_in,
+                        int64_t lda, float *d_Ur, int64_t ldu, void *stream);
 int spr_scale_rows_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                        int64_t n_points, int32_t n_features, const double *d_rowmean,
                        const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream);

@@ -72,6 +72,8 @@ class SprError(RuntimeError):
     """A libspr_hip.so call returned a negative status."""
 
 
+PROTOTYPES['spr_project_x32_acc'] = (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p, _i64, _p])
+
 # f32-storage twins: identical argument lists (the typed pointer is a void* here)
 for _f64, _x32 in (('spr_stats_gram_f64', 'spr_stats_gram_x32'), ('spr_rowstats_f64', 'spr_rowstats_x32'),
                    ('spr_gram_cross_f64', 'spr_gram_cross_x32'), ('spr_project_f64', 'spr_project_x32'),

@@ -41,11 +41,11 @@ template <int MT> struct ProjRows { static constexpr int R = (MT >= 12) ? 32 : 6
 
 // TX: storage type of the snapshot shard, TU: storage type of the basis (f64, or f32 rounded from the f64 result --
 // the reference's own U has the dtype of its X); the arithmetic is f64 either way.
-template <int MT, int RTILES, int VEC, typename TX, typename TU>
+template <int MT, int RTILES, int VEC, typename TX, typename TU, bool ACCIN>
 __global__ __launch_bounds__(NW * 64) void project_kernel(
     const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
     const double *__restrict__ inv_scale, const double *__restrict__ rowmean, const double *__restrict__ W, int r,
-    TU *__restrict__ Ur, int64_t ldu, int accumulate) {
+    TU *__restrict__ Ur, int64_t ldu, int accumulate, const double *__restrict__ acc_in, int64_t lda) {
   constexpr int R = ProjRows<MT>::R;
   constexpr int MPAD = 16 * MT, MP = MPAD + PROJ_PAD;
   constexpr int KSTEPS = MPAD / 4;
@@ -154,10 +154,15 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
               Ur[(row + 8) * ldu + col] = (TU)s2;
               Ur[(row + 12) * ldu + col] = (TU)s3;
             } else if (col < r) {                              // accumulate: second column slice of a wide X
-              if (row < hi) Ur[row * ldu + col] = (TU)((accumulate ? (double)Ur[row * ldu + col] : 0.0) + s0);
-              if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (TU)((accumulate ? (double)Ur[(row + 4) * ldu + col] : 0.0) + s1);
-              if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (TU)((accumulate ? (double)Ur[(row + 8) * ldu + col] : 0.0) + s2);
-              if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (TU)((accumulate ? (double)Ur[(row + 12) * ldu + col] : 0.0) + s3);
+              // accumulate: the earlier slices' partial sum comes from Ur itself, or from a separate f64 block
+              // (acc_in) when Ur is stored narrower than the partial sums may be rounded to
+              auto prev = [&](int64_t rr) {
+                return ACCIN ? acc_in[rr * lda + col] : (double)Ur[rr * ldu + col];
+              };
+              if (row < hi) Ur[row * ldu + col] = (TU)((accumulate ? prev(row) : 0.0) + s0);
+              if (row + 4 < hi) Ur[(row + 4) * ldu + col] = (TU)((accumulate ? prev(row + 4) : 0.0) + s1);
+              if (row + 8 < hi) Ur[(row + 8) * ldu + col] = (TU)((accumulate ? prev(row + 8) : 0.0) + s2);
+              if (row + 12 < hi) Ur[(row + 12) * ldu + col] = (TU)((accumulate ? prev(row + 12) : 0.0) + s3);
             }
           }
         }
@@ -180,11 +185,11 @@ __global__ __launch_bounds__(NW * 64) void project_kernel(
 template <int MT, int RTILES, typename TX, typename TU>
 int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
            int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
-           TU *Ur, int64_t ldu, int accumulate, hipStream_t st) {
+           TU *Ur, int64_t ldu, int accumulate, const double *acc_in, int64_t lda, hipStream_t st) {
   static int total_wg = 0;
   if (!total_wg) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES, 2, TX, TU>, NW * 64, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, project_kernel<MT, RTILES, 2, TX, TU, false>, NW * 64, 0) !=
             hipSuccess || per_cu < 1)
       per_cu = 1;
     if (per_cu > 4) per_cu = 4;
@@ -197,9 +202,17 @@ int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, in
   const int grid = seg_total_wgs(plan);
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
   const int lm = vec_ok ? ((m == 16 * MT) ? 2 : 1) : 0;
+  // the separate f64 partial-sum input only exists for an f32 basis; every other instantiation keeps its register budget
+  constexpr bool CAN_ACC = std::is_same<TU, float>::value;
 #define PJ_LAUNCH(LM)                                                                                         \
-  hipLaunchKernelGGL((project_kernel<MT, RTILES, LM, TX, TU>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, center, \
-                     plan, inv_scale, rowmean, W, (int)r, Ur, ldu, accumulate)
+  do {                                                                                                        \
+    if (CAN_ACC && acc_in)                                                                                    \
+      hipLaunchKernelGGL((project_kernel<MT, RTILES, LM, TX, TU, CAN_ACC>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, \
+                         center, plan, inv_scale, rowmean, W, (int)r, Ur, ldu, accumulate, acc_in, lda);      \
+    else                                                                                                      \
+      hipLaunchKernelGGL((project_kernel<MT, RTILES, LM, TX, TU, false>), dim3(grid), dim3(NW * 64), 0, st, X, ldx, (int)m, \
+                         center, plan, inv_scale, rowmean, W, (int)r, Ur, ldu, accumulate, acc_in, lda);      \
+  } while (0)
   if (lm == 2) PJ_LAUNCH(2);
   else if (lm == 1) PJ_LAUNCH(1);
   else PJ_LAUNCH(0);
@@ -211,12 +224,12 @@ int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, in
 template <int MT, typename TX, typename TU>
 int launch_rt(int rt, const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
               int32_t n_features, int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r,
-              TU *Ur, int64_t ldu, int accumulate, hipStream_t st) {
+              TU *Ur, int64_t ldu, int accumulate, const double *acc_in, int64_t lda, hipStream_t st) {
   switch (rt) {
-    case 1: return launch<MT, 1, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
-    case 2: return launch<MT, 2, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
-    case 4: return launch<MT, 4, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
-    case 8: return launch<MT, 8, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, st);
+    case 1: return launch<MT, 1, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, acc_in, lda, st);
+    case 2: return launch<MT, 2, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, acc_in, lda, st);
+    case 4: return launch<MT, 4, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, acc_in, lda, st);
+    case 8: return launch<MT, 8, TX, TU>(X, n_rows, m, ldx, row0, n_points, n_features, center, inv_scale, rowmean, W, r, Ur, ldu, accumulate, acc_in, lda, st);
   }
   spr_set_error("spr_project_f64: r tile count %d not built", rt);
   return SPR_E_UNSUPPORTED;
@@ -225,7 +238,9 @@ int launch_rt(int rt, const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64
 template <typename TX, typename TU>
 int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
                   int32_t n_features, int32_t center, const double *d_inv_scale, const double *d_rowmean,
-                  const double *d_W, int32_t r, TU *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
+                  const double *d_W, int32_t r, TU *d_Ur, int64_t ldu, int32_t accumulate, void *stream,
+                  const double *d_acc_in = nullptr, int64_t lda = 0) {
+  SPR_REQUIRE(!d_acc_in || (accumulate && lda >= r), SPR_E_INVALID, "%s: acc_in needs accumulate = 1 and lda >= r", who);
   SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && (d_rowmean || !center), SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "%s: bad shape", who);
   SPR_REQUIRE(r > 0 && ldu >= r, SPR_E_INVALID, "%s: bad r=%d (m=%d ldu=%lld)", who, r, m, (long long)ldu);
@@ -243,7 +258,7 @@ int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int
   const int need = (r + 15) / 16;
   const int rt = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define PJ(MTV) return launch_rt<MTV, TX, TU>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, st)
+#define PJ(MTV) return launch_rt<MTV, TX, TU>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, d_acc_in, lda, st)
   switch (spr_round_mt(m)) {
     case 1: PJ(1);
     case 2: PJ(2);
@@ -285,4 +300,15 @@ extern "C" int spr_project_x32_f64out(const float *d_X, int64_t n_rows, int32_t 
                                       int32_t r, double *d_Ur, int64_t ldu, int32_t accumulate, void *stream) {
   return project_entry("spr_project_x32_f64out", d_X, n_rows, m, ldx, row0, n_points, n_features, center,
                        d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, stream);
+}
+
+// last column slice of a wide f32 shard: adds the f64 partial sums of the earlier slices (d_acc_in, row stride lda) to
+// this slice's product and stores the total, rounded to f32 ONCE, in d_Ur -- no separate conversion pass
+extern "C" int spr_project_x32_acc(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                   int64_t n_points, int32_t n_features, int32_t center,
+                                   const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
+                                   const double *d_acc_in, int64_t lda, float *d_Ur, int64_t ldu, void *stream) {
+  SPR_REQUIRE(d_acc_in != nullptr, SPR_E_INVALID, "spr_project_x32_acc: acc_in is NULL");
+  return project_entry("spr_project_x32_acc", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                       d_rowmean, d_W, r, d_Ur, ldu, 1, stream, d_acc_in, lda);
 }

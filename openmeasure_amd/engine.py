@@ -255,16 +255,23 @@ class HipEngine:
             # f64 block of rows and are rounded to f32 once (a dtype-converting copy)
             block = self._PROJECT_BLOCK_ROWS
             scratch = self.empty((min(block, n), ldu))
-            esz, fn = X.element_size(), self.lib.spr_project_x32_f64out
+            esz = X.element_size()
             for i0 in range(0, n, block):
                 rows = min(block, n - i0)
+                mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
+                last = len(slices) - 1
                 for k, (c0, width) in enumerate(slices):
-                    _lib.check(fn(X.data_ptr() + (i0 * ld + c0) * esz, rows, width, ld, row0 + i0, n_points, n_features,
-                                  int(bool(center)), _ptr(inv_scale),
-                                  rowmean.data_ptr() + i0 * rowmean.element_size() if center else None,
-                                  Wc.data_ptr() + c0 * r * Wc.element_size(), r, _ptr(scratch), ldu, int(k > 0),
-                                  self._stream()), 'spr_project_x32_f64out')
-                buf[i0:i0 + rows].copy_(scratch[:rows, :buf.shape[1]])
+                    xp, wp = X.data_ptr() + (i0 * ld + c0) * esz, Wc.data_ptr() + c0 * r * Wc.element_size()
+                    if k < last:                              # partial sums stay f64
+                        _lib.check(self.lib.spr_project_x32_f64out(xp, rows, width, ld, row0 + i0, n_points, n_features,
+                                                                   int(bool(center)), _ptr(inv_scale), mean_p, wp, r,
+                                                                   _ptr(scratch), ldu, int(k > 0), self._stream()),
+                                   'spr_project_x32_f64out')
+                    else:                                     # last slice: f64 total, rounded once into the f32 basis
+                        _lib.check(self.lib.spr_project_x32_acc(xp, rows, width, ld, row0 + i0, n_points, n_features,
+                                                                int(bool(center)), _ptr(inv_scale), mean_p, wp, r,
+                                                                _ptr(scratch), ldu, buf.data_ptr() + i0 * ldu * buf.element_size(),
+                                                                ldu, self._stream()), 'spr_project_x32_acc')
         else:
             for k, (c0, width) in enumerate(slices):
                 _lib.check(self._x('spr_project', X)(X.data_ptr() + c0 * X.element_size(), n, width, ld, row0, n_points,

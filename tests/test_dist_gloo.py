@@ -188,3 +188,44 @@ def test_sharded_f32_storage(tmp_path):
         assert rel_fro(o['X3'], X3) <= REL_FRO and rel_fro(o['X3'], g['X_rec3']) <= 1e-5
         sgn = np.sign(np.sum(o['Ur'].astype(np.float64) * one.Ur[r * n_loc:(r + 1) * n_loc], axis=0))
         np.testing.assert_allclose(o['Ur'] * sgn, one.Ur[r * n_loc:(r + 1) * n_loc], atol=2e-7)
+
+
+def _loop_worker(rank, world, port, fixture, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden
+        from tests.numpy_engine import NumpyEngine
+        g = load_golden(fixture)
+        n = g['X'].shape[0]
+        n_loc = n // world
+        row0 = rank * n_loc
+        spr = SPR(np.ascontiguousarray(g['X'][row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
+                  engine=NumpyEngine())
+        fields, prev = [], None
+        for it in range(3):                                   # the step loop of bench.py: the gather of step k is joined
+            spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])   # only after the fit of step k+1
+            if prev is not None:
+                fields.append(prev.wait().numpy().copy())
+            prev = spr.reconstruct(spr.Ar[:2] * (it + 1), to_host=False, wait=False)
+        fields.append(prev.wait().numpy().copy())
+        ref = spr.reconstruct(spr.Ar[:2] * 3)                 # synchronous path, same coefficients as the last step
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), f0=fields[0], f1=fields[1], f2=fields[2], ref=ref)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_field_gather_loop(tmp_path):
+    """bench.py's step loop over two ranks: at most one field all-gather in flight, joined after the next fit."""
+    from tests.conftest import load_golden
+    g = load_golden('g2_num4')
+    mp.spawn(_loop_worker, args=(2, _free_port(), 'g2_num4', str(tmp_path)), nprocs=2, join=True)
+    outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(2)]
+    for o in outs:
+        np.testing.assert_array_equal(o['f2'].T, o['ref'])
+        np.testing.assert_allclose(o['f1'] - o['f0'], o['f2'] - o['f1'], rtol=0, atol=1e-9 * np.abs(o['f2']).max())
+        np.testing.assert_array_equal(o['f2'], outs[0]['f2'])
+    assert outs[0]['f2'].shape == (2, g['X'].shape[0])

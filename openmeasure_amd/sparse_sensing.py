@@ -15,8 +15,10 @@ but the arithmetic runs in hand-written gfx950 kernels behind ``libspr_hip.so``
     (:112, :115, :169)                               Welford stats, per-feature f64-MFMA Gram
   np.linalg.svd(X0) (:272)                         m x m eigen-problem of the Gram matrix (host,
                                                      tiny) + MFMA projection Ur = X0 V S^-1
-  scipy.linalg.qr(Ur.T, pivoting=True) (:739)      greedy residual-norm pivoting, r streaming
-                                                     sweeps over Ur
+  scipy.linalg.qr(Ur.T, pivoting=True) (:739)      greedy residual-norm pivoting on a candidate
+                                                     set, a handful of MFMA sweeps over Ur
+  SPR.gem (:586-698)                               the same pivoting on row-centred rows with the
+                                                     search mask and d_min exclusion
   C.dot(Ur), C.dot(X_cnt) (:797, :573)             CSR row gather / SpMM
   np.linalg.pinv(W Theta) ... (:873-878)           MFMA normal equations + Cholesky per vector
   Ur @ Ar.T, unscale_data (:371-373, :235)         one streaming GEMV with fused un-scaling
@@ -28,9 +30,10 @@ What differs from the reference, by design:
     mode that row-centring always creates when r = m) is numerically meaningless in both;
   * fitted arrays live in HBM; ``X_cnt``, ``X_scl``, ``Ur``, ... are copied to NumPy on
     first access;
-  * options that have no device implementation yet ('gem' placement, 'COLS', scalings
-    'median' / 'vast_2..4') raise ``NotImplementedError`` --
-    they never fall back to a CPU path.
+  * a float32 X is stored as float32 (and so is Ur); all arithmetic is float64;
+  * options that have no device implementation ('COLS', 'gem' beyond r-1 sensors, the
+    kurtosis scalings 'vast_2..4', which are ill-defined in the reference itself) raise
+    ``NotImplementedError`` -- they never fall back to a CPU path.
 
 Row sharding: pass ``shard=RowShard(row0, n_global, group)`` and the local block of rows;
 the Gram matrix is all-reduced, pivot candidates are all-gathered per step, Theta is
@@ -40,7 +43,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix']
+__all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix', 'PendingField']
 
 _DEVICE_SPECTRUM_MAX_M = 24   # above this the single-workgroup Jacobi is slower than host dsyevd (csrc/spectrum.hip)
 _DENSE_C_LIMIT = 1 << 26   # optimal_placement returns a dense ndarray below this many bytes (64 MiB)

@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """SPR fit+reconstruct throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|...]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one pass of the hot path over a synthetic snapshot shard that already sits in
 HBM:   SPR.fit(select_modes='number', n_modes=s)  +  SPR.reconstruct(a)  (one vector).
 value = bytes of the snapshot matrix (all ranks) / max-over-ranks wall time of K steps.
-Weak scaling: every rank holds one workload-sized shard, the global matrix has N times the
-cells; per step there is one RCCL all-reduce (per-feature Gram) and one all-gather (field).
+
+N > 1.  One process per GPU over RCCL.  When the ranks' environment (WORLD_SIZE/RANK) is absent,
+`python bench.py --gpus N` starts the N rank processes ITSELF -- before anything in this process
+touches the GPU -- waits for them and relays rank 0's JSON line; a failed rank ends the run with a
+non-zero exit code.  The default workload for N > 1 is BASELINE config 4: the SAME 10M-cell x 9 x 256
+matrix as config 3, row-sharded over the N GPUs (strong scaling: 90M/N rows per rank, features
+straddle the shards); `--scaling weak` gives every rank a full workload-sized shard instead.
+Per step there is one RCCL all-reduce (per-feature Gram) and one all-gather (field).
 
 The JSON line also carries
   roofline      the dominant kernel (the fused stats+Gram pass), timed live with HIP events on
                 its launch stream; algorithmic flops/bytes per launch from SURVEY.md 8(d);
+                roofline_per_rank repeats it for every rank when N > 1;
   cpu_baseline  the NumPy/LAPACK oracle (oracle/spr_oracle.py) timed on this host's cores on a
                 bounded sample of the same workload (rank 0, N=1 only);
   phases, parity  extra evidence (per-kernel ms, GPU-vs-oracle agreement on the sample).
@@ -20,6 +27,8 @@ The JSON line also carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,16 +39,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # BASELINE.json configs (cells, features, snapshots, sensors); c1 is the reference's own
-# CPU-sized case, c2/c3 the single-GPU cases, c3 the one the north_star target is quoted on.
+# CPU-sized case, c2/c3 the single-GPU cases, c3 the one the north_star target is quoted on,
+# c4 the same matrix sharded over the GPUs of the node, c5 the one that exceeds a single GPU.
 WORKLOADS = {
     'c1': dict(cells=18_362, features=9, m=41, s=14, cpu_cells=18_362),
     'c2': dict(cells=1_000_000, features=4, m=64, s=32, cpu_cells=1_000_000),
     'c3': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=100_000),
+    # config 4: config 3's matrix, 10M cells IN TOTAL, split into 10M/N cells' worth of rows per rank
+    'c4': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=100_000, scaling='strong'),
     'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000),   # c3 at 1/10 of the rows
     # config-5 shape (16 features x 512 snapshots, 128 sensors) in f64 at 1M cells/GPU (65.5 GB): the column-split path
     'c5s': dict(cells=1_000_000, features=16, m=512, s=128, cpu_cells=15_000),
     # config 5 as BASELINE.json states it: 50M cells x 16 features x 512 snapshots over 8 GPUs = 6.25M cells (100M
-    # rows) per GPU, which only fits in f32 STORAGE (204.8 GB shard + 51.2 GB basis); arithmetic stays f64
+    # rows) per GPU, which only fits in f32 STORAGE (204.8 GB shard + 51.2 GB basis); arithmetic stays f64.
+    # Weak by construction: at --gpus 8 it IS config 5, at --gpus 1 it is one GPU's share of it.
     'c5': dict(cells=6_250_000, features=16, m=512, s=128, cpu_cells=15_000, storage='f32'),
     'c5s32': dict(cells=1_000_000, features=16, m=512, s=128, cpu_cells=15_000, storage='f32'),
     'c3s32': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000, storage='f32'),
@@ -52,47 +65,165 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+# ---------------------------------------------------------------------------------------------
+# shard arithmetic and rank launcher (also driven by tests/test_bench_launcher.py over gloo)
+# ---------------------------------------------------------------------------------------------
+def shard_plan(wl, world, rank, scaling='auto'):
+    """Rows of the global feature-major matrix held by `rank` of `world`.
+
+    strong: the workload's cells are the TOTAL (config 4); every rank holds n_glob/world contiguous rows, so features
+            straddle the shard boundaries.  The cell count is rounded down to a multiple of `world` so that all
+            ranks hold the same number of rows (the field all-gather needs equal shards).
+    weak:   every rank adds one workload-sized block of cells; the global matrix has world x the cells.
+    """
+    mode = wl.get('scaling', 'weak') if scaling == 'auto' else scaling
+    if mode not in ('weak', 'strong'):
+        raise ValueError(f'scaling={scaling!r}')
+    F = wl['features']
+    if mode == 'strong':
+        n_points = (wl['cells'] // world) * world
+        if n_points < world:
+            raise ValueError('fewer cells than ranks')
+    else:
+        n_points = wl['cells'] * world
+    n_glob = n_points * F
+    n_loc = n_glob // world
+    assert n_loc * world == n_glob
+    return dict(scaling=mode, n_points=n_points, n_glob=n_glob, n_loc=n_loc, row0=rank * n_loc)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, env_extra=None, timeout=None, relay=sys.stdout):
+    """Start `n` rank processes running `argv` (a full command line), one per GPU, with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for them.  The caller must not have touched
+    the GPU: the children are fresh processes (never an exec of this one).  Rank 0's stdout is relayed line by line;
+    the other ranks' stdout goes to stderr.  Returns the exit code: 0 when every rank succeeded, else the first
+    failing rank's code (the remaining ranks are terminated by PID)."""
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on these hosts (RCCL needs it)
+        if env_extra:
+            env.update(env_extra)
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=(rank == 0)))
+    t_end = None if timeout is None else time.time() + timeout
+    rc = 0
+    out0 = procs[0].stdout
+    import threading
+
+    def pump():
+        for line in out0:
+            relay.write(line)
+            relay.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                log(f'[launcher] rank {r} exited with code {code}; stopping the other ranks')
+                for o in live:
+                    procs[o].terminate()
+        if t_end is not None and time.time() > t_end and live:
+            log('[launcher] timeout; stopping all ranks')
+            rc = rc or 124
+            for o in live:
+                procs[o].terminate()
+            t_end = None
+        time.sleep(0.05)
+    th.join(timeout=5)
+    return rc
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default=os.environ.get('SPR_BENCH_WORKLOAD', 'c3'), choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default=os.environ.get('SPR_BENCH_WORKLOAD'), choices=sorted(WORKLOADS),
+                    help='default: c3 on one GPU, c4 (config 3 sharded, strong scaling) on several')
+    ap.add_argument('--scaling', default='auto', choices=('auto', 'weak', 'strong'),
+                    help="auto = the workload's own mode (c4: strong, the others: weak)")
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline / parity leg')
     ap.add_argument('--extra', action='store_true', help='also time placement/train/predict')
     ap.add_argument('--sync-gather', action='store_true',
                     help='join the field all-gather at the end of every step instead of overlapping it with the next Gram pass')
-    args = ap.parse_args()
+    ap.add_argument('--share-of', type=int, default=0, metavar='N',
+                    help="developer aid: run ONE rank's shard of an N-rank job on this GPU (collectives in a 1-rank RCCL "
+                         'group); the line says so and is not an N-GPU number')
+    ap.add_argument('--share-rank', type=int, default=0, help='which rank of --share-of')
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.workload is None:
+        args.workload = 'c3' if args.gpus == 1 else 'c4'
+    return args
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU
+        # (device_count() below does not initialise it either).
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            log(f'bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)')
+            sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    run_rank(args)
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
     from openmeasure_amd.engine import HipEngine
     from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix, RowShard
     from openmeasure_amd.synth import make_R
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    env_world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        log(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE')
+    if env_world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU '
+                         '(or drop WORLD_SIZE and let bench.py start the ranks)')
     torch.cuda.set_device(local_rank)
-    force_dist = os.environ.get('SPR_FORCE_DIST', '0') == '1'      # exercise the RCCL path with one rank
-    if world > 1 or force_dist:
+    share = args.share_of if args.share_of > 1 else 0
+    force_dist = os.environ.get('SPR_FORCE_DIST', '0') == '1' or bool(share)   # exercise the RCCL path with one rank
+    if env_world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        world = dist.get_world_size()                 # the RCCL communicator's size is what gets reported
+    else:
+        world = 1
+    assert world == args.gpus, f'RCCL world size {world} != --gpus {args.gpus}'
 
     wl = WORKLOADS[args.workload]
     F, m, s = wl['features'], wl['m'], wl['s']
     f32 = wl.get('storage') == 'f32'
     B = 4 if f32 else 8                           # bytes per stored element of X and Ur
-    cells_loc = wl['cells']                       # cells added per rank (weak scaling)
-    n_points = cells_loc * world                  # global cells
-    n_glob = n_points * F
-    n_loc = cells_loc * F                         # rows per rank: contiguous block of the global matrix
-    row0 = rank * n_loc
+    if share:
+        plan = shard_plan(wl, share, args.share_rank, args.scaling)
+    else:
+        plan = shard_plan(wl, world, rank, args.scaling)
+    n_points, n_glob, n_loc, row0 = plan['n_points'], plan['n_glob'], plan['n_loc'], plan['row0']
     seed, eps = 1234, 1e-3
 
     eng = HipEngine(f'cuda:{local_rank}')
@@ -100,9 +231,14 @@ def main():
     t0 = time.time()
     Xd = eng.synth(n_loc, m, row0, n_points, R, eps, seed, dtype=torch.float32 if f32 else None)
     torch.cuda.synchronize()
-    log(f'[rank {rank}] generated {n_loc} x {m} {"f32" if f32 else "f64"} shard ({n_loc * m * B / 1e9:.2f} GB) in {time.time() - t0:.2f}s')
+    log(f'[rank {rank}] generated rows [{row0}, {row0 + n_loc}) x {m} {"f32" if f32 else "f64"} '
+        f'({n_loc * m * B / 1e9:.2f} GB) of {n_glob} global rows in {time.time() - t0:.2f}s')
 
-    shard = RowShard(row0, n_glob, force_collectives=force_dist) if (world > 1 or force_dist) else None
+    if share:
+        # one rank's block of an N-rank job, alone: the global row numbering (feature boundaries) of the N-rank job
+        shard = RowShard(row0, n_glob, force_collectives=True, partial=True)
+    else:
+        shard = RowShard(row0, n_glob, force_collectives=force_dist) if (world > 1 or force_dist) else None
     spr = SPR(DeviceMatrix(Xd), F, None, shard=shard, engine=eng)
 
     def barrier():
@@ -142,7 +278,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = 1e3 * dt / args.steps
-    x_bytes = float(n_glob) * m * B
+    n_job = n_loc if share else n_glob            # rows this run actually processed (a share run: one rank's block)
+    x_bytes = float(n_job) * m * B
     value = x_bytes / (dt / args.steps) / 1e9
 
     k_ms = {k: float(np.mean([tm[i][0].elapsed_time(tm[i][1]) for tm in timers]))
@@ -156,29 +293,49 @@ def main():
     }
     phases = {k: dict(ms=round(k_ms[k], 4), GBs=round(alg[k]['bytes'] / k_ms[k] / 1e6, 1),
                       TFLOPs=round(alg[k]['flops'] / k_ms[k] / 1e9, 3)) for k in k_ms}
-    dom = max(k_ms, key=k_ms.get)
-    t_bytes = alg[dom]['bytes'] / (HBM_PEAK_GBS * 1e9)
-    t_flops = alg[dom]['flops'] / (MFMA_F64_PEAK_TF * 1e12)
-    if t_flops > t_bytes:
-        roof = dict(kernel=dom, bound='mfma', achieved=round(alg[dom]['flops'] / k_ms[dom] / 1e9, 3),
-                    peak=MFMA_F64_PEAK_TF, unit='TFLOP/s')
-    else:
-        roof = dict(kernel=dom, bound='hbm', achieved=round(alg[dom]['bytes'] / k_ms[dom] / 1e6, 1),
-                    peak=HBM_PEAK_GBS, unit='GB/s')
-    roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+
+    def roofline_of(kms):
+        dom = max(kms, key=kms.get)
+        t_bytes = alg[dom]['bytes'] / (HBM_PEAK_GBS * 1e9)
+        t_flops = alg[dom]['flops'] / (MFMA_F64_PEAK_TF * 1e12)
+        if t_flops > t_bytes:
+            rf = dict(kernel=dom, bound='mfma', achieved=round(alg[dom]['flops'] / kms[dom] / 1e9, 3),
+                      peak=MFMA_F64_PEAK_TF, unit='TFLOP/s')
+        else:
+            rf = dict(kernel=dom, bound='hbm', achieved=round(alg[dom]['bytes'] / kms[dom] / 1e6, 1),
+                      peak=HBM_PEAK_GBS, unit='GB/s')
+        rf['frac'] = round(rf['achieved'] / rf['peak'], 4)
+        rf['ms'] = round(kms[dom], 4)
+        return rf
+
+    roof = roofline_of(k_ms)
+    dom = roof['kernel']
     roof['traffic'] = None                           # HBM bytes/launch from separate rocprofv3 --pmc passes
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            pm = json.load(f).get(args.workload)
-        if pm and dom == 'stats_gram' and world == 1:
-            roof['traffic'] = pm['hbm_bytes']
+            pm = json.load(f).get(args.workload if not share else f'{args.workload}/{share}')
+        ent = (pm or {}).get(dom) if pm and 'kernel' not in pm else (pm if dom == 'stats_gram' else None)
+        if ent and world == 1:
+            roof['traffic'] = ent['hbm_bytes']
             roof['algorithmic_bytes'] = int(alg[dom]['bytes'])
-            roof['traffic_source'] = 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes'
+            roof['traffic_source'] = ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, '
+                                      f"separate passes (round {ent.get('round', '?')})")
     except (OSError, ValueError):
         pass
-    roof['ms'] = round(k_ms[dom], 4)
+    per_rank = None
+    if world > 1:
+        kt = torch.tensor([k_ms['stats_gram'], k_ms['project'], k_ms['reconstruct']], dtype=torch.float64, device=eng.device)
+        allk = [torch.empty_like(kt) for _ in range(world)]
+        dist.all_gather(allk, kt)
+        per_rank = []
+        for q, t in enumerate(allk):
+            v = t.tolist()
+            rf = roofline_of(dict(stats_gram=v[0], project=v[1], reconstruct=v[2]))
+            rf['rank'] = q
+            rf['kernels_ms'] = dict(stats_gram=round(v[0], 4), project=round(v[1], 4), reconstruct=round(v[2], 4))
+            per_rank.append(rf)
     # whole-step algorithmic bytes: (2m + 2r) n B for X and Ur + 8 n (field, f64) + 16 n (row means)
-    step_bytes = (2 * m + 2 * r) * float(n_glob) * B + 24.0 * n_glob
+    step_bytes = (2 * m + 2 * r) * float(n_job) * B + 24.0 * n_job
     hbm_frac = step_bytes / (dt / args.steps) / (world * HBM_PEAK_GBS * 1e9)
 
     extra = {}
@@ -212,9 +369,9 @@ def main():
 
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not share and not args.no_cpu:
         from oracle import spr_oracle as orc
-        cc = min(wl['cpu_cells'], cells_loc)
+        cc = min(wl['cpu_cells'], n_points)
         idx = torch.cat([torch.arange(f * n_points, f * n_points + cc, device=eng.device) for f in range(F)])
         Xs = eng.to_host(Xd[idx])                   # first cc cells of every feature: a valid (cc*F) x m problem
         t1 = time.perf_counter()
@@ -222,12 +379,17 @@ def main():
         Xo = Xs.astype(np.float64) if f32 else Xs
         xr_cpu, st_cpu = orc.fit_reconstruct_timed(Xo, F, s)
         t_cpu = time.perf_counter() - t1
+        blas = 'unknown'
         try:
             import threadpoolctl
-            cores = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+            info = threadpoolctl.threadpool_info()
+            cores = max([p.get('num_threads', 1) for p in info] or [1])
+            blas = '; '.join(sorted({f"{p.get('internal_api')} {p.get('version')} ({p.get('threading_layer', p.get('user_api'))}, "
+                                      f"{p.get('num_threads')} threads)" for p in info if p.get('user_api') == 'blas'})) or blas
         except Exception:
             cores = os.cpu_count()
         cpu = dict(value=round(Xs.nbytes / t_cpu / 1e9, 4), unit='GB/s', cores=int(cores), kind='port',
+                   cpu_model=_cpu_model(), host_cpus=os.cpu_count(), blas=blas,
                    sample=f'{cc} cells x {F} features x {m} snapshots ({Xs.nbytes / 1e6:.0f} MB), s={s}: '
                           f'oracle fit+reconstruct {t_cpu:.2f} s (same generator, first {cc} cells per feature)')
         # parity on the same sample: GPU path vs oracle
@@ -245,23 +407,45 @@ def main():
                       sigma1_over_sigmas=float(sp2.Sigma_r[0] / sp2.Sigma_r[-1]))
 
     if rank == 0:
+        store = 'f32 storage / f64 arithmetic' if f32 else 'f64'
+        if share:
+            what = (f"{args.workload}: rank {args.share_rank}'s block of a {share}-rank run ({n_loc} rows of {n_glob}), "
+                    f'alone on one GPU with its collectives in a 1-rank RCCL group -- NOT an N-GPU number')
+        elif plan['scaling'] == 'strong':
+            what = (f"{args.workload}: {n_points} cells total x {F} features x {m} snapshots, {s} modes/sensors, {store}, "
+                    f'row-sharded over {world} GPU(s) ({n_loc} rows each)')
+        else:
+            what = (f"{args.workload}: {wl['cells']} cells/GPU x {F} features x {m} snapshots, {s} modes/sensors, {store}, "
+                    f'rows sharded over {world} GPU(s)')
         out = {
             'metric': 'SPR fit+reconstruct throughput (GB/s snapshot matrix)', 'value': round(value, 2),
             'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f"{args.workload}: {cells_loc} cells/GPU x {F} features x {m} snapshots, "
-                                   f"{s} modes/sensors, {'f32 storage / f64 arithmetic' if f32 else 'f64'}, rows sharded over {world} GPU(s)",
-                       'rows_per_gpu': n_loc, 'snapshot_GB_per_gpu': round(n_loc * m * B / 1e9, 3), 'storage': 'f32' if f32 else 'f64'},
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': plan['scaling'],
+            'vs_baseline': None, 'dtype': 'f64' if not f32 else 'f64 arithmetic on f32-stored data', 'data': 'synthetic',
+            'config': {'workload': what, 'rows_per_gpu': n_loc, 'rows_total': n_job,
+                       'snapshot_GB_per_gpu': round(n_loc * m * B / 1e9, 3), 'storage': 'f32' if f32 else 'f64'},
             'hbm_roofline_frac_step': round(hbm_frac, 4),
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
         }
+        if per_rank:
+            out['roofline_per_rank'] = per_rank
         if extra:
             out['extra'] = extra
         out['peak_hbm_GB'] = round(torch.cuda.max_memory_allocated() / 1e9, 2)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 if __name__ == '__main__':

@@ -61,14 +61,18 @@ class RowShard:
               ranks) with the same single-threaded LAPACK, so on one node the factors agree bit for bit and nothing
               is exchanged; set True when the ranks' hosts may differ (CPU type, LAPACK build): rank 0's
               decomposition is then broadcast, at the price of one more round trip per fit.
+    partial   the ranks of the group together hold only a slice of the global rows (one rank's block of a larger job
+              run on its own, bench.py --share-of): the global numbering still places the feature boundaries, the
+              statistics, the basis and the gathered field are those of the rows the group holds.
     """
 
-    def __init__(self, row0, n_global, group=None, force_collectives=False, broadcast_basis=False):
+    def __init__(self, row0, n_global, group=None, force_collectives=False, broadcast_basis=False, partial=False):
         self.row0 = int(row0)
         self.n_global = int(n_global)
         self.group = group
         self.force_collectives = bool(force_collectives)   # issue the collectives even in a 1-rank group (tests)
         self.broadcast_basis = bool(broadcast_basis)
+        self.partial = bool(partial)
 
     @property
     def world(self):
@@ -228,7 +232,7 @@ class ROM:
         self._row0 = shard.row0 if shard is not None else 0
         if self._row0 + X.shape[0] > n:
             raise ValueError('The local row block does not fit in the global matrix.')
-        if shard is not None and X.shape[0] * shard.world != n:
+        if shard is not None and X.shape[0] * shard.world != n and not getattr(shard, 'partial', False):
             raise ValueError('Every rank must hold n / world rows (the field all-gather needs equal shards).')
         self._eng = engine
         self._d = {}            # device-resident state

@@ -1,0 +1,86 @@
+"""bench.py's N-rank launcher and shard arithmetic, driven on the CPU (BASELINE configs 4/5).
+
+`python bench.py --gpus N` without a torchrun environment starts the N rank processes itself; here the same
+launcher starts N gloo ranks that run the product's sharded host logic with the NumPy test double, so the process
+spawning, the rank environment, the relay of rank 0's JSON line, failure propagation and the strong-scaling shard
+arithmetic (features straddling the shards) are covered without a GPU."""
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CHILD = os.path.join(ROOT, 'tests', '_bench_rank_double.py')
+
+
+def test_default_workload_and_scaling():
+    a1 = bench.parse_args([])
+    assert (a1.gpus, a1.workload) == (1, 'c3')
+    a8 = bench.parse_args(['--gpus', '8'])
+    assert a8.workload == 'c4'
+    assert bench.parse_args(['--gpus', '8', '--workload', 'c5']).workload == 'c5'
+    wl = bench.WORKLOADS['c4']
+    for world in (1, 2, 4, 8):
+        plans = [bench.shard_plan(wl, world, r) for r in range(world)]
+        assert all(p['scaling'] == 'strong' and p['n_points'] == 10_000_000 and p['n_glob'] == 90_000_000 for p in plans)
+        assert [p['row0'] for p in plans] == [r * (90_000_000 // world) for r in range(world)]
+        assert sum(p['n_loc'] for p in plans) == 90_000_000
+    # config 4 at N = 1 is config 3
+    assert bench.shard_plan(wl, 1, 0) == dict(bench.shard_plan(bench.WORKLOADS['c3'], 1, 0), scaling='strong')
+    # 8 ranks: 11.25M rows each, so rank 0 holds all of feature 0 and the first 1.25M rows of feature 1
+    p = bench.shard_plan(wl, 8, 0)
+    assert p['n_loc'] == 11_250_000 and p['n_loc'] > p['n_points']
+    # weak scaling: config 5 is 6.25M cells per GPU, 50M cells on 8
+    p5 = bench.shard_plan(bench.WORKLOADS['c5'], 8, 7)
+    assert p5['scaling'] == 'weak' and p5['n_points'] == 50_000_000 and p5['n_loc'] == 100_000_000
+    assert p5['row0'] == 700_000_000
+    # a world that does not divide the cells: cells rounded down, shards equal
+    p3 = bench.shard_plan(dict(cells=100, features=3, scaling='strong'), 7, 6)
+    assert p3['n_points'] == 98 and p3['n_loc'] * 7 == p3['n_glob'] == 294
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_launcher_runs_sharded_job_over_gloo(tmp_path, world):
+    out = io.StringIO()
+    field_path = str(tmp_path / 'field.npy')
+    rc = bench.launch_ranks(world, [sys.executable, CHILD, '--gpus', str(world), '--cells', '120', '--out', field_path],
+                            timeout=240, relay=out)
+    assert rc == 0
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # exactly one JSON line, rank 0's
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == world and rec['scaling'] == 'strong'
+    assert rec['rows_total'] == 360 and rec['rows_per_gpu'] * world == 360
+    # same job in one process with the same engine: the gathered field agrees
+    from openmeasure_amd.sparse_sensing import SPR
+    from tests._bench_rank_double import make_X
+    from tests.numpy_engine import NumpyEngine
+    X = make_X(360, 10, 3)
+    spr = SPR(X, 3, None, engine=NumpyEngine())
+    spr.fit(select_modes='number', n_modes=4)
+    ref = spr.reconstruct(spr.Ar[0])
+    got = np.load(field_path)
+    assert got.shape == ref.shape == (360, 1)
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+def test_launcher_propagates_a_failed_rank():
+    out = io.StringIO()
+    rc = bench.launch_ranks(2, [sys.executable, CHILD, '--gpus', '2', '--fail-rank', '1', '--hang-rank', '0'],
+                            timeout=240, relay=out)
+    assert rc == 3                                           # rank 1's exit code; rank 0 (hanging) was terminated
+    assert not [ln for ln in out.getvalue().splitlines() if ln.startswith('{')]
+
+
+def test_world_size_mismatch_is_an_error():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--no-cpu'], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0 and 'WORLD_SIZE=2' in p.stderr

@@ -264,6 +264,20 @@ int spr_solve_ols_f64(const double *d_Theta, int32_t s, int32_t r, const double 
                       int32_t n_p, double *d_Ar, double *d_Ar_sigma, double *d_y0,
                       double *d_info, void *stream);
 
+/* ---- K9b : the same solve with the reference's pseudo-inverse semantics ---------------
+ * np.linalg.pinv(W @ Theta) (:873, :877; SVD, rcond = 1e-15) returns the MINIMUM-NORM least-squares solution when
+ * W Theta is rank deficient or has fewer rows than columns (s < r: every GEM placement, :660-668).  Same inputs and
+ * scaling as spr_solve_ols_f64; per vector the rows of [W Theta | W y0 | y0_sigma] are reduced to an r x (r+2)
+ * triangular factor (streaming Householder QR, only when s > r) and a one-sided Jacobi SVD of that factor gives
+ * a = sum_{sigma_i > rcond sigma_max} v_i (u_i^T b) / sigma_i.  predict() takes this path when s < r, on Cholesky
+ * breakdown, or when the fast path reports cond^2 > 1e13.  s_cnt = entries of d_cnt (must equal s).
+ * d_info (n_p x 4): [0] Jacobi sweeps (negative = not converged), [1] rank kept, [2] sigma_max, [3] smallest
+ * singular value kept. */
+int spr_solve_pinv_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt, int32_t s_cnt,
+                       const double *d_scale, int32_t n_features, const double *d_y, int32_t n_p,
+                       double rcond, double *d_Ar, double *d_Ar_sigma, double *d_y0, double *d_info,
+                       void *stream);
+
 /* ---- synthetic snapshot matrices (benchmark input) -------------------
  * X[i,j] = (f+1) * ( sum_k L[i,k] R[k,j] + eps * N[i,j] ) + 10 f, with L, N standard
  * normal from a counter-based generator keyed by (seed, GLOBAL row, column), so any row

@@ -433,6 +433,21 @@ class HipEngine:
                                               _ptr(y0), _ptr(info), self._stream()), 'spr_solve_ols_f64')
         return Ar, Ar_sigma, y0, info
 
+    def solve_pinv(self, Theta, cnt, scale, y, rcond=1e-15):
+        """Minimum-norm least squares with np.linalg.pinv's semantics (spr_solve_pinv_f64): same arguments as
+        solve_ols. -> Ar (n_p,r), Ar_sigma (n_p,r), y0 (n_p,s,2), info (n_p,4) = sweeps, rank, sigma_max, sigma_min."""
+        s, r = Theta.shape
+        n_p = y.shape[0]
+        Ar = self.empty((n_p, r))
+        Ar_sigma = self.empty((n_p, r))
+        y0 = self.empty((n_p, s, 2))
+        info = self.empty((n_p, 4))
+        _lib.check(self.lib.spr_solve_pinv_f64(_ptr(Theta.contiguous()), s, r, _ptr(cnt), cnt.shape[0], _ptr(scale),
+                                               scale.shape[0], _ptr(y.contiguous()), n_p, float(rcond), _ptr(Ar),
+                                               _ptr(Ar_sigma), _ptr(y0), _ptr(info), self._stream()),
+                   'spr_solve_pinv_f64')
+        return Ar, Ar_sigma, y0, info
+
     # ---- synthetic data ---------------------------------------------------------------------------
     def synth(self, n_rows, m, row0, n_points, R, eps, seed, out=None, dtype=None):
         """Rows [row0, row0+n_rows) of the synthetic matrix; R is (k, >=m) on the device.  dtype float32 stores

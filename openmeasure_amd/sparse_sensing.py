@@ -664,6 +664,8 @@ class ROM:
         self.scale_type = scale_type
         for k in ROM._LAZY + ('C', 'Theta', '_pending'):
             self.__dict__.pop(k, None)
+        for k in ('cnt', 'Theta'):                            # a new basis invalidates the trained measurement state
+            self._d.pop(k, None)
         if self._device_fit(scale_type, axis_cnt, select_modes, n_modes, basis):
             return
         self._stats_pass(scale_type, axis_cnt)
@@ -901,19 +903,49 @@ class SPR(ROM):
             self.k = S_theta[0] / S_theta[-1]
 
     # ------------------------------------------------------------------ a8 / a9
+    _PINV_RCOND = 1e-15    # np.linalg.pinv's default in the reference's NumPy (:873, :877)
+
     def _solve(self, ys):
+        """scale_vector + (weighted) least squares for a list of measurement vectors, on the device.
+        Full-column-rank, well-conditioned systems take the MFMA normal-equations kernel; everything else the
+        reference's pinv accepts -- fewer sensors than modes (every GEM placement), rank-deficient W Theta,
+        cond^2 beyond what the refined normal equations resolve -- takes the QR + one-sided-Jacobi SVD kernel
+        with the same rcond cut, which returns the minimum-norm solution exactly as np.linalg.pinv does."""
         eng = self._engine()
         if 'cnt' not in self._d:
             raise AttributeError("'SPR' object has no attribute 'C'")      # reference fails at self.C (:573)
-        Y = eng.to_device(np.stack([np.asarray(y, dtype=np.float64) for y in ys]))
-        Ar_d, As_d, y0_d, info_d = eng.solve_ols(self._d['Theta'], self._d['cnt'], self._d['scale'], Y)
+        Theta_d, cnt_d = self._d['Theta'], self._d['cnt']
+        if cnt_d.shape[0] != Theta_d.shape[0]:
+            # train(Theta, is_Theta=True) after train(C) with another sensor count: C.dot(X_cnt) (:573) no longer
+            # matches the rows of y -- the reference fails with a broadcast error at :578
+            raise ValueError(f'operands could not be broadcast together: y has {Theta_d.shape[0]} rows, '
+                             f'C has {cnt_d.shape[0]}')
+        Yh = np.stack([np.asarray(y, dtype=np.float64) for y in ys])
+        fid = Yh[:, :, 2].astype('int')                                   # :576 indexes X_scl with it
+        n_loc_rows = self._n_global
+        bad = (fid * self.n_points >= n_loc_rows) | (fid * self.n_points < -n_loc_rows)
+        if bad.any():
+            k = int(fid.ravel()[np.argmax(bad.ravel())]) * self.n_points
+            raise IndexError(f'index {k} is out of bounds for axis 0 with size {n_loc_rows}')
+        if (fid < 0).any():                                               # numpy wraps negative indices (:576)
+            Yh = Yh.copy()
+            Yh[:, :, 2] = np.where(fid < 0, fid + self.n_features, fid)
+        Y = eng.to_device(Yh)
+        s, r = Theta_d.shape
+        if s >= r:
+            Ar_d, As_d, y0_d, info_d = eng.solve_ols(Theta_d, cnt_d, self._d['scale'], Y)
+            info = eng.to_host(info_d)
+            # the kernel's refinement step (corrected semi-normal equations) is as accurate as a QR solve while
+            # cond(W Theta)^2 eps < 1; info[:, 1] estimates cond^2 from the Cholesky pivots
+            if not (np.any(info[:, 0] != 0) or np.any(info[:, 1] > 1e13) or not np.all(np.isfinite(info[:, 1]))):
+                self.solve_path_ = 'cholesky'
+                return eng.to_host(Ar_d), eng.to_host(As_d), eng.to_host(y0_d)
+        Ar_d, As_d, y0_d, info_d = eng.solve_pinv(Theta_d, cnt_d, self._d['scale'], Y, rcond=self._PINV_RCOND)
         info = eng.to_host(info_d)
-        # the kernel's refinement step (corrected semi-normal equations) is as accurate as a QR solve while
-        # cond(W Theta)^2 eps < 1; info[:, 1] estimates cond^2 from the Cholesky pivots
-        if np.any(info[:, 0] != 0) or np.any(info[:, 1] > 1e13):
-            raise np.linalg.LinAlgError(
-                'predict: the normal equations of W*Theta are numerically singular '
-                f'(pivot ratio^2 up to {np.nanmax(info[:, 1]):.3g}); refusing to return a degraded solution.')
+        if np.any(info[:, 0] < 0):
+            raise np.linalg.LinAlgError('SVD did not converge')           # what np.linalg.pinv raises
+        self.solve_path_ = 'pinv'
+        self.solve_rank_ = info[:, 1].astype(int)
         return eng.to_host(Ar_d), eng.to_host(As_d), eng.to_host(y0_d)
 
     def scale_vector(self, y):

@@ -161,9 +161,101 @@ def run_gem_case(sps, name, X, n_features, n_modes, n_sensors, seed, d_min=0.0, 
                C_shape=np.array(C.shape))
     if mask is not None:
         out['mask'] = mask
+    # the placement feeds train -> predict -> reconstruct (docs/sparse_sensing_doc.ipynb cells 10-14): fewer sensors
+    # than modes, so np.linalg.pinv (:873-878) returns the MINIMUM-NORM coefficients
+    out.update(_predict_block(spr, C, picks[0], X, n_points, rng))
     path = os.path.join(OUT, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: n={n} r={spr.r} gem picks={picks[0]} -> {os.path.getsize(path)/1e6:.2f} MB')
+
+
+def _predict_block(spr, C, rows, X, n_points, rng, W_spread=None, drift_tol=1e-7):
+    """train(C) -> predict(3 vectors, the middle one weighted) -> reconstruct through the reference, plus a stability
+    check: pinv's rcond cut (1e-15 sigma_max) sits at rounding level, so a case is only kept when a 1e-13 relative
+    perturbation of the measurements moves the coefficients by less than 1e-7 (i.e. no singular value straddles
+    the cut).  rows: the global row each row of C samples (feature id of the measurement)."""
+    m = X.shape[1]
+    s = C.shape[0]
+    spr.train(C)
+    ys = []
+    for j in range(3):
+        w = rng.standard_normal(m) / np.sqrt(m)
+        xt = X @ w + X.mean(axis=1) * (1 - w.sum())
+        y = np.zeros((s, 3))
+        y[:, 0] = C @ xt
+        y[:, 2] = rows // n_points
+        if j == 1:
+            sig = 0.01 * (1 + rng.random(s)) * np.abs(y[:, 0]).mean()
+            if W_spread is not None:                 # weights spread over several decades: cond(W Theta) grows with it
+                sig = sig * W_spread ** rng.random(s)
+            y[:, 1] = sig
+        ys.append(y)
+    A3, S3 = spr.predict(ys)
+    ys_p = [y.copy() for y in ys]
+    for y in ys_p:
+        y[:, 0] *= 1 + 1e-13 * rng.standard_normal(s)
+    A3p, _ = spr.predict(ys_p)
+    drift = np.abs(A3p - A3).max() / np.abs(A3).max()
+    assert drift < drift_tol, f'pinv result unstable under a 1e-13 perturbation ({drift:.2e}): not a usable fixture'
+    X3 = spr.reconstruct(A3)
+    sv = [np.linalg.svd((np.diag(1 / (y[:, 1] / spr.scl_vector)) if y[:, 1].any() else np.eye(s)) @ spr.Theta,
+                        compute_uv=False) for y in ys]
+    return dict(Theta=spr.Theta.copy(), ys=np.stack(ys), Ar_pred3=A3, Ar_sigma3=S3, X_rec3=X3, X_cnt=spr.X_cnt,
+                X_scl=spr.X_scl, sv_WTheta=np.stack([np.pad(v, (0, max(0, spr.r - len(v)))) for v in sv]))
+
+
+def run_pinv_case(sps, name, X, n_features, n_modes, seed, kind):
+    """predict() on systems where np.linalg.pinv's SVD semantics matter (:873-878):
+      under   -- the first r-2 rows of the QR placement: fewer sensors than modes, minimum-norm solution;
+      dup     -- r sensors of which two are the same row: W Theta has rank r-1;
+      zerocol -- Theta handed over through train(is_Theta=True)-free route is not possible (scale_vector needs C), so
+                 the basis gets an exactly-zero column through fit(basis=...) instead: rank r-1 with an exact zero;
+      illcond -- a basis whose column r-2 is column 0 plus 1e-7 of itself (fit(basis=...)), 3r random sensors: full
+                 column rank, cond(W Theta) ~ 1e7-1e8, beyond the refined normal equations, well inside pinv's range."""
+    if ONLY and name not in ONLY:
+        return
+    n, m = X.shape
+    n_points = n // n_features
+    rng = np.random.default_rng(seed + 7)
+    spr = sps.SPR(X.copy(), n_features, None)
+    spr.fit(select_modes='number', n_modes=n_modes)
+    out = dict(X=X, n_features=np.int64(n_features), n_modes=np.int64(n_modes), kind=np.array(kind))
+    r = spr.r
+    spread = None
+    if kind == 'zerocol':
+        Ur, Ar = np.array(spr.Ur), np.array(spr.Ar)
+        Ur[:, r - 2] = 0.0
+        spr.fit(basis=(Ur, Ar))
+    if kind == 'illcond':
+        Ur, Ar = np.array(spr.Ur), np.array(spr.Ar)
+        Ur[:, r - 2] = Ur[:, 0] + 1e-7 * Ur[:, r - 2]
+        spr.fit(basis=(Ur, Ar))
+    C = spr.optimal_placement() if kind in ('under', 'dup') else None
+    if kind == 'under':
+        C = C[:r - 2]
+        rows = np.argmax(C, axis=1)
+    elif kind == 'dup':
+        C[r - 1] = C[0]
+        rows = np.argmax(C, axis=1)
+    elif kind == 'zerocol':
+        rows = np.sort(rng.choice(n, r + 3, replace=False))
+        C = np.zeros((r + 3, n)); C[np.arange(r + 3), rows] = 1.0
+    elif kind == 'illcond':
+        rows = np.sort(rng.choice(n, 3 * r, replace=False))
+        C = np.zeros((3 * r, n)); C[np.arange(3 * r), rows] = 1.0
+        spread = 1e2
+    else:
+        raise ValueError(kind)
+    out['Ur'], out['Ar'] = np.array(spr.Ur), np.array(spr.Ar)
+    out['C_rows'] = rows.astype(np.int64)
+    # an ill-conditioned full-rank system amplifies the 1e-13 probe by its condition number: looser stability bar
+    out.update(_predict_block(spr, C, rows, X, n_points, rng, W_spread=spread,
+                              drift_tol=1e-3 if kind == 'illcond' else 1e-7))
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    sv = out['sv_WTheta']
+    print(f'{name}: s={C.shape[0]} r={r} sv(W Theta) max/min per vector: '
+          + ', '.join(f'{v.max():.2e}/{v[v > 0].min():.2e}' for v in sv))
 
 
 def run_limits_case(sps, name, X, n_features, seed):
@@ -221,6 +313,14 @@ def main():
     run_gem_case(sps, 'gem_dmin', X, 3, 8, 6, 701, d_min=0.15)
     run_gem_case(sps, 'gem_mask', X, 3, 8, 5, 702, mask_frac=0.5)
     run_gem_case(sps, 'gem_xz_full', X, 3, 6, 5, 703, d_min=0.05, xyz_dim=2)
+    # predict() where pinv's minimum-norm / rank-revealing semantics matter (:873-878)
+    X = synth(400, 3, 16, 16, 0.7, 1e-3, 909)
+    for k, kind in enumerate(['under', 'dup', 'zerocol', 'illcond']):
+        run_pinv_case(sps, 'pinv_' + kind, X, 3, 8, 910 + k, kind)
+    # conditioning of the Gram route (hard part 1): designed spectra with sigma_1/sigma_r = 1e5 and 1e7
+    for tag, decades in (('1e5', 5), ('1e7', 7)):
+        X = synth(1500, 3, 20, 20, 10 ** (-decades / 9), 1e-11, 920 + decades)
+        run_case(sps, 'cond_' + tag, X, 3, 'number', 10, 930 + decades)
 
 
 if __name__ == '__main__':

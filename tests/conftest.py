@@ -11,8 +11,9 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 _ALL = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
-GOLDEN = [n for n in _ALL if not n.startswith(('gem_', 'lim_'))]       # fit -> qr placement -> train -> predict -> reconstruct
+GOLDEN = [n for n in _ALL if not n.startswith(('gem_', 'lim_', 'pinv_'))]       # fit -> qr placement -> train -> predict -> reconstruct
 GOLDEN_GEM = [n for n in _ALL if n.startswith('gem_')]       # calc_type='gem' placement cases
+GOLDEN_PINV = [n for n in _ALL if n.startswith('pinv_')]     # predict() on underdetermined / rank-deficient / ill-conditioned systems
 
 
 def pytest_configure(config):
@@ -51,3 +52,18 @@ def load_golden_gem(name):
 @pytest.fixture(params=GOLDEN_GEM)
 def golden_gem(request):
     return load_golden_gem(request.param)
+
+
+def load_golden_pinv(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    g = {k: z[k] for k in z.files}
+    for k in ('n_features', 'n_modes'):
+        g[k] = int(g[k])
+    g['kind'] = str(g['kind'])
+    g['name'] = name
+    return g
+
+
+@pytest.fixture(params=GOLDEN_PINV)
+def golden_pinv(request):
+    return load_golden_pinv(request.param)

@@ -246,3 +246,24 @@ class NumpyEngine:
             except np.linalg.LinAlgError:
                 info[p, 0] = 1
         return (torch.from_numpy(Ar), torch.from_numpy(As), torch.from_numpy(y0), torch.from_numpy(info))
+
+    def solve_pinv(self, Theta, cnt, scale, y, rcond=1e-15):
+        Th, c, sc, Y = Theta.numpy(), cnt.numpy(), scale.numpy(), y.numpy()
+        n_p, s, r = Y.shape[0], Th.shape[0], Th.shape[1]
+        Ar = np.zeros((n_p, r)); As = np.zeros((n_p, r)); y0 = np.zeros((n_p, s, 2)); info = np.zeros((n_p, 4))
+        for p in range(n_p):
+            scl = sc[Y[p, :, 2].astype(int)]
+            y0[p, :, 0] = (Y[p, :, 0] - c) / scl
+            y0[p, :, 1] = Y[p, :, 1] / scl
+            weighted = np.any(Y[p, :, 1] != 0)
+            w = 1.0 / y0[p, :, 1] if weighted else np.ones(s)
+            A = Th * w[:, None]
+            sv = np.linalg.svd(A, compute_uv=False)
+            Pi = np.linalg.pinv(A, rcond=rcond)
+            Ar[p] = Pi @ (w * y0[p, :, 0])
+            if weighted:
+                As[p] = np.abs(Pi @ y0[p, :, 1])
+            keep = sv > rcond * sv.max()
+            info[p] = (1, keep.sum(), sv.max(), sv[keep].min())
+        return (torch.from_numpy(Ar), torch.from_numpy(As), torch.from_numpy(y0), torch.from_numpy(info))
+

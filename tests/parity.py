@@ -166,6 +166,56 @@ def run_gem_fixture(g, engine):
     np.testing.assert_array_equal(np.argmax(np.asarray(C), axis=1), g['gem_piv'])
     spr.train(C)                                              # the placement feeds train/predict like the QR one
     assert spr.Theta.shape == (g['n_sensors'], spr.r)
+    check_predict_block(spr, g)
+    return spr
+
+
+def check_predict_block(spr, g, coef_tol=1e-7, sigma_rtol=1e-6):
+    """predict -> reconstruct against the reference's stored results on a model whose basis is the fixture's own
+    (no sign ambiguity).  Fewer sensors than modes / rank-deficient W Theta: the reference's pinv (:873-878) returns
+    the minimum-norm coefficients and so must the device path -- never a LinAlgError."""
+    np.testing.assert_allclose(spr.Theta, g['Theta'], rtol=0, atol=1e-9 * np.abs(g['Theta']).max())
+    ys = list(g['ys'])
+    A3, S3 = spr.predict(ys)
+    r = spr.r
+    assert A3.shape == (3, r) and S3.shape == (3, r)
+    scale = np.abs(g['Ar_pred3']).max()
+    np.testing.assert_allclose(A3, g['Ar_pred3'], rtol=0, atol=coef_tol * scale)
+    np.testing.assert_allclose(S3, g['Ar_sigma3'], rtol=sigma_rtol, atol=coef_tol * np.abs(g['Ar_sigma3']).max())
+    assert not S3[0].any() and S3[1].any()
+    A1, _ = spr.predict(ys[2])                                # single-array form (:844-845)
+    np.testing.assert_allclose(A1[0], g['Ar_pred3'][2], rtol=0, atol=coef_tol * scale)
+    X3 = spr.reconstruct(A3)
+    assert X3.shape == g['X_rec3'].shape
+    assert rel_fro(X3, g['X_rec3']) <= REL_FRO
+    return A3, S3
+
+
+def run_pinv_fixture(g, engine):
+    """fit(basis=the fixture's) -> train(C) -> predict -> reconstruct where np.linalg.pinv's SVD semantics decide the
+    answer: 'under' (s = r-2 sensors), 'dup' (a sensor twice: rank r-1), 'zerocol' (an exactly-zero basis column),
+    'illcond' (two nearly collinear basis columns: cond(W Theta) ~ 1e7-1e8, full rank)."""
+    X = g['X'].copy()
+    n = X.shape[0]
+    spr = SPR(X, g['n_features'], None, engine=engine)
+    spr.fit(select_modes='number', n_modes=g['n_modes'])      # statistics (X_cnt, X_scl) from the data ...
+    np.testing.assert_allclose(spr.X_cnt, g['X_cnt'], rtol=1e-13, atol=1e-13 * np.abs(g['X_cnt']).max())
+    spr.fit(basis=(g['Ur'].copy(), g['Ar'].copy()))           # ... the basis exactly the reference's (:493-497)
+    rows = g['C_rows']
+    C = np.zeros((len(rows), n))
+    C[np.arange(len(rows)), rows] = 1.0
+    spr.train(C)
+    # ill-conditioned but full rank: the coefficients themselves are only defined to cond * eps (the two nearly
+    # collinear modes trade off against each other), the reconstructed field is not affected
+    loose = g['kind'] == 'illcond'
+    check_predict_block(spr, g, coef_tol=2e-4 if loose else 1e-7, sigma_rtol=1e-3 if loose else 1e-6)
+    s_, r = spr.Theta.shape
+    if g['kind'] != 'illcond' or True:
+        assert spr.solve_path_ == 'pinv'                      # none of these is a case for the normal equations
+    if g['kind'] in ('dup', 'zerocol'):
+        assert (spr.solve_rank_ == r - 1).all()
+    if g['kind'] == 'under':
+        assert (spr.solve_rank_ == s_).all()
     return spr
 
 

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from oracle import spr_oracle as orc
-from tests.parity import REL_FRO, align_signs, rel_fro, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style
+from tests.parity import (REL_FRO, align_signs, rel_fro, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style,
+                          run_pinv_fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -357,6 +358,161 @@ def test_predict_moderately_ill_conditioned_theta(eng, cond, tol):
     for k in range(2):
         assert np.linalg.norm(Ar[k] - A_ref[k]) <= tol * np.linalg.norm(A_ref[k]), (k, info[k])
     assert np.linalg.norm(As[1] - S_ref[1]) <= tol * np.linalg.norm(S_ref[1])
+
+
+def test_pinv_fixture(golden_pinv, eng):                  # :873-878 -- underdetermined / rank-deficient / ill-conditioned
+    run_pinv_fixture(golden_pinv, eng)
+
+
+def _identity_problem(Theta, ys):
+    """oracle predict_ols for a bare Theta: identity measurement matrix, zero centre, unit scale"""
+    s_ = Theta.shape[0]
+    return orc.predict_ols(ys, Theta, np.eye(s_), np.zeros((s_, 1)), np.ones((s_, 1)), s_)
+
+
+@pytest.mark.parametrize('s_,r,rank', [(5, 12, 5), (12, 12, 9), (40, 17, 11), (200, 33, 33), (70, 64, 40), (300, 128, 100),
+                                      (130, 128, 128), (3, 128, 3), (1, 4, 1), (9, 1, 1)])
+def test_pinv_kernel_vs_oracle(eng, s_, r, rank):
+    """spr_solve_pinv_f64 against np.linalg.pinv on random systems of prescribed rank (exact low rank through a
+    product of thin factors; s < r, s = r, s > r; all four r classes of the kernel), weighted and unweighted."""
+    rng = np.random.default_rng(100 + s_ + r)
+    Theta = rng.standard_normal((s_, rank)) @ rng.standard_normal((rank, r)) if rank < min(s_, r) else \
+        rng.standard_normal((s_, r))
+    ys = []
+    for weighted in (False, True, True):
+        y = np.zeros((s_, 3))
+        y[:, 0] = rng.standard_normal(s_)
+        if weighted:
+            y[:, 1] = 0.05 * (1.0 + rng.random(s_))
+        ys.append(y)
+    A_ref, S_ref = _identity_problem(Theta, ys)
+    Ar, As, y0, info = eng.solve_pinv(eng.to_device(Theta), eng.to_device(np.zeros(s_)), eng.to_device(np.ones(1)),
+                                      eng.to_device(np.stack(ys)))
+    Ar, As, info = eng.to_host(Ar), eng.to_host(As), eng.to_host(info)
+    assert (info[:, 0] >= (1 if min(s_, r) > 1 else 0)).all() and (info[:, 0] <= 30).all(), info   # Jacobi converged
+    np.testing.assert_array_equal(info[:, 1], min(rank, s_, r))               # numerical rank = the designed one
+    # exact rank deficiency: numpy's own tiny singular values sit at eps * sigma_max, a factor ~5 under its cut;
+    # both solutions are the minimum-norm one up to that noise
+    for k in range(3):
+        assert np.linalg.norm(Ar[k] - A_ref[k]) <= 1e-9 * np.linalg.norm(A_ref[k]), (k, info[k])
+    assert np.linalg.norm(As[1] - S_ref[1]) <= 1e-9 * np.linalg.norm(S_ref[1])
+    assert not As[0].any()
+    np.testing.assert_allclose(eng.to_host(y0)[1, :, 1], ys[1][:, 1])
+
+
+@pytest.mark.parametrize('cond', [1e7, 1e10, 1e13])
+def test_predict_ill_conditioned_goes_through_svd(eng, cond):
+    """Beyond cond ~ 3e6 the normal equations are refused by predict() and the QR + Jacobi-SVD kernel answers, as
+    np.linalg.pinv does, to about cond * eps."""
+    rng = np.random.default_rng(17)
+    s_, r = 60, 20
+    Uq, _ = np.linalg.qr(rng.standard_normal((s_, r)))
+    Vq, _ = np.linalg.qr(rng.standard_normal((r, r)))
+    Theta = (Uq * np.logspace(0, -np.log10(cond), r)) @ Vq.T
+    y = np.zeros((s_, 3))
+    y[:, 0] = Theta @ rng.standard_normal(r)
+    A_ref, _ = _identity_problem(Theta, [y])
+    Ar, _, _, info = eng.solve_pinv(eng.to_device(Theta), eng.to_device(np.zeros(s_)), eng.to_device(np.ones(1)),
+                                    eng.to_device(y[None]))
+    info = eng.to_host(info)
+    assert info[0, 1] == r
+    np.testing.assert_allclose(info[0, 2] / info[0, 3], cond, rtol=1e-3 if cond < 1e12 else 0.2)
+    assert np.linalg.norm(eng.to_host(Ar)[0] - A_ref[0]) <= 50 * cond * 2.2e-16 * np.linalg.norm(A_ref[0])
+
+
+def test_predict_tomography_sized_weighted_solve(eng):
+    """s = 4096 sensors x r = 32 modes (many panels of the MFMA normal equations), weighted, batch of 3 -- and the
+    same systems through the streaming-QR pinv kernel."""
+    rng = np.random.default_rng(23)
+    s_, r, F = 4096, 32, 5
+    Theta = rng.standard_normal((s_, r)) / np.sqrt(s_)
+    cnt = rng.standard_normal(s_)
+    scl_f = 1 + rng.random(F)
+    ys = []
+    for p in range(3):
+        y = np.zeros((s_, 3))
+        y[:, 0] = rng.standard_normal(s_)
+        y[:, 2] = rng.integers(0, F, s_)
+        if p:
+            y[:, 1] = 0.05 + rng.random(s_)
+        ys.append(y)
+    n_points = 3
+    X_scl = np.repeat(scl_f, n_points)[:, None]
+
+    class _C:
+        def dot(self, v):
+            return cnt
+    A_ref, S_ref = orc.predict_ols(ys, Theta, _C(), np.zeros((F * n_points, 1)), X_scl, n_points)
+    args = (eng.to_device(Theta), eng.to_device(cnt), eng.to_device(scl_f), eng.to_device(np.stack(ys)))
+    Ar, As, _, info = eng.solve_ols(*args)
+    assert not eng.to_host(info)[:, 0].any()
+    np.testing.assert_allclose(eng.to_host(Ar), A_ref, rtol=0, atol=1e-10 * np.abs(A_ref).max())
+    np.testing.assert_allclose(eng.to_host(As), S_ref, rtol=0, atol=1e-10 * np.abs(S_ref).max())
+    Ar2, As2, _, info2 = eng.solve_pinv(*args)
+    assert (eng.to_host(info2)[:, 1] == r).all()
+    np.testing.assert_allclose(eng.to_host(Ar2), A_ref, rtol=0, atol=1e-10 * np.abs(A_ref).max())
+    np.testing.assert_allclose(eng.to_host(As2), S_ref, rtol=0, atol=1e-10 * np.abs(S_ref).max())
+
+
+def test_predict_feature_id_out_of_range_raises_like_the_reference(eng):
+    """:576 indexes X_scl with y[:,2]*n_points: an id past the last feature is an IndexError, a negative one wraps."""
+    X = synth_host(300, 3, 12, 8, 0.7, 1e-3, 5)
+    from openmeasure_amd.sparse_sensing import SPR
+    spr = SPR(X, 3, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=4)
+    C = spr.optimal_placement()
+    spr.train(C)
+    y = np.zeros((4, 3)); y[:, 0] = X[spr.sensors_, 0]; y[:, 2] = spr.sensors_ // 300
+    a_ok, _ = spr.predict(y)
+    ybad = y.copy(); ybad[1, 2] = 3
+    with pytest.raises(IndexError):
+        spr.predict(ybad)
+    yneg = y.copy(); yneg[:, 2] -= 3                                      # -3..-1 wrap onto features 0..2
+    a_neg, _ = spr.predict(yneg)
+    np.testing.assert_array_equal(a_neg, a_ok)
+    # a Theta handed over directly with another sensor count no longer matches C (ADVICE): the reference fails in
+    # scale_vector's broadcast, never reads out of bounds
+    spr.train(np.vstack([spr.Theta, spr.Theta]), is_Theta=True)
+    with pytest.raises(ValueError):
+        spr.predict(np.vstack([y, y]))
+
+
+def test_reconstruct_many_vectors(eng):
+    """n_p = 40 coefficient vectors: three passes of 16 + 16 + 8 through reconstruct.hip, f64 and f32-stored basis."""
+    import torch
+    rng = np.random.default_rng(31)
+    n_points, F, r, n_p = 4099, 3, 24, 40
+    n = n_points * F
+    U = rng.standard_normal((n, r))
+    mu = rng.standard_normal(n)
+    scl_f = 1 + rng.random(F)
+    A = rng.standard_normal((n_p, r))
+    ref = orc.reconstruct(A, U, mu[:, None], np.repeat(scl_f, n_points)[:, None])
+    out = eng.reconstruct(eng.to_device(U), 0, n_points, F, eng.to_device(mu), eng.to_device(scl_f), eng.to_device(A))
+    got = eng.to_host(out).T
+    assert got.shape == (n, n_p)
+    assert rel_fro(got, ref) <= 1e-14
+    U32 = U.astype(np.float32)
+    ref32 = orc.reconstruct(A, U32.astype(np.float64), mu[:, None], np.repeat(scl_f, n_points)[:, None])
+    out32 = eng.reconstruct(eng.to_device(U32, dtype=torch.float32), 0, n_points, F, eng.to_device(mu),
+                            eng.to_device(scl_f), eng.to_device(A))
+    assert rel_fro(eng.to_host(out32).T, ref32) <= 1e-14
+
+
+def test_csr_measurement_matrix_with_many_nonzeros(eng):
+    """tomography-like C: 600 rays x 50 000 cells with 2e5 non-zeros (CSR measure kernel, Theta and cnt)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(41)
+    n, r, s_ = 50_000, 32, 600
+    U = rng.standard_normal((n, r))
+    mu = rng.standard_normal(n)
+    C = sp.random(s_, n, density=2e5 / (s_ * n), random_state=9, format='csr')
+    assert C.nnz >= 1e5
+    t = eng.torch
+    Th, cnt = eng.measure_csr(eng.to_device(C.indptr, dtype=t.int64), eng.to_device(C.indices, dtype=t.int64),
+                              eng.to_device(C.data), eng.to_device(U), 0, eng.to_device(mu))
+    np.testing.assert_allclose(eng.to_host(Th), C @ U, atol=1e-11)
+    np.testing.assert_allclose(eng.to_host(cnt), C @ mu, atol=1e-11)
 
 
 def test_general_csr_measurement_matrix(eng):

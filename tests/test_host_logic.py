@@ -7,7 +7,7 @@ import scipy.sparse as sp
 
 from openmeasure_amd.sparse_sensing import ROM, SPR
 from tests.numpy_engine import NumpyEngine
-from tests.parity import run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style
+from tests.parity import run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style, run_pinv_fixture
 
 
 def test_fixture_through_host_logic(golden):
@@ -22,6 +22,10 @@ def test_gpr_style_subclass(golden, foreign):           # gpr.py:379-402: a ROM 
 
 def test_gem_fixture_through_host_logic(golden_gem):   # :586-698
     run_gem_fixture(golden_gem, NumpyEngine())
+
+
+def test_pinv_fixture_through_host_logic(golden_pinv):  # :873-878 minimum-norm / rank-deficient / ill-conditioned
+    run_pinv_fixture(golden_pinv, NumpyEngine())
 
 
 def _synth(n_points, F, m, k, rho, eps, seed):

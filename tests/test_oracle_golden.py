@@ -163,6 +163,40 @@ def test_gem_pivots(golden_gem):                       # :586-698, noise-free li
     np.testing.assert_array_equal(piv_n, g['gem_piv'])
 
 
+def _oracle_predict_block(g, Ur, rows):
+    n = g['X'].shape[0]
+    n_points = n // g['n_features']
+    C = np.zeros((len(rows), n)); C[np.arange(len(rows)), rows] = 1.0
+    Theta = orc.train_theta(C, Ur, n)
+    np.testing.assert_array_equal(Theta, g['Theta'])
+    A3, S3 = orc.predict_ols(list(g['ys']), Theta, C, g['X_cnt'], g['X_scl'], n_points)
+    np.testing.assert_array_equal(A3, g['Ar_pred3'])
+    np.testing.assert_array_equal(S3, g['Ar_sigma3'])
+    np.testing.assert_array_equal(orc.reconstruct(A3, Ur, g['X_cnt'], g['X_scl']), g['X_rec3'])
+
+
+def test_gem_predict_minimum_norm(golden_gem):         # fewer sensors than modes: pinv's minimum-norm solution (:873-878)
+    g = golden_gem
+    assert g['n_sensors'] < g['Ur'].shape[1]
+    _oracle_predict_block(g, g['Ur'], g['gem_piv'])
+
+
+def test_pinv_cases(golden_pinv):                      # underdetermined / rank-deficient / ill-conditioned W Theta
+    g = golden_pinv
+    X_cnt, X_scl, _ = orc.scale_data(g['X'], g['n_features'])
+    np.testing.assert_array_equal(X_cnt, g['X_cnt'])
+    np.testing.assert_array_equal(X_scl, g['X_scl'])
+    _oracle_predict_block(g, g['Ur'], g['C_rows'])
+    sv = g['sv_WTheta']
+    r = g['Ur'].shape[1]
+    if g['kind'] == 'under':
+        assert len(g['C_rows']) == r - 2
+    if g['kind'] in ('dup', 'zerocol'):                 # numerically rank r-1: the smallest singular value is below the rcond cut
+        assert (sv[:, -1] <= 1e-15 * sv[:, 0]).all() and (sv[:, -2] > 1e-6 * sv[:, 0]).all()
+    if g['kind'] == 'illcond':
+        assert (sv[:, 0] / sv[:, -1] > 3e6).all() and (sv[:, 0] / sv[:, -1] < 1e10).all()
+
+
 def test_scale_limits():                               # :173-210, both the ordinary and the clamped branch
     import os
     from tests.conftest import GOLDEN_DIR

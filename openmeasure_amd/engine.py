@@ -207,6 +207,8 @@ class HipEngine:
     # ---- K3b: device-side spectrum (m <= 64) ------------------------------------------------------
     SCALE_CODES = {'std': 0, 'none': 1, 'pareto': 2, 'vast': 3, 'level': 4, 'variance': 5, 'poisson': 6, 'l2-norm': 7}
 
+    spectrum_max_sweeps = 15                                 # SP_MAX_SWEEPS of csrc/spectrum.hip (info[0] when not converged)
+
     @property
     def spectrum_max_m(self):
         return int(self.lib.spr_spectrum_max_m())
@@ -281,6 +283,33 @@ class HipEngine:
                                                      int(k > 0), self._stream()), 'spr_project')
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf
+
+    def project_f64(self, X, i0, rows, row0, n_points, n_features, inv_scale, W, rowmean, out, center=True):
+        """out[:rows, :q] = ((X[i0:i0+rows] - rowmean) W) / X_scl in float64 whatever the storage of X, for any
+        q = W.shape[1] <= out.shape[1] (column groups of <= 128 go to column offsets of `out`; a wide X goes as two
+        accumulating column slices).  Used by the conditioning refinement of fit(), where the product must not be
+        rounded to the storage type of the basis."""
+        n, m, ld = self._check_matrix(X)
+        q = W.shape[1]
+        if not (out.dtype == self.torch.float64 and out.dim() == 2 and out.stride(1) == 1 and out.shape[1] >= q
+                and out.shape[0] >= rows and out.stride(0) % 2 == 0):
+            raise ValueError('project_f64: out must be a float64 matrix with an even row stride')
+        if m > _lib.SPR_MAX_M_WIDE:
+            raise NotImplementedError(f'project: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
+        fn = self.lib.spr_project_f64 if X.dtype == self.torch.float64 else self.lib.spr_project_x32_f64out
+        Wc = W.contiguous()
+        mA = _lib.SPR_MAX_M
+        slices = ((0, m),) if m <= mA else ((0, mA), (mA, m - mA))
+        esz = X.element_size()
+        mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
+        for g0 in range(0, q, _lib.SPR_MAX_R):
+            qg = min(_lib.SPR_MAX_R, q - g0)
+            Wg = Wc[:, g0:g0 + qg].contiguous()
+            for k, (c0, width) in enumerate(slices):
+                _lib.check(fn(X.data_ptr() + (i0 * ld + c0) * esz, rows, width, ld, row0 + i0, n_points, n_features, int(bool(center)),
+                              _ptr(inv_scale), mean_p, Wg.data_ptr() + c0 * qg * 8, qg,
+                              out.data_ptr() + g0 * 8, out.stride(0), int(k > 0), self._stream()), 'spr_project_f64')
+        return out
 
     def feature_minmax(self, X, row0, n_points, n_features):
         """-> (F, 2) tensor: min and max of the raw block per feature over the local rows."""

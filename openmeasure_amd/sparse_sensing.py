@@ -46,6 +46,11 @@ import numpy as np
 __all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix', 'PendingField']
 
 _DEVICE_SPECTRUM_MAX_M = 24   # above this the single-workgroup Jacobi is slower than host dsyevd (csrc/spectrum.hip)
+# Gram route (fit): singular vectors come from the eigenvectors of X0^T X0, whose rounding error eps * sigma_1^2 reaches
+# mode i as eps * (sigma_1/sigma_i)^2.  Up to this ratio the basis is as good as LAPACK's to ~1e-8 (sensor parity
+# verified on reference fixtures); above it fit() runs the refinement pass of _refine_spectrum (one more read of X).
+_GRAM_KAPPA_REFINE = 1e4
+_GRAM_REFINE_MAX_PASSES = 3
 _DENSE_C_LIMIT = 1 << 26   # optimal_placement returns a dense ndarray below this many bytes (64 MiB)
 
 
@@ -585,25 +590,88 @@ class ROM:
         return U[:, :r], A[:, :r]
 
     # ------------------------------------------------------------------ a3 decomposition
+    def _same_on_all_ranks(self, *arrays):
+        """RowShard(broadcast_basis=True): rank 0's host factors win (heterogeneous hosts)."""
+        if not (self._dist() and self._shard.broadcast_basis):
+            return arrays
+        import torch.distributed as dist
+        eng = self._engine()
+        pack = eng.to_device(np.concatenate([np.ravel(a) for a in arrays]))
+        dist.broadcast(pack, src=dist.get_global_rank(self._shard.group, 0) if self._shard.group is not None else 0,
+                       group=self._shard.group)
+        pack = eng.to_host(pack)
+        out, o = [], 0
+        for a in arrays:
+            out.append(pack[o:o + a.size].reshape(a.shape).copy())
+            o += a.size
+        return tuple(out)
+
     def _spectrum(self, G):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
         lam, V = _eigh_small(G)
-        if self._dist() and self._shard.broadcast_basis:
-            # heterogeneous hosts: every rank must project with bit-identical factors, rank 0's decomposition wins
-            import torch.distributed as dist
-            eng = self._engine()
-            pack = eng.to_device(np.concatenate([lam, V.ravel()]))
-            dist.broadcast(pack, src=dist.get_global_rank(self._shard.group, 0) if self._shard.group is not None else 0,
-                           group=self._shard.group)
-            pack = eng.to_host(pack)
-            m_ = lam.shape[0]
-            lam, V = pack[:m_].copy(), pack[m_:].reshape(m_, m_).copy()
+        lam, V = self._same_on_all_ranks(lam, V)
         lam = lam[::-1]
         V = _sign_fix(V[:, ::-1])
         lam_pos = np.maximum(lam, 0.0)
         S = np.sqrt(lam_pos)
         exp_variance = 100 * np.cumsum(lam_pos) / np.sum(lam_pos)
         return S, V, exp_variance
+
+    def _refine_spectrum(self, S, V, r, Xd, row0, n_points, n_features, inv_scale_d, rowmean_d, center):
+        """Conditioning safeguard of the Gram route (hard part 1).
+
+        The eigenvectors of G = X0^T X0 carry an error eps * (sigma_1/sigma_i)^2, which LAPACK's SVD of X0 itself
+        (reference :272) does not have.  One more pass over X removes it: with the first-stage factors V^, S^,
+        Y = X0 V^ diag(1/S^) has columns of nearly unit norm that are nearly orthogonal, so its Gram matrix
+        H = Y^T Y (same MFMA kernels: projection of a row block into an f64 scratch block, Gram of the block) is
+        formed with errors relative to 1, not to sigma_1^2 -- the small modes are now resolved to eps * sigma_1/sigma_i
+        like in the reference.  From H = Z L Z^T:  X0 = (Y Z L^-1/2) (L^1/2 Z^T diag(S^) V^T) = Q M with Q
+        orthonormal, and the SVD of the m x m matrix M gives the singular values and right singular vectors of X0.
+        Repeated (at most _GRAM_REFINE_MAX_PASSES passes) until the retained block of H is well conditioned;
+        raises LinAlgError if it never is -- never returns silently degraded sensors.
+        Returns (S, V, exp_variance, passes)."""
+        eng = self._engine()
+        n_loc, m = Xd.shape
+        eps = np.finfo(float).eps
+        block = int(max(1 << 16, min(n_loc, (1 << 31) // (8 * (m + (m & 1))))))
+        Y = eng.empty((min(block, n_loc), m + (m & 1)))
+        passes = 0
+        while True:
+            passes += 1
+            floor = S[0] * np.sqrt(m * eps)
+            d = np.maximum(S, floor if floor > 0 else 1.0)
+            W2 = eng.to_device(V / d)
+            H_d = None
+            for i0 in range(0, n_loc, block):
+                rows = min(block, n_loc - i0)
+                eng.project_f64(Xd, i0, rows, row0, n_points, n_features, inv_scale_d, W2, rowmean_d, Y, center=center)
+                Yb = Y[:rows, :m] if Y.shape[1] != m else Y[:rows]
+                _, _, g = eng.stats_gram(Yb, 0, rows, 1, center=False)
+                H_d = g[0].clone() if H_d is None else H_d.add_(g[0])
+            H = eng.to_host(self._all_reduce(H_d))
+            H = 0.5 * (H + H.T)
+            lamH, Z = _eigh_small(H)
+            M = (np.sqrt(np.maximum(lamH, 0.0))[:, None] * Z.T) * d[None, :] @ V.T
+            _, S_new, Vt = np.linalg.svd(M)
+            S_new, Vt = self._same_on_all_ranks(S_new, Vt)
+            # is the pass converged?  The retained columns of Y must have come out nearly orthonormal.  Modes below
+            # 1e-12 sigma_1 (the null mode that row-centring creates when all m modes are kept) are rounding noise
+            # in the reference as well and are left out of the verdict.
+            keep = np.flatnonzero(S_new[:r] > 1e-12 * S_new[0])
+            dn = np.sqrt(np.maximum(np.diag(H), np.finfo(float).tiny))
+            ev = np.linalg.eigvalsh((H / dn[:, None] / dn[None, :])[np.ix_(keep, keep)])
+            cond_r = ev[-1] / max(ev[0], np.finfo(float).tiny)
+            S, V = S_new, _sign_fix(Vt.T.copy())
+            if cond_r < 4.0:                                   # |off-diagonal| of the retained block well below 1
+                break
+            if passes >= _GRAM_REFINE_MAX_PASSES:
+                raise np.linalg.LinAlgError(
+                    f'fit: sigma_1/sigma_r = {S[0] / max(S[r - 1], np.finfo(float).tiny):.3g} is beyond what the Gram '
+                    f'route resolves even after {passes} refinement passes (retained block of the second-stage Gram '
+                    f'matrix still has condition {cond_r:.3g}); keep fewer modes or rescale the data.')
+        lam = S * S
+        exp_variance = 100 * np.cumsum(lam) / np.sum(lam)
+        return S, V, exp_variance, passes
 
     def _basis_from_gram(self, G, select_modes, n_modes, center, inv_scale_d):
         eng = self._engine()
@@ -612,9 +680,15 @@ class ROM:
         S, V, exp_variance = self._spectrum(G)
         self._trace.mark('eigh')
         r = self._select_rank(exp_variance, m, select_modes, n_modes)
+        self.gram_refine_passes_ = 0
+        if S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
+            S, V, exp_variance, self.gram_refine_passes_ = self._refine_spectrum(
+                S, V, r, Xd, self._row0, self.n_points, self.n_features, inv_scale_d, self._d.get('rowmean'), center)
+            r = self._select_rank(exp_variance, m, select_modes, n_modes)
+            self._trace.mark('refine')
         # modes below sqrt(m eps) sigma_1 carry no information on the Gram route; keep the
         # projection finite for them (their reference counterparts are LAPACK rounding noise)
-        floor = S[0] * np.sqrt(m * np.finfo(float).eps)
+        floor = S[0] * np.sqrt(m * np.finfo(float).eps) if not self.gram_refine_passes_ else S[0] * m * np.finfo(float).eps
         S_safe = np.maximum(S[:r], floor if floor > 0 else 1.0)
         W = V[:, :r] / S_safe
         W_d = eng.to_device(W)
@@ -646,6 +720,10 @@ class ROM:
             m = X0d.shape[1]
             r = self._select_rank(exp_variance, m, select_modes, n_modes)
             floor = S[0] * np.sqrt(m * np.finfo(float).eps)
+            if S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
+                S, V, exp_variance, _ = self._refine_spectrum(S, V, r, X0d, 0, X0d.shape[0], 1, ones, None, False)
+                r = self._select_rank(exp_variance, m, select_modes, n_modes)
+                floor = S[0] * m * np.finfo(float).eps
             W = V[:, :r] / np.maximum(S[:r], floor if floor > 0 else 1.0)
             Ur_d = eng.project(X0d, 0, X0d.shape[0], 1, ones, eng.to_device(W), center=False)
             Ar, expv = V[:, :r] * S[:r], exp_variance[:r]
@@ -720,6 +798,12 @@ class ROM:
         self._d['Ur'] = eng.project(Xd, self._row0, self.n_points, F, sp['inv_scale'], sp['W'], center=True,
                                     out=self._d.pop('Ur', None), rowmean=rowmean)
         tr_.mark('project')
+        # the only download of this path: the two singular values that decide whether the Gram route was good enough
+        # and the Jacobi verdict (sweeps, off^2, diag^2) -- fetched after the projection has been enqueued
+        chk = eng.to_host(eng.torch.cat([sp['S'][:1], sp['S'][r - 1:r], sp['info']]))
+        converged = chk[2] < eng.spectrum_max_sweeps or chk[3] <= 1e-24 * chk[4]
+        if not converged or chk[1] * _GRAM_KAPPA_REFINE < chk[0]:
+            return False                                       # the host route decides (refinement pass or LinAlgError)
         self.r = r
         sp['r'] = r
         self._pending = sp

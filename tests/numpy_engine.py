@@ -66,6 +66,14 @@ class NumpyEngine:
         U = ((x - mean[:, None]) @ W.numpy()) * inv_scale.numpy()[feat][:, None]
         return torch.from_numpy(np.ascontiguousarray(U)).to(X.dtype)     # stored like the shard
 
+    def project_f64(self, X, i0, rows, row0, n_points, n_features, inv_scale, W, rowmean, out, center=True):
+        x = self._w(X)[i0:i0 + rows]
+        feat = self._feat(rows, row0 + i0, n_points, n_features)
+        mean = rowmean.numpy()[i0:i0 + rows, None] if center else 0.0
+        U = ((x - mean) @ W.numpy()) * inv_scale.numpy()[feat][:, None]
+        out[:rows, :W.shape[1]] = torch.from_numpy(U)
+        return out
+
     def feature_minmax(self, X, row0, n_points, n_features):
         x = self._w(X)
         feat = self._feat(x.shape[0], row0, n_points, n_features)

@@ -281,3 +281,27 @@ def run_f32_storage(engine, n_points, F, m, r, seed, synth):
     np.testing.assert_array_equal(spr.sensors_, want_m)
     np.testing.assert_array_equal(spr.Ur.astype(np.float64), U_masked)
     return spr
+
+
+def run_conditioning_guard(engine, decades, synth):
+    """Gram route on a designed spectrum sigma_1/sigma_r ~ 10^decades: fit() must either return the reference's
+    sensors exactly (refinement pass of _refine_spectrum) or refuse with LinAlgError -- never degrade silently."""
+    from oracle import spr_oracle as orc
+    X = synth(1500, 3, 20, 20, 10 ** (-decades / 9), 1e-16, 77 + decades)
+    st = orc.fit(X, 3, 'number', 10)
+    piv, _ = orc.qr_pivots(st['Ur'])
+    kappa = st['Sigma_r'][0] / st['Sigma_r'][-1]
+    spr = SPR(X, 3, None, engine=engine)
+    try:
+        spr.fit(select_modes='number', n_modes=10)
+    except np.linalg.LinAlgError as e:
+        assert kappa > 1e8 and 'refinement' in str(e)
+        return None
+    assert (spr.gram_refine_passes_ > 0) == (kappa > 1e4)
+    spr.optimal_placement()
+    np.testing.assert_array_equal(spr.sensors_, piv)
+    eps_k = np.finfo(float).eps * kappa
+    np.testing.assert_allclose(spr.Sigma_r, st['Sigma_r'], rtol=max(1e-9, 100 * eps_k))
+    sg = align_signs(spr.Ar, st['Ar'])
+    np.testing.assert_allclose(spr.Ur * sg, st['Ur'], rtol=0, atol=max(1e-9, 1e3 * eps_k) * np.abs(st['Ur']).max())
+    return spr

@@ -60,7 +60,8 @@ def _worker(rank, world, port, fixture, out_dir, bcast=False):
 
 
 @pytest.mark.parametrize('fixture,world', [('g2_num4', 2), ('g2_num4', 3), ('g3_num8', 2), ('g2_num4_mask', 2), ('g4_num5', 3),
-                                           ('g5_range', 2), ('g5_l2norm', 3), ('g5_median', 3), ('g6_axisnone', 2)])
+                                           ('g5_range', 2), ('g5_l2norm', 3), ('g5_median', 3), ('g6_axisnone', 2),
+                                           ('cond_1e7', 2), ('cond_1e5', 3)])   # second-stage Gram all-reduce
 def test_sharded_path_matches_reference(tmp_path, fixture, world):
     _run_sharded(tmp_path, fixture, world, False)
 

@@ -9,7 +9,7 @@ import pytest
 
 from oracle import spr_oracle as orc
 from tests.parity import (REL_FRO, align_signs, rel_fro, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style,
-                          run_pinv_fixture)
+                          run_conditioning_guard, run_pinv_fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -358,6 +358,11 @@ def test_predict_moderately_ill_conditioned_theta(eng, cond, tol):
     for k in range(2):
         assert np.linalg.norm(Ar[k] - A_ref[k]) <= tol * np.linalg.norm(A_ref[k]), (k, info[k])
     assert np.linalg.norm(As[1] - S_ref[1]) <= tol * np.linalg.norm(S_ref[1])
+
+
+@pytest.mark.parametrize('decades', [3, 5, 7, 9, 11, 13])
+def test_conditioning_guard(eng, decades):                # sigma_1/sigma_r up to 1e13: exact sensors or LinAlgError
+    run_conditioning_guard(eng, decades, synth_host)
 
 
 def test_pinv_fixture(golden_pinv, eng):                  # :873-878 -- underdetermined / rank-deficient / ill-conditioned

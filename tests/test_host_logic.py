@@ -7,7 +7,8 @@ import scipy.sparse as sp
 
 from openmeasure_amd.sparse_sensing import ROM, SPR
 from tests.numpy_engine import NumpyEngine
-from tests.parity import run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style, run_pinv_fixture
+from tests.parity import (run_conditioning_guard, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style,
+                          run_pinv_fixture)
 
 
 def test_fixture_through_host_logic(golden):
@@ -36,6 +37,11 @@ def _synth(n_points, F, m, k, rho, eps, seed):
     for f in range(F):
         X[f * n_points:(f + 1) * n_points] = (f + 1) * X[f * n_points:(f + 1) * n_points] + 10.0 * f
     return np.ascontiguousarray(X)
+
+
+@pytest.mark.parametrize('decades', [3, 6, 9, 12])
+def test_conditioning_guard_through_host_logic(decades):   # SURVEY 7 hard part 1: exact sensors or explicit refusal
+    run_conditioning_guard(NumpyEngine(), decades, _synth)
 
 
 @pytest.mark.parametrize('n_points,F,m,r', [(400, 3, 12, 4), (300, 2, 41, 14)])

@@ -16,7 +16,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libspr_hip.so')
+# SPR_HIP_LIBRARY: load another build of the same library (the ASan host build of `make asan`, tests only)
+LIB_PATH = os.environ.get('SPR_HIP_LIBRARY') or os.path.join(_HERE, 'libspr_hip.so')
 
 SPR_MAX_M = 256
 SPR_MAX_M_WIDE = 512

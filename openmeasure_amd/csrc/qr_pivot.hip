@@ -26,7 +26,6 @@
 namespace {
 
 constexpr int QR_THREADS = 256;
-constexpr int QR_UNR = 4;
 #ifndef QR_TOPT_N
 #define QR_TOPT_N 16   // 16 instead of 8: 5 sweeps instead of 6 at config 3 (55.6 -> 49.7 ms, tools/topt_ab.sh); a batch of
                        // 32 directions on top of that certified [18,16,14,10,6]: still 5 sweeps, each slower
@@ -51,20 +50,14 @@ struct Best {
   }
 };
 
-// dot product of a row (read by LPR lanes, two doubles each) with up to NQ directions held in
-// registers, then v <- max(v - d^2, 0) per direction, in direction order
-template <int LPR, int NQ>
-__device__ inline double downdate(double v, f64x2 u, const double (&q0)[NQ], const double (&q1)[NQ], int nq) {
-#pragma unroll
-  for (int t = 0; t < NQ; ++t) {
-    if (t < nq) {
-      double d = u.x * q0[t] + u.y * q1[t];
-      d = group_sum_t<LPR>(d);
-      v -= d * d;
-      v = v < 0.0 ? 0.0 : v;
-    }
-  }
-  return v;
+// candidate step: dot product of a row (read by LPR lanes, two doubles each) with the new direction held in
+// registers, then v <- max(v - d^2, 0)
+template <int LPR>
+__device__ inline double downdate(double v, f64x2 u, double q0, double q1) {
+  double d = u.x * q0 + u.y * q1;
+  d = group_sum_t<LPR>(d);
+  v -= d * d;
+  return v < 0.0 ? 0.0 : v;
 }
 
 // TU: storage type of the basis (f64, or f32 widened on load); every norm and dot product is f64
@@ -423,9 +416,8 @@ __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / LPR, lig = lane % LPR;
   const int k0 = 2 * lig;
-  double q0[1], q1[1];
-  q0[0] = (k0 < r) ? q[k0] : 0.0;
-  q1[0] = (k0 + 1 < r) ? q[k0 + 1] : 0.0;
+  const double q0 = (k0 < r) ? q[k0] : 0.0;
+  const double q1 = (k0 + 1 < r) ? q[k0 + 1] : 0.0;
   const int64_t piv = *piv_ptr;
   double pc[3] = {0.0, 0.0, 0.0};                       // position of the pick (GEM's d_min exclusion, :649-652)
   if (xyz)
@@ -436,7 +428,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
     const bool valid = c < n_cand;
     const f64x2 u = load_row_piece(cand_U + (int64_t)(valid ? c : 0) * ldc, k0, r, true, valid);
     const double old = (valid && lig == 0) ? cand_res[c] : 0.0;
-    double v = downdate<LPR, 1>(old, u, q0, q1, 1);
+    double v = downdate<LPR>(old, u, q0, q1);
     if (valid && lig == 0) {
       if (old < 0.0) v = old;
       if (cand_idx[c] == piv) v = -1.0;
@@ -495,8 +487,10 @@ int pick_lpr(int r) {
   return l;
 }
 
-int sweep_grid(int64_t n_rows, int lpr) {
-  const int rows_it = (QR_THREADS / 64) * (64 / lpr) * QR_UNR;
+// workgroups of a sweep over Ur (each keeps its QR_TOPT best rows: grid * QR_TOPT candidates): one per 64-row panel,
+// at most 4 per CU and QR_MAX_BLOCKS
+int sweep_grid(int64_t n_rows) {
+  const int rows_it = 64;
   int64_t steps = (n_rows + rows_it - 1) / rows_it;
   const int cus = spr_cached_cus();
   int64_t cap = 4LL * (cus > 0 ? cus : 256);
@@ -609,7 +603,7 @@ static int qr_init_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_
   SPR_REQUIRE(d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
+  const int grid = sweep_grid(n_rows);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
   QrWs w(d_workspace);
   rc = launch_refresh<TU, true>(grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, 0, d_nrm, w.tops);
@@ -646,7 +640,7 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   hipStream_t st = static_cast<hipStream_t>(stream);
   QrWs w(d_workspace);
   const int lpr = pick_lpr(r);
-  const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows, lpr) * QR_TOPT;
+  const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows) * QR_TOPT;
   hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_recs, (int)n_rec, d_taus, (int)n_tau,
                      (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok);
   SPR_LAUNCH_CHECK();
@@ -714,7 +708,7 @@ static int qr_refresh_entry(const char *who, const TU *d_Ur, int64_t n_rows, int
   SPR_REQUIRE(j0 >= 0 && nq >= 1 && nq <= QR_BATCH && j0 + nq <= r, SPR_E_INVALID, "%s: bad j0=%d nq=%d", who, j0, nq);
   SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int lpr = pick_lpr(r), grid = sweep_grid(n_rows, lpr);
+  const int grid = sweep_grid(n_rows);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
   QrWs w(d_workspace);
   hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + j0, (int)nq, row0, n_rows, d_nrm);

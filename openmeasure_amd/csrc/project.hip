@@ -17,8 +17,11 @@
 // strided ds_read_b64; with the row stride MP = MPAD + 2 (2 mod 4 doubles) the 32 lanes of a
 // group fall on 32 distinct bank pairs.  B[k = l>>4][j = l&15] = W[k0 + k][16 cg + j].
 // Result: col = l&15, row = (l>>4) + 4 reg.
+#include <stdlib.h>
+
 #include <type_traits>
 
+#include "project_ws.hpp"
 #include "rowtile.hpp"
 
 #ifndef PROJ_PAD
@@ -258,6 +261,17 @@ int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int
   const int need = (r + 15) / 16;
   const int rt = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // W-stationary form first (project_ws.hip): W in LDS, X straight into the MFMA operand registers, no barrier in the
+  // loop -- 15 % faster where both pipes are loaded (m = 256, r = 64).  SPR_PROJECT_WS=0 forces the general kernel
+  // (A/B measurements, and the parity tests run both).
+  if constexpr (std::is_same<TX, TU>::value) {
+    static const bool ws_on = [] { const char *e = getenv("SPR_PROJECT_WS"); return !(e && e[0] == '0'); }();
+    if (ws_on && !d_acc_in && n_rows >= 4096) {
+      const int rc = spr_project_ws<TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                                            d_rowmean, d_W, r, d_Ur, ldu, accumulate, st);
+      if (rc != SPR_E_UNSUPPORTED) return rc;
+    }
+  }
 #define PJ(MTV) return launch_rt<MTV, TX, TU>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, d_acc_in, lda, st)
   switch (spr_round_mt(m)) {
     case 1: PJ(1);

@@ -805,6 +805,7 @@ class ROM:
         if not converged or chk[1] * _GRAM_KAPPA_REFINE < chk[0]:
             return False                                       # the host route decides (refinement pass or LinAlgError)
         self.r = r
+        self.gram_refine_passes_ = 0
         sp['r'] = r
         self._pending = sp
         tr_.report()

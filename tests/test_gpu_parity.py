@@ -202,6 +202,38 @@ def test_project_vs_oracle(eng, n_points, F, m, r):
     assert np.abs(U - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize('n_points,F,m,r,row0_cells,f32', [
+    (3000, 3, 256, 64, 0, False), (2000, 4, 256, 64, 1500, False), (2500, 3, 256, 33, 0, False), (1700, 5, 256, 17, 300, False),
+    (3000, 2, 128, 64, 0, False), (2100, 3, 192, 48, 0, False), (1500, 3, 128, 16, 300, False), (4099, 1, 256, 64, 0, False),
+    (3000, 3, 256, 64, 0, True), (2222, 3, 128, 30, 111, True),
+])
+def test_project_w_stationary_vs_oracle(eng, n_points, F, m, r, row0_cells, f32):
+    """The W-stationary projection kernel (csrc/project_ws.hip: n >= 4096 rows, m in {128, 192, 256} packed, r <= 64):
+    full and ragged tails, r not a multiple of 16, shards starting inside a feature (row0 != 0), f32 storage, and
+    the un-centred form -- against ((X - mean) W) / X_scl formed in NumPy."""
+    import torch
+    X = synth_host(n_points, F, m, min(m, 2 * r), 0.9, 1e-3, 3000 + m + r)
+    if f32:
+        X = X.astype(np.float32).astype(np.float64)
+    X_cnt, X_scl, X0 = orc.scale_data_std(X, F)
+    rng = np.random.default_rng(2)
+    W = rng.standard_normal((m, r))
+    row0 = row0_cells                                           # local block = global rows [row0, n)
+    Xl = X[row0:]
+    assert Xl.shape[0] >= 4096
+    inv = eng.to_device(1.0 / X_scl[::n_points, 0])
+    Xd = eng.to_device(Xl.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(Xl)
+    U = eng.to_host(eng.project(Xd, row0, n_points, F, inv, eng.to_device(W), rowmean=eng.to_device(X_cnt[row0:, 0])))
+    ref = X0[row0:] @ W
+    tol = 2e-7 if f32 else 1e-12                                # f32 basis: one rounding of the f64 result
+    assert U.shape == ref.shape and np.abs(U - ref).max() <= tol * np.abs(ref).max()
+    if not f32:
+        ones = eng.to_device(np.ones(F))
+        U0 = eng.to_host(eng.project(Xd, row0, n_points, F, ones, eng.to_device(W), center=False))
+        ref0 = Xl @ W
+        assert np.abs(U0 - ref0).max() <= 1e-12 * np.abs(ref0).max()
+
+
 @pytest.mark.parametrize('n,r,n_p', [(20, 5, 1), (999, 5, 3), (4096, 32, 1), (5000, 64, 5), (3001, 128, 2), (777, 1, 1), (1234, 14, 2)])
 def test_reconstruct_vs_oracle(eng, n, r, n_p):
     rng = np.random.default_rng(n + r)

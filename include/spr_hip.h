@@ -111,6 +111,16 @@ int spr_spectrum_f64(const double *d_gram, const double *d_fstats_all, int32_t n
                      double *d_scale, double *d_inv_scale, double *d_lam, double *d_S, double *d_expvar,
                      double *d_V, double *d_W, double *d_Ar, double *d_info, void *stream);
 
+/* ---- K3a' : per-feature Gram blocks -> the scaled m x m Gram matrix --------------------
+ * G = sum_f G_f / X_scl_f^2 is the Gram matrix of the reference's X0 = (X - X_cnt)/X_scl (:169) whose SVD :272 takes.
+ * Inputs as for spr_spectrum_f64 (all-reduced d_gram [F][m][m], all-gathered d_fstats_all [n_ranks][F][3], scale_code
+ * 0..7); outputs d_G [m][m], d_feat [F][5] = (count, block mean, block variance (:115), scale, 1/scale), and the scales
+ * d_scale / d_inv_scale [F] that the projection and reconstruction kernels read.  Replaces the host merge of fit():
+ * one download of m^2 + 5 F doubles instead of F m^2, no upload. */
+int spr_gram_combine_f64(const double *d_gram, const double *d_fstats_all, int32_t n_ranks,
+                         int32_t n_features, int32_t m, int32_t scale_code, double *d_G, double *d_feat,
+                         double *d_scale, double *d_inv_scale, void *stream);
+
 /* ---- K4 : basis projection  Ur = X0 . W,  W = V_r Sigma_r^-1 (m x r) ----------------
  * Replaces the U factor of np.linalg.svd (:272) and the truncation U[:, :r] (:336).
  * Second read of X.  center = 1: d_rowmean (the row means written by spr_stats_gram_f64)

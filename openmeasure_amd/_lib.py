@@ -42,6 +42,7 @@ PROTOTYPES = {
     'spr_gram_cross_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
     'spr_spectrum_max_m': (_i32, []),
     'spr_spectrum_f64': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'spr_gram_combine_f64': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _i32, _p]),
     'spr_scale_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
     'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p]),

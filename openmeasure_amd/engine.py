@@ -227,6 +227,18 @@ class HipEngine:
                    'spr_spectrum_f64')
         return out
 
+    def gram_combine(self, gram, fstats_all, scale_type):
+        """gram (F,m,m) all-reduced, fstats_all (ranks,F,3) -> packed (m*m + 5F,) tensor [G | feat], scale (F,),
+        inv_scale (F,) -- the statistics merge, feature scales and scaled sum of fit() on the device."""
+        F, m = gram.shape[0], gram.shape[1]
+        packed = self.empty((m * m + 5 * F,))
+        scale, inv_scale = self.empty((F,)), self.empty((F,))
+        _lib.check(self.lib.spr_gram_combine_f64(_ptr(gram.contiguous()), _ptr(fstats_all.contiguous()),
+                                                 fstats_all.shape[0], F, m, self.SCALE_CODES[scale_type], _ptr(packed),
+                                                 packed.data_ptr() + m * m * 8, _ptr(scale), _ptr(inv_scale),
+                                                 self._stream()), 'spr_gram_combine_f64')
+        return packed, scale, inv_scale
+
     # ---- K4 --------------------------------------------------------------------------------
     _PROJECT_BLOCK_ROWS = 4_000_000
 

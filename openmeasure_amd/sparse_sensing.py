@@ -460,6 +460,23 @@ class ROM:
         tr_.mark('stats_gram')
         gram = self._all_reduce(gram)
         fs_d = self._all_gather(fstats)                      # (world, F, 3)
+        if axis_cnt == 1 and scale_type in getattr(eng, 'SCALE_CODES', ()) and hasattr(eng, 'gram_combine'):
+            # statistics merge, feature scales and G = sum_f G_f / scl_f^2 on the device (csrc/combine.hip): one
+            # download of m^2 + 5F doubles, the scales never leave HBM
+            packed_d, scale_d, inv_d = eng.gram_combine(gram, fs_d, scale_type)
+            packed = eng.to_host(packed_d)
+            tr_.mark('collect')
+            feat = packed[m * m:].reshape(F, 5)
+            self._G = packed[:m * m].reshape(m, m)
+            self._scl_f = feat[:, 3].copy()
+            self._var_f = self._scl_f ** 2
+            self._d['rowmean'] = rowmean
+            self._d['scale'] = scale_d
+            self._d['inv_scale'] = inv_d
+            for k in ('X_cnt', 'X_scl', 'X0'):
+                self._host.pop(k, None)
+            tr_.mark('merge')
+            return
         # one download for both: every host round trip is a sync point the GPU idles at
         packed = eng.to_host(eng.torch.cat([gram.reshape(-1), fs_d.reshape(-1)]))
         G_f = packed[:gram.numel()].reshape(F, m, m)
@@ -487,7 +504,8 @@ class ROM:
             v = cs[:, 1, :] - mu[:, None] * cs[:, 0, :]       # sum_i (mean_i - mu_f) c_i
             G_f = G_f + v[:, :, None] + v[:, None, :] + m2[:, None, None]
             rowmean = eng.fill_feature(Xd.shape[0], self._row0, self.n_points, eng.to_device(mu))
-        self._G_f = G_f
+        with np.errstate(invalid='ignore', divide='ignore'):
+            self._G = np.sum(G_f / self._var_f[:, None, None], axis=0)   # Gram matrix of X0 = (X - X_cnt)/X_scl
         self._d['rowmean'] = rowmean
         self._d['scale'] = eng.to_device(self._scl_f)
         with np.errstate(divide='ignore'):
@@ -705,9 +723,8 @@ class ROM:
         (the pattern of GPR.fit, gpr.py:379-381) the Gram blocks of that pass and the resident X are used instead
         of uploading X0 and reading it twice."""
         eng = self._engine()
-        if X0 is self._host.get('X0') and '_G_f' in self.__dict__ and 'rowmean' in self._d:
-            with np.errstate(invalid='ignore', divide='ignore'):
-                G = np.sum(self._G_f / self._var_f[:, None, None], axis=0)
+        if X0 is self._host.get('X0') and '_G' in self.__dict__ and 'rowmean' in self._d:
+            G = self._G
             self._trace = _Trace(eng)
             self._d.pop('Ur', None)
             Ur_d, Ar, expv, _, r, _ = self._basis_from_gram(G, select_modes, n_modes, True, self._d['inv_scale'])
@@ -749,9 +766,7 @@ class ROM:
         self._stats_pass(scale_type, axis_cnt)
         self._host.clear()
         if basis is None:
-            with np.errstate(invalid='ignore', divide='ignore'):
-                G = np.sum(self._G_f / self._var_f[:, None, None], axis=0)
-            Ur_d, Ar, expv, S, r, V_r = self._basis_from_gram(G, select_modes, n_modes, True, self._d['inv_scale'])
+            Ur_d, Ar, expv, S, r, V_r = self._basis_from_gram(self._G, select_modes, n_modes, True, self._d['inv_scale'])
             self.exp_variance_ = expv
             self.S_ = S
         else:

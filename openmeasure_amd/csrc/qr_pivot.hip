@@ -21,6 +21,10 @@
 // Candidate record (one per rank, all-gathered between steps when sharded), r+3 doubles:
 //   [0] best residual norm^2   [1] its global row (as double, exact below 2^53)
 //   [2] runner-up norm^2 among this rank's candidates   [3..3+r) the row of Ur
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "rowtile.hpp"
 
 namespace {
@@ -264,6 +268,98 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
   // entry of its row, (lane & 15) = (lane >> 4) + 4 i
   const bool owner = INIT ? (((lane & 15) & 3) == (lane >> 4)) : ((lane & 15) == 0);
   const int slot = INIT ? ((lane >> 4) * 4 + ((lane & 15) >> 2)) : (lane >> 4);
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
+}
+
+// Refresh / init sweep, register-direct form (r a multiple of 16, rows 16-byte aligned): the same arithmetic, the same
+// row -> wave -> lane assignment and therefore the same candidate lists as qr_refresh_mfma_kernel, but the rows of Ur
+// go HBM -> registers directly in the MFMA A layout instead of through an LDS panel behind a barrier.  Lane
+// (i = l & 15, kk = l >> 4) owns row i of its wave's 16-row block and loads the four consecutive elements
+// [16 g + 4 kk, +4) of it for g = 0 .. r/16 - 1 (one 16-byte piece of an f32 row, two of an f64 row); MFMA step 4 g + t
+// contracts over column 16 g + 4 kk + t, and the direction fragments are permuted the same way once per kernel.
+// Waves are independent: no LDS traffic, no barrier until the final list merge; the next block of the wave is
+// requested before the current one is multiplied.  An f32-stored basis moves half the bytes per block with the
+// same (small) fixed cost per block, which is what kept the LDS form at 2.9-3.6 TB/s on it.
+template <int NG, typename TU, bool INIT>
+__global__ __launch_bounds__(QR_THREADS) void qr_refresh_direct_kernel(
+    const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
+    const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
+  constexpr int NW = QR_THREADS / 64, R = 64;
+  constexpr int SPW = INIT ? 16 : 4;
+  __shared__ double smem[2 * (QR_THREADS / 64) * SPW * QR_TOPT];
+  double *const sval = smem;
+  long long *const sidx = reinterpret_cast<long long *>(smem + (QR_THREADS / 64) * SPW * QR_TOPT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kk = lane >> 4;
+  using P4 = typename std::conditional<std::is_same<TU, float>::value, float4, double4>::type;
+
+  double bfrag[4 * NG];          // B[k][j] = Q[j][k] at the permuted k of step 4 g + t
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      bfrag[4 * g + t] = (!INIT && li < nq) ? Q[(int64_t)li * r + 16 * g + 4 * kk + t] : 0.0;
+  TopList top;
+  top.init();
+  const int64_t npanels = (n_rows + R - 1) / R;
+  auto load_block = [&](int64_t c, P4 (&dst)[NG]) {
+    int64_t row = c * R + wave * 16 + li;
+    row = row < n_rows ? row : n_rows - 1;                  // rows past the end re-read the last row; never stored
+    const TU *rp = Ur + row * ldu + 4 * kk;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) dst[g] = *reinterpret_cast<const P4 *>(rp + 16 * g);
+  };
+  int64_t c = blockIdx.x;
+  P4 cur[NG], nxt[NG];
+  if (c < npanels) load_block(c, cur);
+  while (c < npanels) {
+    const int64_t cn = c + gridDim.x;
+    load_block(cn < npanels ? cn : c, nxt);
+    const int64_t brow = c * R + wave * 16 + kk;           // this lane's first output row of the block
+    double old[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t rr = brow + 4 * i;
+      old[i] = INIT ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];
+    }
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const double a4[4] = {(double)cur[g].x, (double)cur[g].y, (double)cur[g].z, (double)cur[g].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], INIT ? a4[t] : bfrag[4 * g + t], acc, 0, 0, 0);
+    }
+    if (INIT) {
+      const double dv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rr = brow + 4 * i;
+        const bool mine = (li == kk + 4 * i) && (rr < n_rows);
+        if (mine) nrm[rr] = dv[i];
+        top.insert(dv[i], row0 + rr, mine);
+      }
+    } else {
+      const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
+                            group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rr = brow + 4 * i;
+        const bool mine = (li == 0) && (rr < n_rows);
+        double v = old[i] - d2[i];
+        v = v < 0.0 ? 0.0 : v;
+        v = old[i] < 0.0 ? -1.0 : v;
+        if (mine) nrm[rr] = v;
+        top.insert(v, row0 + rr, mine);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
+    c = cn;
+  }
+  const bool owner = INIT ? ((li & 3) == kk) : (li == 0);
+  const int slot = INIT ? (kk * 4 + (li >> 2)) : kk;
   top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
 }
 
@@ -522,6 +618,28 @@ int launch_refresh(int grid, hipStream_t st, const TU *Ur, int64_t n_rows, int r
                    const double *Qj, int nq, double *nrm, double *tops) {
   const int mtr = spr_round_mt(r);      // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
   const int lm = vec_ok ? ((r == 16 * mtr) ? 2 : 1) : 0;
+  // register-direct form: whole 16-column groups, 16-byte aligned pieces (SPR_QR_DIRECT=0 keeps the LDS-panel form)
+  static const bool direct_on = [] { const char *e = getenv("SPR_QR_DIRECT"); return !(e && e[0] == '0'); }();
+  // measured (MI355X, 9M rows x 64, one launch): init 1.13 ms direct vs 1.39 LDS; f64 refresh with 8 directions 1.02 vs
+  // 0.91 (the LDS form's 4-rows-per-instruction loads stream better); f32 basis, config-5 share: placement 138 vs 186 ms
+  const bool want_direct = INIT || std::is_same<TU, float>::value;
+  if (direct_on && want_direct && r % 16 == 0 && (ldu * sizeof(TU)) % 16 == 0 &&
+      (reinterpret_cast<uintptr_t>(Ur) & 15) == 0) {
+#define RD(NGV) hipLaunchKernelGGL((qr_refresh_direct_kernel<NGV, TU, INIT>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, row0, Qj, nq, nrm, tops)
+    switch (r / 16) {
+      case 1: RD(1); break;
+      case 2: RD(2); break;
+      case 3: RD(3); break;
+      case 4: RD(4); break;
+      case 5: RD(5); break;
+      case 6: RD(6); break;
+      case 7: RD(7); break;
+      default: RD(8); break;
+    }
+#undef RD
+    SPR_LAUNCH_CHECK();
+    return SPR_OK;
+  }
 #define RF(MTV, LM) hipLaunchKernelGGL((qr_refresh_mfma_kernel<MTV, LM, TU, INIT>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, row0, Qj, nq, nrm, tops)
 #define RFV(MTV) do { if (lm == 2) RF(MTV, 2); else if (lm == 1) RF(MTV, 1); else RF(MTV, 0); } while (0)
   switch (mtr) {

@@ -446,6 +446,21 @@ class HipEngine:
                                                _ptr(st['rec']), _ptr(st['tau']), _ptr(st['ws']),
                                                st['ws'].numel(), self._stream()), 'spr_qr_refresh_f64')
 
+    def qr_apply(self, st, dirs, picks):
+        """Down-date every row with the given directions (k, r) -- nrm <- max(nrm - (u.d)^2, 0) per direction --, take
+        the rows `picks` (k int64 global rows, -1 = none) out of the pool and redraw candidates / record / tau.  Same
+        sweep kernel as qr_refresh, for directions that did not come out of the candidate steps (GEM's ridge phase)."""
+        k = dirs.shape[0]
+        t = self.torch
+        for j0 in range(0, k, self.qr_batch):
+            nq = min(self.qr_batch, k - j0)
+            Qv = dirs[j0:j0 + nq].contiguous()
+            pv = picks[j0:j0 + nq].contiguous().to(t.int64)
+            _lib.check(self._u('spr_qr_refresh', st['Ur'])(_ptr(st['Ur']), st['n'], st['r'], st['ldu'], st['row0'],
+                                                          _ptr(Qv), _ptr(pv), 0, nq, _ptr(st['nrm']), _ptr(st['rec']),
+                                                          _ptr(st['tau']), _ptr(st['ws']), st['ws'].numel(),
+                                                          self._stream()), 'spr_qr_refresh_f64')
+
     # ---- K7 + K8 -------------------------------------------------------------------------------
     def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean, scale=None, n_points=0):
         """-> Theta (s,r), cnt (s,) [, scl (s,) = C . X_scl when the per-feature scale is given]."""

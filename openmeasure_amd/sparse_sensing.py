@@ -31,9 +31,11 @@ What differs from the reference, by design:
   * fitted arrays live in HBM; ``X_cnt``, ``X_scl``, ``Ur``, ... are copied to NumPy on
     first access;
   * a float32 X is stored as float32 (and so is Ur); all arithmetic is float64;
-  * options that have no device implementation ('COLS', 'gem' beyond r-1 sensors, the
-    kurtosis scalings 'vast_2..4', which are ill-defined in the reference itself) raise
-    ``NotImplementedError`` -- they never fall back to a CPU path.
+  * 'gem' placement is the noise-free limit of the reference's rule (it adds unseeded noise, :667) for the first
+    r-1 sensors and, beyond, a deterministic ridge stand-in for that noise (see _gem_ridge_phase);
+  * at most 128 retained modes / sensors per QR placement and 512 snapshots are built (SPR_MAX_R, SPR_MAX_M_WIDE);
+  * options that have no device implementation ('COLS', the kurtosis scalings 'vast_2..4', which are
+    ill-defined in the reference itself) raise ``NotImplementedError`` -- they never fall back to a CPU path.
 
 Row sharding: pass ``shard=RowShard(row0, n_global, group)`` and the local block of rows;
 the Gram matrix is all-reduced, pivot candidates are all-gathered per step, Theta is
@@ -924,9 +926,8 @@ class SPR(ROM):
         r = self.r
         if type(n_sensors) is not int or n_sensors < 1:
             raise ValueError('n_sensors must be a positive integer.')
-        if n_sensors > r - 1:
-            raise NotImplementedError(f'gem with n_sensors={n_sensors} > r-1={r - 1}: the covariance of the picked rows '
-                                      'is singular there and the reference result is set by its unseeded noise.')
+        if r < 3:
+            raise NotImplementedError('gem needs at least three modes (row variances over r entries, r-1 >= 2 picks).')
         mask_d = None
         if mask is not None:
             mask = np.asarray(mask)
@@ -940,13 +941,17 @@ class SPR(ROM):
                 raise ValueError('gem with d_min > 0 needs xyz of shape (n_points, 1..3).')
             near = (eng.to_device(xyz), self.n_points, float(d_min))
         s = n_sensors
+        s_exact = min(s, r - 1)                               # picks the noise-free rule defines (S_aa regular)
         st = eng.qr_begin(Ur_d, self._row0, s + 1)
         st['Q'][0] = r ** -0.5                                # centring direction; no row is attached to it
         st['piv'][0] = -1
         if mask_d is not None:
             eng.qr_exclude(st, mask=mask_d, n_points=self.n_points)
         eng.qr_refresh(st, 0, 1)
-        sweeps = 1 + pivot_loop(eng, st, s + 1, self._all_gather if self._dist() else None, start=1, near=near)
+        gather = self._all_gather if self._dist() else None
+        sweeps = 1 + pivot_loop(eng, st, s_exact + 1, gather, start=1, near=near)
+        if s > s_exact:
+            sweeps += self._gem_ridge_phase(st, s_exact, s, mask_d, near)
         self.pivot_sweeps_ = sweeps
         piv = eng.to_host(st['piv'])[1:].astype(np.int64)
         self.sensors_ = piv
@@ -958,6 +963,74 @@ class SPR(ROM):
             C = C.toarray()
         self._placed = (C, piv)
         return C
+
+    _GEM_RIDGE = 1e-5      # RMS of the reference's unseeded regularisation noise (:667), in its scaled units
+
+    def _gem_ridge_phase(self, st, s_exact, s, mask_d, near):
+        """GEM picks beyond r-1 sensors.  After r-1 picks the covariance of the picked rows spans the whole centred
+        space: every conditional variance is zero and the reference's choice is made by the unseeded noise
+        1e-5*N(0,1) it adds to the diagonal of S_aa before inverting it (:667-668).  Documented deterministic
+        stand-in: the noise is replaced by its RMS, S_aa + 1e-5 I (in the reference's scaled units, coef =
+        2/sqrt(max row variance), :622-624), i.e. ridge-regularised conditional variances
+
+            v(y) = (r-1) [s_yy - S_ya (S_aa + d I)^-1 S_ay] = d' u_y^T (U_a^T U_a + d' I)^-1 u_y,   d' = d (r-1),
+
+        u = rows of Ur centred over their r entries.  v is what the sweep kernels' residual array holds: each pick u
+        down-dates it by (g.u_y)^2 with the Sherman-Morrison direction g = A^-1 u sqrt(d'/(1 + u^T A^-1 u)),
+        A = U_a^T U_a + d' I -- for d' -> 0 the orthonormalised residual direction of the noise-free phase.  A row
+        is never picked twice; mask and d_min act as before.  One sweep over Ur per extra sensor."""
+        eng = self._engine()
+        t = eng.torch
+        r = self.r
+        Ur_d = self._d['Ur']
+        piv = eng.to_host(st['piv'])[1:s_exact + 1].astype(np.int64)
+        # the picked rows of Ur (each lives on one rank)
+        ip, ix, v = self._csr_device(None, (np.arange(s_exact + 1), piv, np.ones(s_exact)))
+        rows_d, _ = eng.measure_csr(ip, ix, v, Ur_d, self._row0, self._d['rowmean'])
+        Ua = eng.to_host(self._all_reduce(rows_d))
+        Uc = Ua - Ua.mean(axis=1, keepdims=True)
+        var_max = np.sum(Uc[0] ** 2) / (r - 1)                 # the first pick is the row of largest variance (:641)
+        dprime = self._GEM_RIDGE * var_max / 4.0 * (r - 1)
+        lam, Qe = np.linalg.eigh(Uc.T @ Uc)
+        lam = np.maximum(lam, 0.0)
+        one = np.full(r, r ** -0.5)
+        Qe = Qe - np.outer(one, one @ Qe)                       # eigenvectors inside the centred space
+        keep = np.linalg.norm(Qe, axis=0) > 0.5                 # drops the eigenvector along 1
+        lam, Qe = lam[keep], Qe[:, keep] / np.linalg.norm(Qe[:, keep], axis=0)
+        Ainv = (Qe / (lam + dprime)) @ Qe.T
+        # residual array from scratch: v = |u_c|^2 - sum_k lam_k/(lam_k + d') (q_k.u)^2
+        st2 = eng.qr_begin(Ur_d, self._row0, s + 1)
+        st2['piv'][:s_exact + 1] = st['piv'][:s_exact + 1]
+        if mask_d is not None:
+            eng.qr_exclude(st2, mask=mask_d, n_points=self.n_points)
+        if near is not None:
+            for j0 in range(1, s_exact + 1, eng.qr_batch):
+                eng.qr_exclude(st2, xyz=near[0], n_points=near[1], j0=j0, nq=min(eng.qr_batch, s_exact + 1 - j0),
+                               d_min=near[2])
+        dirs = np.vstack([one[None, :], (Qe * np.sqrt(lam / (lam + dprime))).T])
+        picks0 = np.concatenate([[-1], piv, -np.ones(dirs.shape[0] - 1 - s_exact, dtype=np.int64)])[:dirs.shape[0]]
+        eng.qr_apply(st2, eng.to_device(dirs), eng.to_device(picks0, dtype=t.int64))
+        sweeps = 1 + -(-dirs.shape[0] // eng.qr_batch)
+        for j in range(s_exact + 1, s + 1):
+            recs = eng.to_host(self._all_gather(st2['rec']))   # (ranks, r+3): value, global row, runner-up, row of Ur
+            order = np.lexsort((recs[:, 1], -recs[:, 0]))
+            best = recs[order[0]]
+            if not best[0] > 0.0:
+                raise RuntimeError('gem: no admissible row left for the remaining sensors (mask / d_min too strict)')
+            others = [best[2]] + [recs[i, 0] for i in order[1:]]
+            u = best[3:3 + r] - best[3:3 + r].mean()
+            g = Ainv @ u
+            den = 1.0 + u @ g
+            Ainv -= np.outer(g, g) / den
+            st2['piv'][j] = int(best[1])
+            st2['gap'][j] = (best[0] - max(others)) / best[0]
+            if near is not None:
+                eng.qr_exclude(st2, xyz=near[0], n_points=near[1], j0=j, nq=1, d_min=near[2])
+            eng.qr_apply(st2, eng.to_device((g * np.sqrt(dprime / den))[None, :]), st2['piv'][j:j + 1])
+            sweeps += 1
+        st['piv'][s_exact + 1:] = st2['piv'][s_exact + 1:]
+        st['gap'][s_exact + 1:] = st2['gap'][s_exact + 1:]
+        return sweeps
 
     # ------------------------------------------------------------------ a7 train
     def train(self, C, is_Theta=False, limits=None, method='OLS', solver='CLARABEL', cond=False, verbose=False):

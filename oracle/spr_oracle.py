@@ -211,7 +211,7 @@ def qr_pivots(Ur, mask=None):
     return np.asarray(P[:r], dtype=np.int64), Ur
 
 
-def gem_pivots(Ur, n_sensors, xyz, n_features, mask=None, d_min=0.0, noise=None):
+def gem_pivots(Ur, n_sensors, xyz, n_features, mask=None, d_min=0.0, noise=None, ridge=None):
     """SPR.gem (:586-698): greedy conditional-variance ("entropy") maximisation.
 
     Follows the reference statement by statement -- row variances with ddof=1 over the r entries (:621, :637),
@@ -222,6 +222,12 @@ def gem_pivots(Ur, n_sensors, xyz, n_features, mask=None, d_min=0.0, noise=None)
     (:670) is evaluated for all candidates at once (same covariance entries: centred dot products / (r-1)).
     ``noise``: None -> the regularisation-free limit (what the device path computes);
                a callable k -> vector of length k to reproduce the reference's 1e-5*np.random.normal (:667).
+    ``ridge``: None -> the reference's rule throughout.  A number d (the product uses 1e-5, the RMS of that noise):
+               from the r-th pick on -- where S_aa of the r-1 picks already spans the centred space, every conditional
+               variance is zero and the reference's choice is decided by its unseeded noise alone -- the noise is
+               replaced by d on the whole diagonal (S_aa + d I), and rows already picked are no longer candidates.
+               This is the documented deterministic stand-in of openmeasure_amd for n_sensors > r-1; parity with the
+               reference is undefined there (its result changes from run to run).
     Returns the picked global rows (int64) and the relative lead of every pick over the runner-up."""
     Ur = np.asarray(Ur, dtype=np.float64)
     n, r = Ur.shape
@@ -245,6 +251,8 @@ def gem_pivots(Ur, n_sensors, xyz, n_features, mask=None, d_min=0.0, noise=None)
         if s == 0:
             temp = sigma_coef
         else:
+            if ridge is not None and s >= r - 1:
+                mask_d = mask_d & ~np.isin(index_msk, picks)
             Ur_msk, xyz_msk, index_msk = Ur_msk[mask_d], xyz_msk[mask_d], index_msk[mask_d]
             A = Ur_scl[picks, :]
             Ac = A - A.mean(axis=1, keepdims=True)
@@ -253,6 +261,8 @@ def gem_pivots(Ur, n_sensors, xyz, n_features, mask=None, d_min=0.0, noise=None)
                 S_inv = 1 / S_aa
             else:
                 reg = np.zeros(s) if noise is None else np.asarray(noise(s))
+                if ridge is not None and s >= r - 1:
+                    reg = np.full(s, float(ridge))
                 S_inv = np.linalg.inv(S_aa + np.diag(reg))
             Yc = Ur_msk - Ur_msk.mean(axis=1, keepdims=True)
             S_ya = Yc @ Ac.T / (r - 1)                            # rows: Sigma[-1, :-1] of every candidate

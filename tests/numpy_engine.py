@@ -209,6 +209,20 @@ class NumpyEngine:
             nrm[:] = new
             self._record(st)
 
+    def qr_apply(self, st, dirs, picks):
+        nrm = st['nrm'].numpy()
+        U = self._w(st['Ur'])
+        for q in dirs.numpy():
+            d = U @ q
+            new = np.maximum(nrm - d * d, 0.0)
+            new[nrm < 0] = -1.0
+            nrm[:] = new
+        for g in picks.numpy():
+            li = int(g) - st['row0']
+            if g >= 0 and 0 <= li < st['n']:
+                nrm[li] = -1.0
+        self._record(st)
+
     # K7 + K8
     def measure_csr(self, indptr, indices, vals, Ur, row0, rowmean, scale=None, n_points=0):
         ip, ix, v = indptr.numpy(), indices.numpy(), vals.numpy()

@@ -305,3 +305,27 @@ def run_conditioning_guard(engine, decades, synth):
     sg = align_signs(spr.Ar, st['Ar'])
     np.testing.assert_allclose(spr.Ur * sg, st['Ur'], rtol=0, atol=max(1e-9, 1e3 * eps_k) * np.abs(st['Ur']).max())
     return spr
+
+
+def run_gem_beyond_rank(engine, n_points, F, r, n_sensors, d_min, masked, seed, xyz_dim=3):
+    """calc_type='gem' with more sensors than r-1: the first r-1 picks are the noise-free rule (pinned by the
+    reference fixtures), the rest follow the documented ridge stand-in for the reference's unseeded noise --
+    compared with the oracle's literal covariance formulas (gem_pivots(ridge=1e-5)): exact and ordered."""
+    from oracle import spr_oracle as orc
+    rng = np.random.default_rng(seed)
+    n = n_points * F
+    Ur, _ = np.linalg.qr(rng.standard_normal((n, r)) * (1.0 + 3.0 * rng.random((n, 1))))
+    xyz = rng.random((n_points, xyz_dim))
+    mask = (rng.random(n) < 0.6) if masked else None
+    want, lead = orc.gem_pivots(Ur, n_sensors, xyz, F, mask, d_min, ridge=1e-5)
+    assert lead[:r - 1].min() > 1e-6 and lead[r - 1:].min() > 1e-6   # no near-ties: the comparison is meaningful
+    spr = SPR(rng.standard_normal((n, 4)), F, xyz, engine=engine)
+    spr.fit(basis=(Ur.copy(), np.eye(4, r)))
+    C = spr.optimal_placement(calc_type='gem', n_sensors=n_sensors, mask=mask, d_min=d_min)
+    assert C.shape == (n_sensors, n)
+    np.testing.assert_array_equal(spr.sensors_, want)
+    assert len(set(spr.sensors_.tolist())) == n_sensors
+    first, _ = orc.gem_pivots(Ur, r - 1, xyz, F, mask, d_min)          # the reference's own (noise-free) rule
+    np.testing.assert_array_equal(spr.sensors_[:r - 1], first)
+    return spr
+

@@ -142,6 +142,48 @@ def test_sharded_gem_matches_reference(tmp_path, fixture, world):
         assert tuple(o['C_shape']) == tuple(g['C_shape'])
 
 
+def _gem_ridge_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.numpy_engine import NumpyEngine
+        Ur, xyz, F, r = _gem_ridge_case()
+        n = Ur.shape[0]
+        n_loc = n // world
+        row0 = rank * n_loc
+        sl = slice(row0, row0 + n_loc)
+        spr = SPR(np.zeros((n_loc, 4)), F, xyz, shard=RowShard(row0, n), engine=NumpyEngine())
+        spr.fit(basis=(np.ascontiguousarray(Ur[sl]), np.eye(4, r)))
+        spr.optimal_placement(calc_type='gem', n_sensors=r + 4, d_min=0.05)
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_)
+    finally:
+        dist.destroy_process_group()
+
+
+def _gem_ridge_case():
+    rng = np.random.default_rng(77)
+    n_points, F, r = 120, 3, 5
+    n = n_points * F
+    Ur, _ = np.linalg.qr(rng.standard_normal((n, r)) * (1.0 + 3.0 * rng.random((n, 1))))
+    return Ur, rng.random((n_points, 3)), F, r
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_gem_beyond_rank(tmp_path, world):
+    """GEM with more sensors than r-1 over row shards: the picked rows are collected with an all-reduce, every extra
+    pick is agreed on from the all-gathered per-rank records; same sensors as the oracle's ridge rule."""
+    from oracle import spr_oracle as orc
+    Ur, xyz, F, r = _gem_ridge_case()
+    want, lead = orc.gem_pivots(Ur, r + 4, xyz, F, None, 0.05, ridge=1e-5)
+    assert lead.min() > 1e-6
+    mp.spawn(_gem_ridge_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for k in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f'rank{k}.npz')['piv'], want)
+
+
 def _f32_worker(rank, world, port, fixture, out_dir):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'

@@ -9,7 +9,7 @@ import pytest
 
 from oracle import spr_oracle as orc
 from tests.parity import (REL_FRO, align_signs, rel_fro, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style,
-                          run_conditioning_guard, run_pinv_fixture)
+                          run_conditioning_guard, run_gem_beyond_rank, run_pinv_fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -395,6 +395,12 @@ def test_predict_moderately_ill_conditioned_theta(eng, cond, tol):
 @pytest.mark.parametrize('decades', [3, 5, 7, 9, 11, 13])
 def test_conditioning_guard(eng, decades):                # sigma_1/sigma_r up to 1e13: exact sensors or LinAlgError
     run_conditioning_guard(eng, decades, synth_host)
+
+
+@pytest.mark.parametrize('n_points,F,r,n_sensors,d_min,masked', [(150, 2, 5, 9, 0.0, False), (2000, 3, 16, 24, 0.03, True),
+                                                              (5000, 2, 8, 40, 0.0, False), (700, 4, 33, 40, 0.02, False)])
+def test_gem_beyond_rank(eng, n_points, F, r, n_sensors, d_min, masked):   # more sensors than r-1: ridge rule vs oracle
+    run_gem_beyond_rank(eng, n_points, F, r, n_sensors, d_min, masked, 50 + r)
 
 
 def test_pinv_fixture(golden_pinv, eng):                  # :873-878 -- underdetermined / rank-deficient / ill-conditioned

@@ -7,7 +7,7 @@ import scipy.sparse as sp
 
 from openmeasure_amd.sparse_sensing import ROM, SPR
 from tests.numpy_engine import NumpyEngine
-from tests.parity import (run_conditioning_guard, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style,
+from tests.parity import (run_conditioning_guard, run_f32_storage, run_gem_beyond_rank, run_fixture, run_gem_fixture, run_gpr_style,
                           run_pinv_fixture)
 
 
@@ -23,6 +23,12 @@ def test_gpr_style_subclass(golden, foreign):           # gpr.py:379-402: a ROM 
 
 def test_gem_fixture_through_host_logic(golden_gem):   # :586-698
     run_gem_fixture(golden_gem, NumpyEngine())
+
+
+@pytest.mark.parametrize('n_points,F,r,n_sensors,d_min,masked', [(150, 2, 5, 9, 0.0, False), (200, 3, 6, 8, 0.08, True),
+                                                              (120, 2, 4, 20, 0.0, False)])
+def test_gem_beyond_rank_through_host_logic(n_points, F, r, n_sensors, d_min, masked):
+    run_gem_beyond_rank(NumpyEngine(), n_points, F, r, n_sensors, d_min, masked, 5 + r)
 
 
 def test_pinv_fixture_through_host_logic(golden_pinv):  # :873-878 minimum-norm / rank-deficient / ill-conditioned
@@ -94,8 +100,8 @@ def test_unsupported_options_raise_not_fallback(small):
     with pytest.raises(NotImplementedError):
         spr.fit(axis_cnt=0)
     spr.fit(n_modes=100)
-    with pytest.raises(NotImplementedError):
-        spr.optimal_placement(calc_type='gem', n_sensors=spr.r)      # > r-1: decided by the reference's noise
+    Cg = spr.optimal_placement(calc_type='gem', n_sensors=spr.r + 2)  # > r-1: deterministic ridge stand-in for the noise
+    assert Cg.shape == (spr.r + 2, 20) and len(set(spr.sensors_.tolist())) == spr.r + 2
     with pytest.raises(ValueError):
         spr.optimal_placement(calc_type='gem', n_sensors=0)
     with pytest.raises(NotImplementedError):

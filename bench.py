@@ -121,9 +121,10 @@ def launch_ranks(n, argv, env_extra=None, timeout=None, relay=sys.stdout):
     import threading
 
     def pump():
-        for line in out0:
-            relay.write(line)
-            relay.flush()
+        for line in out0:                                      # rank 0's JSON line goes to stdout, anything else to stderr
+            dst = relay if line.lstrip().startswith('{') else sys.stderr
+            dst.write(line)
+            dst.flush()
     th = threading.Thread(target=pump, daemon=True)
     th.start()
     live = set(range(n))
@@ -189,6 +190,12 @@ def main():
 
 
 def run_rank(args):
+    # exactly ONE line may reach stdout (the JSON line of rank 0): RCCL prints a version banner to the C-level stdout
+    # when its communicator is created, so file descriptor 1 points at stderr for the whole run and the JSON line is
+    # written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from openmeasure_amd.engine import HipEngine
@@ -432,7 +439,8 @@ def run_rank(args):
         if extra:
             out['extra'] = extra
         out['peak_hbm_GB'] = round(torch.cuda.max_memory_allocated() / 1e9, 2)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

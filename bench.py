@@ -48,6 +48,7 @@ WORKLOADS = {
     # config 4: config 3's matrix, 10M cells IN TOTAL, split into 10M/N cells' worth of rows per rank
     'c4': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=100_000, scaling='strong'),
     'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000),   # c3 at 1/10 of the rows
+    'c4s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000, scaling='strong'),   # c4 at 1/10 (rehearsals)
     # config-5 shape (16 features x 512 snapshots, 128 sensors) in f64 at 1M cells/GPU (65.5 GB): the column-split path
     'c5s': dict(cells=1_000_000, features=16, m=512, s=128, cpu_cells=15_000),
     # config 5 as BASELINE.json states it: 50M cells x 16 features x 512 snapshots over 8 GPUs = 6.25M cells (100M
@@ -182,7 +183,7 @@ def main():
         # (device_count() below does not initialise it either).
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get('SPR_BENCH_ONE_GPU') != '1':
             log(f'bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)')
             sys.exit(2)
         sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
@@ -208,6 +209,12 @@ def run_rank(args):
     if env_world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU '
                          '(or drop WORLD_SIZE and let bench.py start the ranks)')
+    # Rehearsal of the N-rank code path on a box with ONE GPU (RCCL refuses two ranks on one device):
+    # SPR_BENCH_ONE_GPU=1 puts every rank on cuda:0 and SPR_BENCH_BACKEND=gloo moves the collectives to gloo (staged
+    # through the host).  The line says so; such a run measures nothing, it only exercises the code.
+    backend = os.environ.get('SPR_BENCH_BACKEND', 'nccl')
+    if os.environ.get('SPR_BENCH_ONE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     share = args.share_of if args.share_of > 1 else 0
     force_dist = os.environ.get('SPR_FORCE_DIST', '0') == '1' or bool(share)   # exercise the RCCL path with one rank
@@ -216,7 +223,10 @@ def run_rank(args):
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        else:
+            dist.init_process_group(backend)
         world = dist.get_world_size()                 # the RCCL communicator's size is what gets reported
     else:
         world = 1
@@ -432,6 +442,8 @@ def run_rank(args):
             'config': {'workload': what, 'rows_per_gpu': n_loc, 'rows_total': n_job,
                        'snapshot_GB_per_gpu': round(n_loc * m * B / 1e9, 3), 'storage': 'f32' if f32 else 'f64'},
             'hbm_roofline_frac_step': round(hbm_frac, 4),
+            **({'rehearsal': f'{backend} backend, all ranks on one GPU: exercises the code path, measures nothing'}
+               if (backend != 'nccl' or os.environ.get('SPR_BENCH_ONE_GPU') == '1') else {}),
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
         }
         if per_rank:

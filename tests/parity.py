@@ -283,21 +283,34 @@ def run_f32_storage(engine, n_points, F, m, r, seed, synth):
     return spr
 
 
-def run_conditioning_guard(engine, decades, synth):
+def run_conditioning_guard(engine, decades, synth, f32=False):
     """Gram route on a designed spectrum sigma_1/sigma_r ~ 10^decades: fit() must either return the reference's
     sensors exactly (refinement pass of _refine_spectrum) or refuse with LinAlgError -- never degrade silently."""
     from oracle import spr_oracle as orc
     X = synth(1500, 3, 20, 20, 10 ** (-decades / 9), 1e-16, 77 + decades)
+    if f32:                                                   # f32 STORAGE: the problem is the rounded data, solved in f64
+        X32 = X.astype(np.float32)
+        X = X32.astype(np.float64)
     st = orc.fit(X, 3, 'number', 10)
     piv, _ = orc.qr_pivots(st['Ur'])
     kappa = st['Sigma_r'][0] / st['Sigma_r'][-1]
-    spr = SPR(X, 3, None, engine=engine)
+    spr = SPR(X32 if f32 else X, 3, None, engine=engine)
     try:
         spr.fit(select_modes='number', n_modes=10)
     except np.linalg.LinAlgError as e:
         assert kappa > 1e8 and 'refinement' in str(e)
         return None
     assert (spr.gram_refine_passes_ > 0) == (kappa > 1e4)
+    if f32:
+        # the basis is stored in f32: the sensors are dgeqp3's pivots on the STORED basis; it agrees with the f64 basis of
+        # the same data to f32 rounding
+        sgn = align_signs(spr.Ar, st['Ar'])
+        np.testing.assert_allclose(spr.Ur.astype(np.float64) * sgn, st['Ur'], rtol=0, atol=3e-7 * np.abs(st['Ur']).max())
+        spr.optimal_placement()
+        want, _ = orc.qr_pivots(spr.Ur.astype(np.float64))
+        np.testing.assert_array_equal(spr.sensors_, want)
+        np.testing.assert_allclose(spr.Sigma_r, st['Sigma_r'], rtol=max(1e-9, 100 * np.finfo(float).eps * kappa))
+        return spr
     spr.optimal_placement()
     np.testing.assert_array_equal(spr.sensors_, piv)
     eps_k = np.finfo(float).eps * kappa

@@ -395,6 +395,8 @@ def test_predict_moderately_ill_conditioned_theta(eng, cond, tol):
 @pytest.mark.parametrize('decades', [3, 5, 7, 9, 11, 13])
 def test_conditioning_guard(eng, decades):                # sigma_1/sigma_r up to 1e13: exact sensors or LinAlgError
     run_conditioning_guard(eng, decades, synth_host)
+    if decades in (5, 7):                                  # f32-stored data: refinement through spr_project_x32_f64out
+        run_conditioning_guard(eng, decades, synth_host, f32=True)
 
 
 @pytest.mark.parametrize('n_points,F,r,n_sensors,d_min,masked', [(150, 2, 5, 9, 0.0, False), (2000, 3, 16, 24, 0.03, True),

@@ -48,6 +48,8 @@ def _synth(n_points, F, m, k, rho, eps, seed):
 @pytest.mark.parametrize('decades', [3, 6, 9, 12])
 def test_conditioning_guard_through_host_logic(decades):   # SURVEY 7 hard part 1: exact sensors or explicit refusal
     run_conditioning_guard(NumpyEngine(), decades, _synth)
+    if decades == 6:
+        run_conditioning_guard(NumpyEngine(), decades, _synth, f32=True)
 
 
 @pytest.mark.parametrize('n_points,F,m,r', [(400, 3, 12, 4), (300, 2, 41, 14)])

@@ -283,20 +283,21 @@ def run_f32_storage(engine, n_points, F, m, r, seed, synth):
     return spr
 
 
-def run_conditioning_guard(engine, decades, synth, f32=False):
+def run_conditioning_guard(engine, decades, synth, f32=False, shape=(1500, 3, 20, 10)):
     """Gram route on a designed spectrum sigma_1/sigma_r ~ 10^decades: fit() must either return the reference's
     sensors exactly (refinement pass of _refine_spectrum) or refuse with LinAlgError -- never degrade silently."""
     from oracle import spr_oracle as orc
-    X = synth(1500, 3, 20, 20, 10 ** (-decades / 9), 1e-16, 77 + decades)
+    n_points, F, m, r = shape
+    X = synth(n_points, F, m, min(m, 2 * r), 10 ** (-decades / (r - 1)), 1e-16, 77 + decades)
     if f32:                                                   # f32 STORAGE: the problem is the rounded data, solved in f64
         X32 = X.astype(np.float32)
         X = X32.astype(np.float64)
-    st = orc.fit(X, 3, 'number', 10)
+    st = orc.fit(X, F, 'number', r)
     piv, _ = orc.qr_pivots(st['Ur'])
     kappa = st['Sigma_r'][0] / st['Sigma_r'][-1]
-    spr = SPR(X32 if f32 else X, 3, None, engine=engine)
+    spr = SPR(X32 if f32 else X, F, None, engine=engine)
     try:
-        spr.fit(select_modes='number', n_modes=10)
+        spr.fit(select_modes='number', n_modes=r)
     except np.linalg.LinAlgError as e:
         assert kappa > 1e8 and 'refinement' in str(e)
         return None

@@ -397,6 +397,10 @@ def test_conditioning_guard(eng, decades):                # sigma_1/sigma_r up t
     run_conditioning_guard(eng, decades, synth_host)
     if decades in (5, 7):                                  # f32-stored data: refinement through spr_project_x32_f64out
         run_conditioning_guard(eng, decades, synth_host, f32=True)
+    if decades == 7:                                        # wider shapes: two column slices (m = 300), W in two column groups (m = 160)
+        run_conditioning_guard(eng, decades, synth_host, shape=(600, 2, 300, 12))
+        run_conditioning_guard(eng, decades, synth_host, shape=(900, 3, 160, 24))
+        run_conditioning_guard(eng, 5, synth_host, f32=True, shape=(500, 2, 300, 9))
 
 
 @pytest.mark.parametrize('n_points,F,r,n_sensors,d_min,masked', [(150, 2, 5, 9, 0.0, False), (2000, 3, 16, 24, 0.03, True),

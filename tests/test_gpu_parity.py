@@ -234,6 +234,36 @@ def test_project_w_stationary_vs_oracle(eng, n_points, F, m, r, row0_cells, f32)
         assert np.abs(U0 - ref0).max() <= 1e-12 * np.abs(ref0).max()
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_project_w_stationary_random_shapes(eng, seed):
+    """Seeded random shapes through the W-stationary projection kernel: rows from 4096 to ~40k (ragged 16-row and
+    128-row tails), 1-6 features with the shard starting and ending inside features, r from 1 to 64, m in
+    {128, 192, 256}, f64 and f32 storage, centred and not -- against NumPy."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([128, 192, 256]))
+    r = int(rng.integers(1, 65))
+    F = int(rng.integers(1, 7))
+    n_points = int(rng.integers(4096 // F + 400, 40000 // F))
+    n = n_points * F
+    row0 = int(rng.integers(0, n - 4096 - 1)) if seed % 3 else 0
+    n_loc = int(rng.integers(4096, n - row0 + 1))
+    f32 = bool(seed % 4 == 3)
+    X = rng.standard_normal((n_loc, m)) * 3.0 + rng.standard_normal((n_loc, 1)) * 10.0
+    if f32:
+        X = X.astype(np.float32).astype(np.float64)
+    mu = X.mean(axis=1)
+    scl = 0.5 + rng.random(F)
+    feat = (row0 + np.arange(n_loc)) // n_points
+    W = rng.standard_normal((m, r))
+    Xd = eng.to_device(X.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(X)
+    U = eng.to_host(eng.project(Xd, row0, n_points, F, eng.to_device(1.0 / scl), eng.to_device(W), rowmean=eng.to_device(mu)))
+    ref = ((X - mu[:, None]) @ W) / scl[feat][:, None]
+    tol = 2e-7 if f32 else 1e-12
+    assert U.shape == ref.shape
+    assert np.abs(U - ref).max() <= tol * np.abs(ref).max(), (m, r, F, n_points, row0, n_loc, f32)
+
+
 @pytest.mark.parametrize('n,r,n_p', [(20, 5, 1), (999, 5, 3), (4096, 32, 1), (5000, 64, 5), (3001, 128, 2), (777, 1, 1), (1234, 14, 2)])
 def test_reconstruct_vs_oracle(eng, n, r, n_p):
     rng = np.random.default_rng(n + r)

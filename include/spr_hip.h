@@ -80,20 +80,27 @@ int spr_stats_gram_finalize_f64(int64_t n_rows, int32_t m, int64_t row0, int64_t
  * (ldg = m, origin = 0 for a stand-alone Gram).
  *
  * 256 < m <= 512 (column-split path, csrc/gram_wide.hip): columns A = [0,256), B = [256,m).
- *   spr_rowstats_f64      row means of the FULL rows + per-feature statistics (one read of X);
+ *   spr_gram_cross_f64    A^T B and its transpose into ldg = m matrices.  center = 1: the means of the FULL rows are
+ *                         formed in this pass (the panels hold whole rows) and WRITTEN to d_rowmean; run it first,
+ *                         then spr_rowmean_stats_f64 for the per-feature statistics (count, mean, M2 of the row
+ *                         means: reads the n means, not X).  center = 2: means READ from d_rowmean; 0: none;
+ *   spr_rowstats_f64      (alternative to center = 1 above) row means of the full rows + per-feature statistics in a
+ *                         separate read of X;
  *   spr_stats_gram_f64    on the slices (d_X, 256) and (d_X + 256, m - 256), ldx = full stride,
  *                         center = 2: the row means are READ from d_rowmean (no statistics; give
  *                         the finalize call a scratch d_fstats), finalize with ldg = m and
- *                         origin = 0 / 256;
- *   spr_gram_cross_f64    A^T B and its transpose into the same ldg = m matrices (center = 2 or 0). */
+ *                         origin = 0 / 256. */
 size_t spr_rowstats_workspace(int32_t n_features);
 int spr_rowstats_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                      int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
                      void *d_workspace, size_t workspace_bytes, void *stream);
 size_t spr_gram_cross_workspace(int32_t m, int32_t n_features);
 int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                       int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                       int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                        double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_rowmean_stats_f64(const double *d_rowmean, int64_t n_rows, int64_t row0, int64_t n_points,
+                          int32_t n_features, double *d_fstats, void *d_workspace, size_t workspace_bytes,
+                          void *stream);   /* workspace: spr_rowstats_workspace(n_features) */
 
 /* ---- K3b : device-side spectrum for m <= spr_spectrum_max_m() (= 64) ------------------------
  * Replaces, for small snapshot counts, the host eigen-solve behind np.linalg.svd (:272), the block
@@ -316,7 +323,7 @@ int spr_rowstats_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, i
                      int64_t n_points, int32_t n_features, double *d_rowmean, double *d_fstats,
                      void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_gram_cross_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                       int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                       int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                        double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_project_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                     int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,

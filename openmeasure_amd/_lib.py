@@ -40,6 +40,7 @@ PROTOTYPES = {
     'spr_rowstats_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     'spr_gram_cross_workspace': (_sz, [_i32, _i32]),
     'spr_gram_cross_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
+    'spr_rowmean_stats_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     'spr_spectrum_max_m': (_i32, []),
     'spr_spectrum_f64': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'spr_gram_combine_f64': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),

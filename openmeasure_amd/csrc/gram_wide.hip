@@ -74,6 +74,31 @@ __global__ void rowstats_finalize_kernel(const double *__restrict__ stat_part, S
   }
 }
 
+// ---- per-feature statistics (count, mean, M2) of row means that already exist -----------------
+// Same partial layout and fixed-order finalize as rowstats_kernel, but reads the n row means instead of X.
+__global__ __launch_bounds__(256) void rowmean_stats_kernel(const double *__restrict__ rowmean, SegPlan plan,
+                                                            double *__restrict__ stat_part) {
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  RowStats st;
+  st.init();
+  // wave w of workgroup wl takes the rows of its 4-row groups; lane 0..63 strided inside 256-row spans
+  for (int64_t row = lo + ((int64_t)wl * 4 + wave) * 64 + lane; row < hi; row += (int64_t)wpf * 256)
+    st.push(rowmean[row], true);
+  // lane partials -> one (count, mean, M2) per wave, fixed lane order
+  double n = st.cnt, mu = st.mean(), m2 = st.m2();
+  for (int o = 32; o > 0; o >>= 1) {
+    const double on = __shfl_down(n, o, 64), om = __shfl_down(mu, o, 64), os = __shfl_down(m2, o, 64);
+    chan_merge_w(n, mu, m2, on, om, os);
+  }
+  if (lane == 0) {
+    double *q = stat_part + ((int64_t)blockIdx.x * 4 + wave) * 3;
+    q[0] = n; q[1] = mu; q[2] = m2;
+  }
+}
+
 // ---- cross block A^T B ------------------------------------------------------------------------
 // Panels of 16 full rows (both column halves) in LDS, centred with the external row means.  Two
 // workgroup flavours (og = 0, 1) share the 16 tile rows of A: wave w of flavour og owns tile row
@@ -83,10 +108,13 @@ constexpr int CW = 8;        // waves
 constexpr int CR = 16;       // panel rows
 constexpr int CMA = 256;     // width of A
 
-template <int NTJ, int VEC, typename TX>
+// OWN = true (centre mode 1): the row means are formed in this pass from the full rows the panel holds anyway (the
+// staging computes the row sums in every mode) and written to rowmean[] -- both flavours write the same bits --, so
+// the separate row-statistics pass over X is not needed; OWN = false: external means (mode 2) or none (mode 0).
+template <int NTJ, int VEC, typename TX, bool OWN>
 __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restrict__ X, int64_t ldx, int m,
                                                             int center, SegPlan plan,
-                                                            const double *__restrict__ rowmean,
+                                                            double *__restrict__ rowmean,
                                                             double *__restrict__ slab) {
   constexpr int MTF = 16 + NTJ;                 // padded full width in tiles
   constexpr int MP = 16 * MTF + ((MTF % 2 == 0) ? 16 : 0);
@@ -107,13 +135,13 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
   for (int j = 0; j < NTJ; ++j) acc[j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
   RT tile;
-  RowStats st;   // unused (external means), required by the staging interface
+  RowStats st;   // required by the staging interface; the feature statistics come from spr_rowmean_stats_f64
   st.init();
-  const double *mean_in = rowmean;
+  const double *mean_in = OWN ? nullptr : rowmean;
   const int64_t nchunks = (hi - lo + CR - 1) / CR;
   int64_t c = wl;
   tile.template load<VEC>(X, ldx, m, lo + c * CR, hi, wave, lane, mean_in);
-  tile.template center_store<false>(lds[0], m, center, lo + c * CR, hi, wave, lane, nullptr, &st);
+  tile.template center_store<OWN>(lds[0], m, center, lo + c * CR, hi, wave, lane, OWN ? rowmean : nullptr, &st);
   int64_t cn = c + wpf;
   int64_t nrow0 = (cn < nchunks) ? lo + cn * CR : hi;
   tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in);
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
 #pragma unroll
       for (int j = 0; j < NTJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[j], 0, 0, 0);
       if (k == 0) {
-        tile.template center_store_pass<false>(0, nxt, m, center, nrow0, hi, wave, lane, nullptr, &st);
+        tile.template center_store_pass<OWN>(0, nxt, m, center, nrow0, hi, wave, lane, OWN ? rowmean : nullptr, &st);
         tile.template load_pass<VEC>(0, X, ldx, m, n2row0, hi, wave, lane, mean_in);
       }
     }
@@ -191,7 +219,7 @@ int plan_wgs(SegPlan &plan, int64_t n_rows, int64_t row0, int64_t n_points, int3
 
 template <int NTJ, typename TX>
 int launch_cross(const TX *X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
-                 int32_t n_features, int center, const double *rowmean, double *gram, void *ws, size_t ws_bytes,
+                 int32_t n_features, int center, double *rowmean, double *gram, void *ws, size_t ws_bytes,
                  hipStream_t st) {
   SegPlan plan;
   const int pairs = plan_wgs(plan, n_rows, row0, n_points, n_features, CR, 1);   // one workgroup per CU: 2 flavours share them
@@ -203,12 +231,10 @@ int launch_cross(const TX *X, int64_t n_rows, int m, int64_t ldx, int64_t row0, 
   SPR_REQUIRE(ws_bytes >= need, SPR_E_WORKSPACE, "spr_gram_cross_f64: workspace %zu < %zu", ws_bytes, need);
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
   double *slab = static_cast<double *>(ws);
-  if (vec_ok)
-    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 1, TX>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
-                       rowmean, slab);
-  else
-    hipLaunchKernelGGL((gram_cross_kernel<NTJ, 0, TX>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan,
-                       rowmean, slab);
+#define GXK(V, O) hipLaunchKernelGGL((gram_cross_kernel<NTJ, V, TX, O>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan, rowmean, slab)
+  if (center == 1) { if (vec_ok) GXK(1, true); else GXK(0, true); }
+  else { if (vec_ok) GXK(1, false); else GXK(0, false); }
+#undef GXK
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_cross_finalize_kernel<NTJ>, dim3(16 * NTJ, n_features), dim3(256), 0, st, slab, m, plan, gram);
   SPR_LAUNCH_CHECK();
@@ -258,6 +284,25 @@ extern "C" int spr_rowstats_x32(const float *d_X, int64_t n_rows, int32_t m, int
                         d_workspace, workspace_bytes, stream);
 }
 
+extern "C" int spr_rowmean_stats_f64(const double *d_rowmean, int64_t n_rows, int64_t row0, int64_t n_points,
+                                     int32_t n_features, double *d_fstats, void *d_workspace, size_t workspace_bytes,
+                                     void *stream) {
+  SPR_REQUIRE(d_rowmean && d_fstats && d_workspace, SPR_E_INVALID, "spr_rowmean_stats_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && row0 >= 0 && n_points > 0 && n_features > 0 && row0 + n_rows <= n_points * (int64_t)n_features,
+              SPR_E_INVALID, "spr_rowmean_stats_f64: bad shape");
+  SPR_REQUIRE(workspace_bytes >= spr_rowstats_workspace(n_features), SPR_E_WORKSPACE,
+              "spr_rowmean_stats_f64: workspace too small");
+  SegPlan plan;
+  const int grid = plan_wgs(plan, n_rows, row0, n_points, n_features, 256, 8);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(rowmean_stats_kernel, dim3(grid), dim3(256), 0, st, d_rowmean, plan, static_cast<double *>(d_workspace));
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rowstats_finalize_kernel, dim3(n_features), dim3(64), 0, st,
+                     static_cast<const double *>(d_workspace), plan, d_fstats);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
 extern "C" size_t spr_gram_cross_workspace(int32_t m, int32_t n_features) {
   const int cus = spr_cached_cus();
   const int ntj = (m - CMA + 15) / 16;
@@ -267,13 +312,13 @@ extern "C" size_t spr_gram_cross_workspace(int32_t m, int32_t n_features) {
 
 template <typename TX>
 static int gram_cross_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                            int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                            int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                             double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
   SPR_REQUIRE(d_X && d_rowmean && d_gram && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > CMA && m <= 512 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
               SPR_E_INVALID, "%s: bad shape (m must be in (256, 512])", who);
-  SPR_REQUIRE(center == 0 || center == 2, SPR_E_INVALID, "%s: centre mode must be 0 or 2 (external means)", who);
+  SPR_REQUIRE(center >= 0 && center <= 2, SPR_E_INVALID, "%s: centre mode must be 0, 1 (own means, written) or 2 (external means)", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntj = (m - CMA + 15) / 16;
 #define GX(N) return launch_cross<N, TX>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_gram, \
@@ -286,14 +331,14 @@ static int gram_cross_entry(const char *who, const TX *d_X, int64_t n_rows, int3
 }
 
 extern "C" int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                                  int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                                  int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                                   double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
   return gram_cross_entry("spr_gram_cross_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean,
                           d_gram, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int spr_gram_cross_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                                  int64_t n_points, int32_t n_features, int32_t center, const double *d_rowmean,
+                                  int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                                   double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
   return gram_cross_entry("spr_gram_cross_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean,
                           d_gram, d_workspace, workspace_bytes, stream);

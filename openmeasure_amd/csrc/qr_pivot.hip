@@ -284,7 +284,7 @@ template <int NG, typename TU, bool INIT>
 __global__ __launch_bounds__(QR_THREADS) void qr_refresh_direct_kernel(
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
     const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
-  constexpr int NW = QR_THREADS / 64, R = 64;
+  constexpr int R = 64;
   constexpr int SPW = INIT ? 16 : 4;
   __shared__ double smem[2 * (QR_THREADS / 64) * SPW * QR_TOPT];
   double *const sval = smem;

@@ -180,16 +180,23 @@ class HipEngine:
         gram = self.empty((F, m, m))
         tic, toc = self._timed('stats_gram')
         tic()
+        esz = X.element_size()
+        wsx = self._workspace('cross', self.lib.spr_gram_cross_workspace(m, F))
         if center:
+            # the cross block first, in centre mode 1: its panels hold whole rows, so it forms the row means itself and
+            # writes them (no separate row-statistics read of X); the feature statistics then come from the n means
             rowmean = self.empty((n,))
+            _lib.check(self._x('spr_gram_cross', X)(_ptr(X), n, m, ld, row0, n_points, F, 1, _ptr(rowmean), _ptr(gram),
+                                                   _ptr(wsx), wsx.numel(), st), 'spr_gram_cross_f64')
             ws = self._workspace('rowstats', self.lib.spr_rowstats_workspace(F))
-            _lib.check(self._x('spr_rowstats', X)(_ptr(X), n, m, ld, row0, n_points, F, _ptr(rowmean), _ptr(fstats),
-                                                 _ptr(ws), ws.numel(), st), 'spr_rowstats_f64')
+            _lib.check(self.lib.spr_rowmean_stats_f64(_ptr(rowmean), n, row0, n_points, F, _ptr(fstats), _ptr(ws),
+                                                      ws.numel(), st), 'spr_rowmean_stats_f64')
         else:
             rowmean = self.zeros((n,))
+            _lib.check(self._x('spr_gram_cross', X)(_ptr(X), n, m, ld, row0, n_points, F, 0, _ptr(rowmean), _ptr(gram),
+                                                   _ptr(wsx), wsx.numel(), st), 'spr_gram_cross_f64')
         mode = 2 if center else 0
         scratch = self.empty((F, 3))
-        esz = X.element_size()
         for origin, width in ((0, mA), (mA, mB)):
             ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(width, F))
             xp = X.data_ptr() + origin * esz
@@ -198,9 +205,6 @@ class HipEngine:
             _lib.check(self.lib.spr_stats_gram_finalize_f64(n, width, row0, n_points, F, _ptr(ws), ws.numel(),
                                                             _ptr(scratch), _ptr(gram), m, origin, st),
                        'spr_stats_gram_finalize_f64')
-        ws = self._workspace('cross', self.lib.spr_gram_cross_workspace(m, F))
-        _lib.check(self._x('spr_gram_cross', X)(_ptr(X), n, m, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(gram),
-                                               _ptr(ws), ws.numel(), st), 'spr_gram_cross_f64')
         toc()
         return rowmean, fstats, gram
 

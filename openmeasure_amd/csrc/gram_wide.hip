@@ -122,10 +122,16 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
   using RT = RowTile<MTF, CR, MP, CW, 32, TX>;
   __shared__ double lds[2][CR * MP];
 
-  const int og = blockIdx.x & 1;
+  // The two flavours of a pair read the same rows: give them block indices that differ by 8, i.e. (workgroups being
+  // dealt round-robin over the 8 XCDs) the same XCD and L2, so the second read of a panel is an L2 hit.  Placement is
+  // a speed matter only; the last npairs % 8 pairs keep neighbouring block indices.
+  const int npairs_full = (int)((gridDim.x >> 1) & ~7u);
+  int og, pair;
+  if ((int)blockIdx.x < 2 * npairs_full) { og = (blockIdx.x >> 3) & 1; pair = (int)((blockIdx.x >> 4) << 3) | (int)(blockIdx.x & 7); }
+  else { const int t = (int)blockIdx.x - 2 * npairs_full; og = t & 1; pair = npairs_full + (t >> 1); }
   int f, wl, wpf, base;
   int64_t lo, hi;
-  if (!seg_locate(plan, blockIdx.x >> 1, f, wl, wpf, base, lo, hi)) return;
+  if (!seg_locate(plan, pair, f, wl, wpf, base, lo, hi)) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ti = og * 8 + wave;
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
     nrow0 = n2row0;
   }
   // slab[(block >> 1)][ti][tj][reg][lane]   (the two flavours of a block pair write disjoint tile rows)
-  double *sp = slab + (((int64_t)(blockIdx.x >> 1) * 16 + ti) * NTJ) * 256 + lane;
+  double *sp = slab + (((int64_t)pair * 16 + ti) * NTJ) * 256 + lane;
 #pragma unroll
   for (int j = 0; j < NTJ; ++j) {
     double *tp = sp + (int64_t)j * 256;

@@ -256,7 +256,8 @@ def run_rank(args):
         shard = RowShard(row0, n_glob, force_collectives=True, partial=True)
     else:
         shard = RowShard(row0, n_glob, force_collectives=force_dist) if (world > 1 or force_dist) else None
-    spr = SPR(DeviceMatrix(Xd), F, None, shard=shard, engine=eng)
+    # f32-stored workloads (config 5) also store the basis in f32 -- the explicit storage option; the default would be f64
+    spr = SPR(DeviceMatrix(Xd, basis='f32' if f32 else None), F, None, shard=shard, engine=eng)
 
     def barrier():
         if world > 1 or force_dist:
@@ -409,16 +410,20 @@ def run_rank(args):
                    cpu_model=_cpu_model(), host_cpus=os.cpu_count(), blas=blas,
                    sample=f'{cc} cells x {F} features x {m} snapshots ({Xs.nbytes / 1e6:.0f} MB), s={s}: '
                           f'oracle fit+reconstruct {t_cpu:.2f} s (same generator, first {cc} cells per feature)')
-        # parity on the same sample: GPU path vs oracle
-        sp2 = SPR(Xs, F, None, engine=eng)
+        # parity on the same sample: GPU path vs oracle.  The oracle ran in f64 on the stored values widened, which is
+        # what the reference computes for a float32 X as well (X_cnt / X_scl are float64: X0, U float64, :106-107, :169)
+        Xs_in = DeviceMatrix(eng.to_device(Xs, dtype=torch.float32), basis='f32') if f32 else Xs
+        sp2 = SPR(Xs_in, F, None, engine=eng)
         sp2.fit(select_modes='number', n_modes=s)
-        xr_gpu = sp2.reconstruct(st_cpu['Ar'][0])   # same coefficients need the same sign convention:
-        sg = np.sign(np.sum(sp2.Ur * st_cpu['Ur'], axis=0))
+        sg = np.sign(np.sum(sp2.Ur.astype(np.float64) * st_cpu['Ur'], axis=0))   # same coefficients need the same signs
         xr_gpu = sp2.reconstruct(st_cpu['Ar'][0] * sg)
         sp2.optimal_placement()
-        # f32 storage: the sensors are those of the STORED basis (oracle's dgeqp3 on it, widened to f64)
-        piv_cpu, _ = orc.qr_pivots(sp2.Ur.astype(np.float64) if f32 else st_cpu['Ur'])
+        # sensors: against the REFERENCE's choice -- dgeqp3's pivots of the oracle's f64 basis -- also when the device
+        # basis is stored in f32 (config 5); min_pivot_gap says how far every pick was from a tie (f32 rounding: 6e-8)
+        piv_cpu, _ = orc.qr_pivots(st_cpu['Ur'])
         parity = dict(sensors_equal=bool(np.array_equal(sp2.sensors_, piv_cpu)),
+                      sensors_vs='dgeqp3 pivots of the oracle f64 basis (the reference\'s sensors)',
+                      basis_dtype=str(sp2.Ur.dtype), min_pivot_gap=float(sp2.pivot_gap_.min()),
                       field_rel_fro=float(np.linalg.norm(xr_gpu - xr_cpu) / np.linalg.norm(xr_cpu)),
                       sigma_rel=float(np.max(np.abs(sp2.Sigma_r - st_cpu['Sigma_r']) / st_cpu['Sigma_r'])),
                       sigma1_over_sigmas=float(sp2.Sigma_r[0] / sp2.Sigma_r[-1]))

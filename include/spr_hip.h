@@ -141,6 +141,21 @@ int spr_project_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx,
                     const double *d_inv_scale, const double *d_rowmean, const double *d_W, int32_t r,
                     double *d_Ur, int64_t ldu, int32_t accumulate, void *stream);
 
+/* ---- K4s : the same projection for ANY snapshot count m (csrc/project_stream.hip) -----------------------------
+ * Replaces the U factor of np.linalg.svd (:272) / U[:, :r] (:336) when W = V_r Sigma_r^-1 no longer fits a workgroup's
+ * registers or LDS (m > 256; BASELINE config 5 has m = 512, r = 128).  ONE launch over the full contraction length:
+ * W streams through LDS in k-chunks from a permuted image the call builds in the workspace, the accumulators live
+ * across all chunks and d_Ur is written once (rounded once when it is float).  m is a run-time loop count -- no upper
+ * bound; r <= SPR_MAX_R per call (the caller projects wider bases in column groups: d_W = the group's columns packed
+ * m x r, d_Ur + column offset, same ldu).  center: 0 rows as they are, 1 row means removed in the epilogue
+ * (x.W - mean (1^T W)), 2 row means subtracted from the operand before the multiplication (data whose mean dwarfs its
+ * fluctuation).  Workspace: spr_project_stream_workspace(m, r, x_is_f32) bytes, 16-byte aligned. */
+size_t spr_project_stream_workspace(int32_t m, int32_t r, int32_t x_is_f32);
+int spr_project_stream_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                           int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                           const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- K2 / K11 as stand-alone calls (ROM.scale_data's return value, ROM.unscale_data) --
  * spr_scale_rows:  X0 = (X - rowmean) * inv_scale[feature]   (:169), n_rows x m.
  * spr_unscale:     x  = scale[feature] * x0 + rowmean        (:235), n_rows; with d_rowscale != NULL
@@ -340,6 +355,16 @@ int spr_project_x32_acc(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx
                         int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
                         const double *d_rowmean, const double *d_W, int32_t r, const double *d_acc_in,
                         int64_t lda, float *d_Ur, int64_t ldu, void *stream);
+/* streamed-W projection (any m) of an f32 shard: float basis, or double basis (the reference's dtype for a float32 X:
+ * X_cnt / X_scl are float64, :106-107, so X0 = (X - X_cnt)/X_scl and U are float64 whatever the dtype of X) */
+int spr_project_stream_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                           int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                           const double *d_rowmean, const double *d_W, int32_t r, float *d_Ur, int64_t ldu,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_project_stream_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                  int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                                  const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                                  void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_scale_rows_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                        int64_t n_points, int32_t n_features, const double *d_rowmean,
                        const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream);

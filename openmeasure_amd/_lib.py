@@ -45,6 +45,8 @@ PROTOTYPES = {
     'spr_spectrum_f64': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'spr_gram_combine_f64': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     'spr_project_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _i32, _p]),
+    'spr_project_stream_workspace': (_sz, [_i32, _i32, _i32]),
+    'spr_project_stream_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p, _sz, _p]),
     'spr_scale_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
     'spr_unscale_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     'spr_feature_minmax_workspace': (_sz, [_i32]),
@@ -82,6 +84,8 @@ PROTOTYPES['spr_project_x32_acc'] = (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64,
 for _f64, _x32 in (('spr_stats_gram_f64', 'spr_stats_gram_x32'), ('spr_rowstats_f64', 'spr_rowstats_x32'),
                    ('spr_gram_cross_f64', 'spr_gram_cross_x32'), ('spr_project_f64', 'spr_project_x32'),
                    ('spr_project_f64', 'spr_project_x32_f64out'),
+                   ('spr_project_stream_f64', 'spr_project_stream_x32'),
+                   ('spr_project_stream_f64', 'spr_project_stream_x32_f64out'),
                    ('spr_scale_rows_f64', 'spr_scale_rows_x32'), ('spr_feature_minmax_f64', 'spr_feature_minmax_x32'),
                    ('spr_colsums_f64', 'spr_colsums_x32'), ('spr_feature_digit_hist_f64', 'spr_feature_digit_hist_x32'),
                    ('spr_synth_f64', 'spr_synth_f32'), ('spr_reconstruct_f64', 'spr_reconstruct_u32'),

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(CB_THREADS) void gram_combine_kernel(
         n = tot;
       }
     }
-    const double var = (trs[f] + m * m2) / (n * m);   // population variance of the raw block (:115)
+    // population variance of the raw block (:115).  A feature WITHOUT rows (only possible in a partial row group,
+    // RowShard(partial=True): one rank's block of a larger job run alone) takes no part: scale 1, Gram block zero
+    const bool present = n > 0.0;
+    const double var = present ? (trs[f] + m * m2) / (n * m) : 0.0;
     const double sd = sqrt(var);
     double scl;
     switch (scale_code) {
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(CB_THREADS) void gram_combine_kernel(
       case SC_L2: scl = sqrt(n * m * (var + mu * mu)); break;
       default: scl = sd; break;
     }
+    if (!present) scl = 1.0;
     scl2[f] = scl * scl;
     if (blockIdx.x == 0) {
       feat_out[5 * f] = n; feat_out[5 * f + 1] = mu; feat_out[5 * f + 2] = var;

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(SP_THREADS) void spectrum_kernel(
       double tr = 0.0;
       const double *G = gram + (int64_t)f * m * m;
       for (int i = 0; i < m; ++i) tr += G[(int64_t)i * m + i];
-      const double var = (tr + m * m2) / (n * m);   // population variance of the raw block (:115)
+      // population variance of the raw block (:115); a feature without rows (partial row group) takes no part
+      const bool present = n > 0.0;
+      const double var = present ? (tr + m * m2) / (n * m) : 0.0;
       const double sd = sqrt(var);
       double scl;
       switch (scale_code) {
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(SP_THREADS) void spectrum_kernel(
         case SC_L2: scl = sqrt(n * m * (var + mu * mu)); break;
         default: scl = sd; break;
       }
+      if (!present) scl = 1.0;
       feat_out[5 * f] = n; feat_out[5 * f + 1] = mu; feat_out[5 * f + 2] = var;
       feat_out[5 * f + 3] = scl; feat_out[5 * f + 4] = 1.0 / scl;
       scale[f] = scl;

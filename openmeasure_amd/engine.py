@@ -244,87 +244,84 @@ class HipEngine:
         return packed, scale, inv_scale
 
     # ---- K4 --------------------------------------------------------------------------------
-    _PROJECT_BLOCK_ROWS = 4_000_000
+    def _project_group(self, X, i0, rows, row0, n_points, n_features, inv_scale, Wg, rowmean, center, out_ptr, ldu,
+                       out_f64, precenter):
+        """One column group (q <= SPR_MAX_R columns of W, packed m x q) of the projection of rows [i0, i0+rows) of X,
+        written at out_ptr with row stride ldu.  m <= 256: W-stationary / register-resident kernels (spr_project_*);
+        wider X, or row means that must be removed before the multiplication: the streamed-W kernel, one launch over
+        the full contraction length (spr_project_stream_*)."""
+        n, m, ld = self._check_matrix(X)
+        q = Wg.shape[1]
+        f32 = X.dtype == self.torch.float32
+        xp = X.data_ptr() + i0 * ld * X.element_size()
+        mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
+        st = self._stream()
+        if m > _lib.SPR_MAX_M or (precenter and center):
+            name = 'spr_project_stream_f64' if not f32 else ('spr_project_stream_x32_f64out' if out_f64 else
+                                                             'spr_project_stream_x32')
+            nbytes = self.lib.spr_project_stream_workspace(m, q, int(f32))
+            ws = self._workspace('pstream', nbytes)
+            _lib.check(getattr(self.lib, name)(xp, rows, m, ld, row0 + i0, n_points, n_features,
+                                               (2 if precenter else 1) if center else 0, _ptr(inv_scale), mean_p,
+                                               _ptr(Wg), q, out_ptr, ldu, _ptr(ws), ws.numel(), st), name)
+        else:
+            name = 'spr_project_f64' if not f32 else ('spr_project_x32_f64out' if out_f64 else 'spr_project_x32')
+            _lib.check(getattr(self.lib, name)(xp, rows, m, ld, row0 + i0, n_points, n_features, int(bool(center)),
+                                               _ptr(inv_scale), mean_p, _ptr(Wg), q, out_ptr, ldu, 0, st), name)
 
-    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
+    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None,
+                basis_dtype=None, precenter=False):
         """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even.
         ``out``: a previous result of the same shape to overwrite (keeps one basis buffer alive).
-        ``rowmean``: the row means from stats_gram (required when center=True)."""
+        ``rowmean``: the row means from stats_gram (required when center=True).
+        ``basis_dtype``: storage type of the result; default float64 (the reference's U is float64 whatever the dtype
+        of X, sparse_sensing.py:106-107, :169, :272); torch.float32 only for a float32 X (storage option).
+        ``precenter``: subtract the row means before the multiplication instead of in the epilogue.
+        Any m; r > 128 goes in column groups of 128 (each one more read of X)."""
         if center and rowmean is None:
             raise ValueError('project(center=True) needs the row means of the Gram pass')
         n, m, ld = self._check_matrix(X)
         r = W.shape[1]
         ldu = r + (r & 1)
+        t = self.torch
+        dt = basis_dtype or t.float64
+        if dt == t.float32 and X.dtype != t.float32:
+            raise ValueError('a float32 basis is a storage option of a float32 snapshot matrix')
         if (out is not None and tuple(out.shape) == (n, r) and out.stride(0) == ldu and out.stride(1) == 1
-                and out.dtype == X.dtype):
+                and out.dtype == dt):
             buf = out
         else:
             del out
-            buf = self.empty((n, ldu), dtype=X.dtype)        # the basis is stored like the shard (f64 or f32)
+            buf = self.empty((n, ldu), dtype=dt)
         tic, toc = self._timed('project')
         tic()
         Wc = W.contiguous()
-        mA = _lib.SPR_MAX_M
-        slices = ((0, m),) if m <= mA else ((0, mA), (mA, m - mA))     # a wide X goes as two column slices
-        if m > _lib.SPR_MAX_M_WIDE:
-            raise NotImplementedError(f'project: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
-        if len(slices) > 1 and X.dtype == self.torch.float32:
-            # f32 basis of a wide X: the slices' partial sums cancel by up to sigma_1/sigma_r, so they meet in an
-            # f64 block of rows and are rounded to f32 once (a dtype-converting copy)
-            block = self._PROJECT_BLOCK_ROWS
-            scratch = self.empty((min(block, n), ldu))
-            esz = X.element_size()
-            for i0 in range(0, n, block):
-                rows = min(block, n - i0)
-                mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
-                last = len(slices) - 1
-                for k, (c0, width) in enumerate(slices):
-                    xp, wp = X.data_ptr() + (i0 * ld + c0) * esz, Wc.data_ptr() + c0 * r * Wc.element_size()
-                    if k < last:                              # partial sums stay f64
-                        _lib.check(self.lib.spr_project_x32_f64out(xp, rows, width, ld, row0 + i0, n_points, n_features,
-                                                                   int(bool(center)), _ptr(inv_scale), mean_p, wp, r,
-                                                                   _ptr(scratch), ldu, int(k > 0), self._stream()),
-                                   'spr_project_x32_f64out')
-                    else:                                     # last slice: f64 total, rounded once into the f32 basis
-                        _lib.check(self.lib.spr_project_x32_acc(xp, rows, width, ld, row0 + i0, n_points, n_features,
-                                                                int(bool(center)), _ptr(inv_scale), mean_p, wp, r,
-                                                                _ptr(scratch), ldu, buf.data_ptr() + i0 * ldu * buf.element_size(),
-                                                                ldu, self._stream()), 'spr_project_x32_acc')
-        else:
-            for k, (c0, width) in enumerate(slices):
-                _lib.check(self._x('spr_project', X)(X.data_ptr() + c0 * X.element_size(), n, width, ld, row0, n_points,
-                                                     n_features, int(bool(center)), _ptr(inv_scale),
-                                                     _ptr(rowmean) if center else None,
-                                                     Wc.data_ptr() + c0 * r * Wc.element_size(), r, _ptr(buf), ldu,
-                                                     int(k > 0), self._stream()), 'spr_project')
+        G = _lib.SPR_MAX_R
+        for g0 in range(0, r, G):
+            qg = min(G, r - g0)
+            Wg = Wc if qg == r else Wc[:, g0:g0 + qg].contiguous()
+            self._project_group(X, 0, n, row0, n_points, n_features, inv_scale, Wg, rowmean, center,
+                                buf.data_ptr() + g0 * buf.element_size(), ldu, dt == t.float64, precenter)
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf
 
-    def project_f64(self, X, i0, rows, row0, n_points, n_features, inv_scale, W, rowmean, out, center=True):
+    def project_f64(self, X, i0, rows, row0, n_points, n_features, inv_scale, W, rowmean, out, center=True,
+                    precenter=False):
         """out[:rows, :q] = ((X[i0:i0+rows] - rowmean) W) / X_scl in float64 whatever the storage of X, for any
-        q = W.shape[1] <= out.shape[1] (column groups of <= 128 go to column offsets of `out`; a wide X goes as two
-        accumulating column slices).  Used by the conditioning refinement of fit(), where the product must not be
-        rounded to the storage type of the basis."""
+        q = W.shape[1] <= out.shape[1] (column groups of <= 128 go to column offsets of `out`).  Used by the
+        conditioning refinement of fit(), whose product must not be rounded to a narrower storage type."""
         n, m, ld = self._check_matrix(X)
         q = W.shape[1]
         if not (out.dtype == self.torch.float64 and out.dim() == 2 and out.stride(1) == 1 and out.shape[1] >= q
                 and out.shape[0] >= rows and out.stride(0) % 2 == 0):
             raise ValueError('project_f64: out must be a float64 matrix with an even row stride')
-        if m > _lib.SPR_MAX_M_WIDE:
-            raise NotImplementedError(f'project: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
-        fn = self.lib.spr_project_f64 if X.dtype == self.torch.float64 else self.lib.spr_project_x32_f64out
         Wc = W.contiguous()
-        mA = _lib.SPR_MAX_M
-        slices = ((0, m),) if m <= mA else ((0, mA), (mA, m - mA))
-        esz = X.element_size()
-        mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
-        for g0 in range(0, q, _lib.SPR_MAX_R):
-            qg = min(_lib.SPR_MAX_R, q - g0)
-            Wg = Wc[:, g0:g0 + qg].contiguous()
-            for k, (c0, width) in enumerate(slices):
-                _lib.check(fn(X.data_ptr() + (i0 * ld + c0) * esz, rows, width, ld, row0 + i0, n_points, n_features, int(bool(center)),
-                              _ptr(inv_scale), mean_p, Wg.data_ptr() + c0 * qg * 8, qg,
-                              out.data_ptr() + g0 * 8, out.stride(0), int(k > 0), self._stream()), 'spr_project_f64')
+        G = _lib.SPR_MAX_R
+        for g0 in range(0, q, G):
+            qg = min(G, q - g0)
+            Wg = Wc if qg == q else Wc[:, g0:g0 + qg].contiguous()
+            self._project_group(X, i0, rows, row0, n_points, n_features, inv_scale, Wg, rowmean, center,
+                                out.data_ptr() + g0 * 8, out.stride(0), True, precenter)
         return out
 
     def feature_minmax(self, X, row0, n_points, n_features):

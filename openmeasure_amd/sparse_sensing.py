@@ -30,10 +30,11 @@ What differs from the reference, by design:
     mode that row-centring always creates when r = m) is numerically meaningless in both;
   * fitted arrays live in HBM; ``X_cnt``, ``X_scl``, ``Ur``, ... are copied to NumPy on
     first access;
-  * a float32 X is stored as float32 (and so is Ur); all arithmetic is float64;
+  * a float32 X is stored as float32 in HBM; all arithmetic is float64 and the basis Ur is float64, as in the reference
+    (X_cnt / X_scl are float64, :106-107, so X0 = (X - X_cnt)/X_scl and its SVD are float64 whatever the dtype of X);
+    a float32 BASIS is an explicit storage option, DeviceMatrix(tensor, basis='f32') (BASELINE config 5);
   * 'gem' placement is the noise-free limit of the reference's rule (it adds unseeded noise, :667) for the first
     r-1 sensors and, beyond, a deterministic ridge stand-in for that noise (see _gem_ridge_phase);
-  * at most 128 retained modes / sensors per QR placement and 512 snapshots are built (SPR_MAX_R, SPR_MAX_M_WIDE);
   * options that have no device implementation ('COLS', the kurtosis scalings 'vast_2..4', which are
     ill-defined in the reference itself) raise ``NotImplementedError`` -- they never fall back to a CPU path.
 
@@ -94,11 +95,20 @@ class RowShard:
 
 class DeviceMatrix:
     """A snapshot block that already lives in HBM (2-D float64 or float32 CUDA tensor, rows contiguous).
-    float32 = storage precision only: every kernel widens on load and computes in f64; the basis Ur is then
-    stored in float32 as well (the reference's U has the dtype of its X, np.linalg.svd :272)."""
+    float32 = storage precision only: every kernel widens on load and computes in f64, and the basis Ur is float64
+    like the reference's (its X0 = (X - X_cnt)/X_scl is float64 for any dtype of X because X_cnt / X_scl are, :106-107,
+    :169, and np.linalg.svd :272 keeps that dtype).  ``basis='f32'`` stores the basis in float32 as well -- a storage
+    option the reference does not have, for shards whose f64 basis would not fit (BASELINE config 5: 204.8 GB shard +
+    51.2 GB f32 basis per GPU); the sensors are then those of the stored basis and ``pivot_gap_`` says how far each
+    pick was from a tie."""
 
-    def __init__(self, tensor):
+    def __init__(self, tensor, basis=None):
+        if basis not in (None, 'f64', 'f32'):
+            raise ValueError("basis must be None / 'f64' / 'f32'")
         self.tensor = tensor
+        self.basis = 'f32' if basis == 'f32' else 'f64'
+        if self.basis == 'f32' and str(tensor.dtype) != 'torch.float32':
+            raise ValueError("basis='f32' is a storage option of a float32 snapshot block")
 
     @property
     def shape(self):
@@ -303,6 +313,11 @@ class ROM:
                 self._d['X'] = eng.to_device(self.X, dtype=eng.torch.float32 if self.X.dtype == np.float32 else None)
         return self._d['X']
 
+    def _basis_dtype(self):
+        """storage type of Ur: float64 (the reference's, for any dtype of X) unless DeviceMatrix(basis='f32')"""
+        t = self._engine().torch
+        return t.float32 if (isinstance(self.X, DeviceMatrix) and self.X.basis == 'f32') else t.float64
+
     def _all_reduce(self, t):
         if self._dist():
             import torch.distributed as dist
@@ -324,6 +339,13 @@ class ROM:
             self._host[key] = make()
         return self._host[key]
 
+    def _fitted(self, key, attr):
+        """Device-resident state `key`; before fit()/scale_data() the reference fails with AttributeError on `attr`."""
+        try:
+            return self._d[key]
+        except KeyError:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute '{attr}'") from None
+
     def _feature_rows(self):
         """per local row: its feature id (host, int) -- only used to expand per-feature scalars"""
         n_loc = self.X.shape[0]
@@ -333,17 +355,18 @@ class ROM:
     @property
     def X_cnt(self):
         """(n_local, 1) row means (reference attribute set at :166)."""
-        return self._lazy('X_cnt', lambda: self._engine().to_host(self._d['rowmean'])[:, None])
+        return self._lazy('X_cnt', lambda: self._engine().to_host(self._fitted('rowmean', 'X_cnt'))[:, None])
 
     @property
     def X_scl(self):
         """(n_local, 1) per-feature population std, repeated per row (:167)."""
+        self._fitted('scale', 'X_scl')
         return self._lazy('X_scl', lambda: self._scl_f[self._feature_rows()][:, None])
 
     @property
     def Ur(self):
         """(n_local, r) POD basis rows held by this rank."""
-        return self._lazy('Ur', lambda: np.ascontiguousarray(self._engine().to_host(self._d['Ur'])))
+        return self._lazy('Ur', lambda: np.ascontiguousarray(self._engine().to_host(self._fitted('Ur', 'Ur'))))
 
     @Ur.setter
     def Ur(self, value):
@@ -361,7 +384,7 @@ class ROM:
         """(n_local, m) centred/scaled matrix (:169, :492); built on first access only."""
         def make():
             eng = self._engine()
-            t = eng.scale_rows(self._Xd(), self._row0, self.n_points, self.n_features, self._d['rowmean'],
+            t = eng.scale_rows(self._Xd(), self._row0, self.n_points, self.n_features, self._fitted('rowmean', 'X0'),
                                self._d['inv_scale'])
             return eng.to_host(t)
         return self._lazy('X0', make)
@@ -455,13 +478,22 @@ class ROM:
         """Fused K1+K3a pass, cross-rank merge, per-feature scale. Leaves rowmean/scale on the device."""
         eng = self._engine()
         Xd = self._Xd()
-        m = Xd.shape[1]
         F = self.n_features
         tr_ = self._trace = _Trace(eng)
         rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
         tr_.mark('stats_gram')
         gram = self._all_reduce(gram)
         fs_d = self._all_gather(fstats)                      # (world, F, 3)
+        self._merge_stats(gram, fs_d, rowmean, scale_type, axis_cnt)
+
+    def _merge_stats(self, gram, fs_d, rowmean, scale_type, axis_cnt):
+        """Per-feature Gram blocks (all-reduced) + per-rank feature statistics -> X_scl per feature and the Gram matrix
+        G of X0 = (X - X_cnt)/X_scl (self._G, host)."""
+        eng = self._engine()
+        Xd = self._Xd()
+        m = Xd.shape[1]
+        F = self.n_features
+        tr_ = self._trace
         if axis_cnt == 1 and scale_type in getattr(eng, 'SCALE_CODES', ()) and hasattr(eng, 'gram_combine'):
             # statistics merge, feature scales and G = sum_f G_f / scl_f^2 on the device (csrc/combine.hip): one
             # download of m^2 + 5F doubles, the scales never leave HBM
@@ -472,6 +504,7 @@ class ROM:
             self._G = packed[:m * m].reshape(m, m)
             self._scl_f = feat[:, 3].copy()
             self._var_f = self._scl_f ** 2
+            self._mu_f = feat[:, 1].copy()
             self._d['rowmean'] = rowmean
             self._d['scale'] = scale_d
             self._d['inv_scale'] = inv_d
@@ -495,10 +528,15 @@ class ROM:
                 mu = mu + d * frac
             cnt = tot
         tr = np.trace(G_f, axis1=1, axis2=2)
+        # a feature WITHOUT rows -- only possible in a partial row group (RowShard(partial=True): one rank's block of a
+        # larger job run alone) -- takes no part: scale 1, and its Gram block is zero anyway
+        present = cnt > 0
         with np.errstate(invalid='ignore', divide='ignore'):
-            var_f = (tr + m * m2) / (cnt * m)                # population variance of the raw block (:115)
-        self._scl_f = self._feature_scale(scale_type, cnt, mu, var_f, m)
+            var_f = np.where(present, (tr + m * m2) / np.where(present, cnt * m, 1.0), 0.0)   # population variance (:115)
+        scl = self._feature_scale(scale_type, cnt, mu, var_f, m)
+        self._scl_f = np.where(present, scl, 1.0)
         self._var_f = self._scl_f ** 2                        # what the Gram blocks are divided by
+        self._mu_f = mu.copy()
         if axis_cnt is None:
             # scalar centre per feature (:112 with axis=None): turn the row-centred Gram blocks into those
             # of (X - mu_f) with the two column-sum vectors, and make X_cnt the per-feature constant
@@ -506,6 +544,7 @@ class ROM:
             v = cs[:, 1, :] - mu[:, None] * cs[:, 0, :]       # sum_i (mean_i - mu_f) c_i
             G_f = G_f + v[:, :, None] + v[:, None, :] + m2[:, None, None]
             rowmean = eng.fill_feature(Xd.shape[0], self._row0, self.n_points, eng.to_device(mu))
+            self._mu_f = np.zeros(F)                          # the centre is a per-feature constant: nothing to cancel
         with np.errstate(invalid='ignore', divide='ignore'):
             self._G = np.sum(G_f / self._var_f[:, None, None], axis=0)   # Gram matrix of X0 = (X - X_cnt)/X_scl
         self._d['rowmean'] = rowmean
@@ -515,6 +554,21 @@ class ROM:
         for k in ('X_cnt', 'X_scl', 'X0'):
             self._host.pop(k, None)
         tr_.mark('merge')
+
+    # The projection kernels remove the row mean in their epilogue, x.W - mean (1^T W): the products carry the mean
+    # through the MFMA and lose log10(|mean| / |x - mean|) digits, which W = V/S amplifies by sigma_1/sigma_i for the
+    # small modes.  Above this product the mean is subtracted from the operand before the multiplication instead
+    # (spr_project_stream_* centre mode 2) -- the reference's own order of operations (:169).
+    _PRECENTER_ABOVE = 1e6
+
+    def _needs_precenter(self, kappa):
+        mu, scl = getattr(self, '_mu_f', None), getattr(self, '_scl_f', None)
+        if mu is None or scl is None or not np.isfinite(kappa):
+            return False
+        with np.errstate(invalid='ignore', divide='ignore'):
+            ratio = np.abs(mu) / np.abs(scl)
+        ratio = ratio[np.isfinite(ratio)]
+        return bool(ratio.size and ratio.max() * kappa > self._PRECENTER_ABOVE)
 
     def scale_data(self, scale_type='std', axis_cnt=1):
         """Reference :83-171.  Sets X_cnt / X_scl and returns the scaled matrix X0."""
@@ -561,7 +615,7 @@ class ROM:
             raise ValueError('The number of columns of sampling does not match the number of rows of X.')
         eng = self._engine()
         ip, ix, v = self._csr_device(sampling)
-        Th, cnt, scl = eng.measure_csr(ip, ix, v, self._d['Ur'], self._row0, self._d['rowmean'],
+        Th, cnt, scl = eng.measure_csr(ip, ix, v, self._fitted('Ur', 'Ur'), self._row0, self._fitted('rowmean', 'X_cnt'),
                                        scale=self._d['scale'], n_points=self.n_points)
         return self._all_reduce(Th), self._all_reduce(cnt), self._all_reduce(scl)
 
@@ -577,8 +631,8 @@ class ROM:
             ones = eng.to_device(np.ones(1))
             t = eng.unscale(eng.to_device(x0), 0, x0.shape[0], 1, cnt, ones, rowscale=scl)
         else:
-            t = eng.unscale(eng.to_device(x0), self._row0, self.n_points, self.n_features, self._d['rowmean'],
-                            self._d['scale'])
+            t = eng.unscale(eng.to_device(x0), self._row0, self.n_points, self.n_features,
+                            self._fitted('rowmean', 'X_cnt'), self._d['scale'])
         return eng.to_host(t)
 
     # ------------------------------------------------------------------ a4 reduction
@@ -628,6 +682,9 @@ class ROM:
 
     def _spectrum(self, G):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
+        if not np.all(np.isfinite(G)):
+            # a constant feature (X_scl = 0 -> X0 = nan/inf, :169) or a NaN/Inf in X: np.linalg.svd(X0) (:272) raises
+            raise np.linalg.LinAlgError('SVD did not converge')
         lam, V = _eigh_small(G)
         lam, V = self._same_on_all_ranks(lam, V)
         lam = lam[::-1]
@@ -661,10 +718,12 @@ class ROM:
             floor = S[0] * np.sqrt(m * eps)
             d = np.maximum(S, floor if floor > 0 else 1.0)
             W2 = eng.to_device(V / d)
+            pre = bool(center and self._needs_precenter(S[0] / d[r - 1]))
             H_d = None
             for i0 in range(0, n_loc, block):
                 rows = min(block, n_loc - i0)
-                eng.project_f64(Xd, i0, rows, row0, n_points, n_features, inv_scale_d, W2, rowmean_d, Y, center=center)
+                eng.project_f64(Xd, i0, rows, row0, n_points, n_features, inv_scale_d, W2, rowmean_d, Y, center=center,
+                                precenter=pre)
                 Yb = Y[:rows, :m] if Y.shape[1] != m else Y[:rows]
                 _, _, g = eng.stats_gram(Yb, 0, rows, 1, center=False)
                 H_d = g[0].clone() if H_d is None else H_d.add_(g[0])
@@ -713,8 +772,10 @@ class ROM:
         W = V[:, :r] / S_safe
         W_d = eng.to_device(W)
         self._trace.mark('upload')
+        self.precentered_ = bool(center and self._needs_precenter(S[0] / S_safe[-1]))
         Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, W_d,
-                           center=center, out=self._d.pop('Ur', None), rowmean=self._d.get('rowmean'))
+                           center=center, out=self._d.pop('Ur', None), rowmean=self._d.get('rowmean'),
+                           basis_dtype=self._basis_dtype(), precenter=self.precentered_)
         self._trace.mark('project')
         Ar = V[:, :r] * S[:r]                                # A = (diag(S) Vt).T  (:273)
         return Ur_d, Ar, exp_variance[:r], S, r, V[:, :r]
@@ -763,9 +824,11 @@ class ROM:
             self.__dict__.pop(k, None)
         for k in ('cnt', 'Theta'):                            # a new basis invalidates the trained measurement state
             self._d.pop(k, None)
-        if self._device_fit(scale_type, axis_cnt, select_modes, n_modes, basis):
+        took = self._device_fit(scale_type, axis_cnt, select_modes, n_modes, basis)
+        if took is True:
             return
-        self._stats_pass(scale_type, axis_cnt)
+        if took != 'merged':                                  # 'merged': the device route left its statistics behind
+            self._stats_pass(scale_type, axis_cnt)
         self._host.clear()
         if basis is None:
             Ur_d, Ar, expv, S, r, V_r = self._basis_from_gram(self._G, select_modes, n_modes, True, self._d['inv_scale'])
@@ -806,23 +869,36 @@ class ROM:
         tr_ = self._trace = _Trace(eng)
         rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
         gram = self._all_reduce(gram)
-        sp = eng.spectrum(gram, self._all_gather(fstats), scale_type, r)
+        fs_all = self._all_gather(fstats)
+        sp = eng.spectrum(gram, fs_all, scale_type, r)
         tr_.mark('stats_gram+spectrum')
         self._host.clear()
         self._d['rowmean'] = rowmean
         self._d['scale'] = sp['scale']
         self._d['inv_scale'] = sp['inv_scale']
         self._d['Ur'] = eng.project(Xd, self._row0, self.n_points, F, sp['inv_scale'], sp['W'], center=True,
-                                    out=self._d.pop('Ur', None), rowmean=rowmean)
+                                    out=self._d.pop('Ur', None), rowmean=rowmean, basis_dtype=self._basis_dtype())
         tr_.mark('project')
-        # the only download of this path: the two singular values that decide whether the Gram route was good enough
-        # and the Jacobi verdict (sweeps, off^2, diag^2) -- fetched after the projection has been enqueued
-        chk = eng.to_host(eng.torch.cat([sp['S'][:1], sp['S'][r - 1:r], sp['info']]))
-        converged = chk[2] < eng.spectrum_max_sweeps or chk[3] <= 1e-24 * chk[4]
-        if not converged or chk[1] * _GRAM_KAPPA_REFINE < chk[0]:
-            return False                                       # the host route decides (refinement pass or LinAlgError)
+        # the only download of this path: the two singular values that decide whether the Gram route was good enough,
+        # the Jacobi verdict (sweeps, off^2, diag^2) and the feature statistics -- fetched after the projection has been
+        # enqueued, so the device never idles on the good path
+        chk = eng.to_host(eng.torch.cat([sp['S'][:1], sp['S'][r - 1:r], sp['info'], sp['feat'].reshape(-1)]))
+        feat = chk[5:].reshape(F, 5)
+        self._scl_f, self._mu_f = feat[:, 3].copy(), feat[:, 1].copy()
+        good = bool(np.all(np.isfinite(chk)))
+        if good:
+            converged = chk[2] < eng.spectrum_max_sweeps or chk[3] <= 1e-24 * chk[4]
+            kappa = chk[0] / chk[1] if chk[1] > 0 else np.inf
+            good = converged and not kappa > _GRAM_KAPPA_REFINE and not self._needs_precenter(kappa)
+        if not good:
+            # out of the plain Gram route's range (or non-finite data): the host route decides -- refinement pass,
+            # pre-centred projection or LinAlgError -- from the Gram blocks this pass already has (no second read of X)
+            self._merge_stats(gram, fs_all, rowmean, scale_type, axis_cnt)
+            self._device_fit_fallback_ = True
+            return 'merged'
         self.r = r
         self.gram_refine_passes_ = 0
+        self.precentered_ = False
         sp['r'] = r
         self._pending = sp
         tr_.report()
@@ -851,7 +927,8 @@ class ROM:
             Thp = Th if Th.shape[1] % 2 == 0 else eng.torch.nn.functional.pad(Th, (0, 1))[:, :Th.shape[1]]
             out = eng.reconstruct(Thp, 0, Th.shape[0], 1, cnt, ones, A_d, rowscale=scl)
             return out if not to_host else eng.to_host(out).T
-        Ur_d = self._d['Ur']
+        Ur_d = self._fitted('Ur', 'Ur')
+        self._fitted('rowmean', 'X_cnt')
         n_loc = Ur_d.shape[0]
         n_p = A_d.shape[0]
         world = self._world()
@@ -891,7 +968,7 @@ class SPR(ROM):
             raise NotImplementedError('The sensor selection method has not been implemented yet')
         eng = self._engine()
         n = self._n_global
-        Ur_d = self._d['Ur']
+        Ur_d = self._fitted('Ur', 'Ur')
         if mask is not None:
             mask = np.asarray(mask)
             if mask.dtype != np.bool_ or mask.shape != (Ur_d.shape[0],):
@@ -922,7 +999,7 @@ class SPR(ROM):
         noise-free limit, so picks whose lead over the runner-up is below that noise level are not comparable.
         Beyond r-1 sensors S_aa is singular and the reference's picks are decided by that noise alone."""
         eng = self._engine()
-        Ur_d = self._d['Ur']
+        Ur_d = self._fitted('Ur', 'Ur')
         r = self.r
         if type(n_sensors) is not int or n_sensors < 1:
             raise ValueError('n_sensors must be a positive integer.')
@@ -1050,7 +1127,8 @@ class SPR(ROM):
                 piv = placed[1]
                 known = (np.arange(len(piv) + 1), piv, np.ones(len(piv)))
             ip, ix, v = self._csr_device(C, known)
-            Theta_d, cnt_d = eng.measure_csr(ip, ix, v, self._d['Ur'], self._row0, self._d['rowmean'])
+            Theta_d, cnt_d = eng.measure_csr(ip, ix, v, self._fitted('Ur', 'Ur'), self._row0,
+                                             self._fitted('rowmean', 'X_cnt'))
             Theta_d = self._all_reduce(Theta_d)
             cnt_d = self._all_reduce(cnt_d)
             self.C = C

@@ -317,6 +317,13 @@ def main():
     X = synth(400, 3, 16, 16, 0.7, 1e-3, 909)
     for k, kind in enumerate(['under', 'dup', 'zerocol', 'illcond']):
         run_pinv_case(sps, 'pinv_' + kind, X, 3, 8, 910 + k, kind)
+    # float32 snapshot matrices: X_cnt / X_scl are float64 (np.zeros, :106-107), so X0 = (X - X_cnt)/X_scl (:169), U (:272),
+    # Ur and Ar come out float64 -- the means and the std themselves are formed by NumPy in float32 (np.average / np.std of
+    # a float32 block).  The fixtures store X as float32; consumers read Ur.dtype from the stored array.
+    X = synth(500, 3, 12, 12, 0.7, 1e-3, 202).astype(np.float32)
+    run_case(sps, 'f32_g2_num4', X, 3, 'number', 4, 1001)
+    X = synth(2000, 4, 24, 24, 10 ** (-3 / 15), 1e-4, 303).astype(np.float32)
+    run_case(sps, 'f32_g3_num8', X, 4, 'number', 8, 1002)
     # conditioning of the Gram route (hard part 1): designed spectra with sigma_1/sigma_r = 1e5 and 1e7
     for tag, decades in (('1e5', 5), ('1e7', 7)):
         X = synth(1500, 3, 20, 20, 10 ** (-decades / 9), 1e-11, 920 + decades)

@@ -58,15 +58,17 @@ class NumpyEngine:
         return torch.from_numpy(mean.copy()), torch.from_numpy(fstats), torch.from_numpy(gram)
 
     # K4
-    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None):
+    def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None,
+                basis_dtype=None, precenter=False):
         x = self._w(X)
         n = x.shape[0]
         mean = (rowmean.numpy() if rowmean is not None else x.mean(axis=1)) if center else np.zeros(n)
         feat = self._feat(n, row0, n_points, n_features)
         U = ((x - mean[:, None]) @ W.numpy()) * inv_scale.numpy()[feat][:, None]
-        return torch.from_numpy(np.ascontiguousarray(U)).to(X.dtype)     # stored like the shard
+        return torch.from_numpy(np.ascontiguousarray(U)).to(basis_dtype or torch.float64)   # f64 unless asked otherwise
 
-    def project_f64(self, X, i0, rows, row0, n_points, n_features, inv_scale, W, rowmean, out, center=True):
+    def project_f64(self, X, i0, rows, row0, n_points, n_features, inv_scale, W, rowmean, out, center=True,
+                    precenter=False):
         x = self._w(X)[i0:i0 + rows]
         feat = self._feat(rows, row0 + i0, n_points, n_features)
         mean = rowmean.numpy()[i0:i0 + rows, None] if center else 0.0

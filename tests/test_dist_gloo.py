@@ -190,16 +190,17 @@ def _f32_worker(rank, world, port, fixture, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix, RowShard
         from tests.conftest import load_golden
         from tests.numpy_engine import NumpyEngine
+        import torch
         g = load_golden(fixture)
         X32 = g['X'].astype(np.float32)
         n = X32.shape[0]
         n_loc = n // world
         row0 = rank * n_loc
-        spr = SPR(np.ascontiguousarray(X32[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
-                  engine=NumpyEngine())
+        blk = torch.from_numpy(np.ascontiguousarray(X32[row0:row0 + n_loc]))
+        spr = SPR(DeviceMatrix(blk, basis='f32'), g['n_features'], None, shard=RowShard(row0, n), engine=NumpyEngine())
         spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
         assert spr.Ur.dtype == np.float32
         spr.train(spr.optimal_placement())
@@ -219,7 +220,10 @@ def test_sharded_f32_storage(tmp_path):
     fixture, world = 'g3_num8', 2
     g = load_golden(fixture)
     mp.spawn(_f32_worker, args=(world, _free_port(), fixture, str(tmp_path)), nprocs=world, join=True)
-    one = SPR(g['X'].astype(np.float32), g['n_features'], None, engine=NumpyEngine())
+    import torch
+    from openmeasure_amd.sparse_sensing import DeviceMatrix
+    one = SPR(DeviceMatrix(torch.from_numpy(g['X'].astype(np.float32)), basis='f32'), g['n_features'], None,
+              engine=NumpyEngine())
     one.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
     one.train(one.optimal_placement())
     A3, _ = one.predict(list(g['ys']))

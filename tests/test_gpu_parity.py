@@ -66,10 +66,13 @@ def test_f32_storage_kernels_vs_f64_twins(eng):
     np.testing.assert_array_equal(eng.to_host(eng.colsums(Xs, 0, n_points, F, ms)), eng.to_host(eng.colsums(Xw, 0, n_points, F, mw)))
     W = eng.to_device(rng.standard_normal((m, r)))
     inv = eng.to_device(np.ones(F))
-    Us = eng.project(Xs, 0, n_points, F, inv, W, rowmean=ms)
+    Us = eng.project(Xs, 0, n_points, F, inv, W, rowmean=ms, basis_dtype=torch.float32)
     Uw = eng.project(Xw, 0, n_points, F, inv, W, rowmean=mw)
     assert Us.dtype == torch.float32 and Uw.dtype == torch.float64
     np.testing.assert_array_equal(eng.to_host(Us), eng.to_host(Uw).astype(np.float32))
+    Ud = eng.project(Xs, 0, n_points, F, inv, W, rowmean=ms)            # default: float64 basis of the f32 shard
+    assert Ud.dtype == torch.float64
+    np.testing.assert_array_equal(eng.to_host(Ud), eng.to_host(Uw))
     Uq = eng.to_device(eng.to_host(Us).astype(np.float64))            # the stored basis, widened
     a = eng.to_device(rng.standard_normal((5, r)))
     sc = eng.to_device(np.array([1.0, 2.0, 0.5]))
@@ -223,10 +226,15 @@ def test_project_w_stationary_vs_oracle(eng, n_points, F, m, r, row0_cells, f32)
     assert Xl.shape[0] >= 4096
     inv = eng.to_device(1.0 / X_scl[::n_points, 0])
     Xd = eng.to_device(Xl.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(Xl)
-    U = eng.to_host(eng.project(Xd, row0, n_points, F, inv, eng.to_device(W), rowmean=eng.to_device(X_cnt[row0:, 0])))
+    bd = torch.float32 if f32 else None                         # f32 basis = storage option: one rounding of the f64 result
+    U = eng.to_host(eng.project(Xd, row0, n_points, F, inv, eng.to_device(W), rowmean=eng.to_device(X_cnt[row0:, 0]),
+                                basis_dtype=bd))
     ref = X0[row0:] @ W
-    tol = 2e-7 if f32 else 1e-12                                # f32 basis: one rounding of the f64 result
+    tol = 2e-7 if f32 else 1e-12
     assert U.shape == ref.shape and np.abs(U - ref).max() <= tol * np.abs(ref).max()
+    if f32:                                                     # default for an f32 shard: the reference's float64 basis
+        U64 = eng.to_host(eng.project(Xd, row0, n_points, F, inv, eng.to_device(W), rowmean=eng.to_device(X_cnt[row0:, 0])))
+        assert U64.dtype == np.float64 and np.abs(U64 - ref).max() <= 1e-12 * np.abs(ref).max()
     if not f32:
         ones = eng.to_device(np.ones(F))
         U0 = eng.to_host(eng.project(Xd, row0, n_points, F, ones, eng.to_device(W), center=False))
@@ -257,11 +265,75 @@ def test_project_w_stationary_random_shapes(eng, seed):
     feat = (row0 + np.arange(n_loc)) // n_points
     W = rng.standard_normal((m, r))
     Xd = eng.to_device(X.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(X)
-    U = eng.to_host(eng.project(Xd, row0, n_points, F, eng.to_device(1.0 / scl), eng.to_device(W), rowmean=eng.to_device(mu)))
+    U = eng.to_host(eng.project(Xd, row0, n_points, F, eng.to_device(1.0 / scl), eng.to_device(W), rowmean=eng.to_device(mu),
+                                basis_dtype=torch.float32 if f32 else None))
     ref = ((X - mu[:, None]) @ W) / scl[feat][:, None]
     tol = 2e-7 if f32 else 1e-12
     assert U.shape == ref.shape
     assert np.abs(U - ref).max() <= tol * np.abs(ref).max(), (m, r, F, n_points, row0, n_loc, f32)
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_project_stream_random_shapes(eng, seed):
+    """The streamed-W projection kernel (csrc/project_stream.hip: any m, r <= 128 per column group): m from 257 to 1100
+    incl. widths that are not multiples of 4 / 32 (scalar loads, padded chunks), r from 1 to 300 (column groups of 128),
+    ragged 16- and 256-row tails, shards starting inside a feature, f64 and f32 storage with f64 and f32 bases, centring
+    in the epilogue, in registers (precenter) and none -- against ((X - mean) W) / X_scl formed in NumPy."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    m = int([512, 300, 260, 384, 513, 600, 1024, 257, 640, 1100][seed % 10])
+    r = int([128, 40, 16, 100, 33, 130, 64, 1, 300, 7][(seed // 2) % 10])
+    F = int(rng.integers(1, 5))
+    n_points = int(rng.integers(1200, 6000) // F + 1)
+    n = n_points * F
+    row0 = int(rng.integers(0, n // 3)) if seed % 3 else 0
+    n_loc = int(rng.integers(max(1, (n - row0) // 2), n - row0 + 1))
+    f32 = seed % 4 == 1
+    f32_basis = f32 and seed % 8 == 1
+    X = rng.standard_normal((n_loc, m)) * 3.0 + rng.standard_normal((n_loc, 1)) * 10.0
+    if f32:
+        X = X.astype(np.float32).astype(np.float64)
+    mu = X.mean(axis=1)
+    scl = 0.5 + rng.random(F)
+    feat = (row0 + np.arange(n_loc)) // n_points
+    W = rng.standard_normal((m, r))
+    Xd = eng.to_device(X.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(X)
+    if seed % 5 == 4:                                           # a row stride that is not the width (and odd alignment)
+        pad = torch.empty((n_loc, m + 3), dtype=Xd.dtype, device=Xd.device)
+        pad[:, :m] = Xd
+        Xd = pad[:, :m]
+    bd = torch.float32 if f32_basis else None
+    tol = 2e-7 if f32_basis else 1e-12
+    ref = ((X - mu[:, None]) @ W) / scl[feat][:, None]
+    for pre in (False, True):
+        U = eng.to_host(eng.project(Xd, row0, n_points, F, eng.to_device(1.0 / scl), eng.to_device(W),
+                                    rowmean=eng.to_device(mu), basis_dtype=bd, precenter=pre))
+        assert U.shape == ref.shape and U.dtype == (np.float32 if f32_basis else np.float64)
+        assert np.abs(U - ref).max() <= tol * np.abs(ref).max(), (m, r, F, n_points, row0, n_loc, f32, pre)
+    U0 = eng.to_host(eng.project(Xd, row0, n_points, F, eng.to_device(np.ones(F)), eng.to_device(W), center=False,
+                                 basis_dtype=bd))
+    ref0 = X @ W
+    assert np.abs(U0 - ref0).max() <= tol * np.abs(ref0).max(), (m, r, 'uncentred')
+
+
+def test_project_precentred_large_means(eng):
+    """Row means 1e6 times the fluctuation (pressure / temperature fields): removing the mean in the epilogue,
+    x.W - mean (1^T W), loses 6 digits to cancellation; centre mode 2 of the streamed-W kernel subtracts it from the
+    operand first -- the reference's own order (:169) -- and keeps f64 accuracy.  Both against longdouble NumPy."""
+    rng = np.random.default_rng(77)
+    n_points, F, m, r = 5000, 2, 256, 64
+    n = n_points * F
+    fl = rng.standard_normal((n, m))
+    X = 1e6 * (1.0 + rng.random((n, 1))) + fl
+    mu = X.mean(axis=1)
+    W = rng.standard_normal((m, r))
+    ref = np.asarray((X.astype(np.longdouble) - mu[:, None].astype(np.longdouble)) @ W.astype(np.longdouble), dtype=np.float64)
+    args = (eng.to_device(X), 0, n_points, F, eng.to_device(np.ones(F)), eng.to_device(W))
+    epi = eng.to_host(eng.project(*args, rowmean=eng.to_device(mu)))
+    pre = eng.to_host(eng.project(*args, rowmean=eng.to_device(mu), precenter=True))
+    e_epi, e_pre = np.abs(epi - ref).max() / np.abs(ref).max(), np.abs(pre - ref).max() / np.abs(ref).max()
+    assert e_pre <= 1e-13, e_pre
+    assert 1e-12 < e_epi < 1e-7, e_epi                         # the cancellation the pre-centred form avoids
 
 
 @pytest.mark.parametrize('n,r,n_p', [(20, 5, 1), (999, 5, 3), (4096, 32, 1), (5000, 64, 5), (3001, 128, 2), (777, 1, 1), (1234, 14, 2)])

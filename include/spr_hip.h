@@ -38,9 +38,11 @@ extern "C" {
 #define SPR_E_HIP (-3)       /* a HIP runtime call failed                        */
 #define SPR_E_WORKSPACE (-4) /* workspace too small                              */
 
-#define SPR_MAX_M 256        /* snapshots (columns of X) one Gram / projection launch handles   */
-#define SPR_MAX_M_WIDE 512   /* ... and with the column-split path (spr_rowstats / spr_gram_cross) */
-#define SPR_MAX_R 128        /* retained modes / sensors                              */
+#define SPR_MAX_M 256        /* snapshots (columns of X) one symmetric-Gram / register-resident projection launch handles */
+#define SPR_MAX_M_WIDE 512   /* ... and the two-slice Gram path that forms the row means itself (spr_gram_cross, centre 1);
+                                wider matrices go as slice pairs (spr_gram_cross_pair), any m                       */
+#define SPR_MAX_R 128        /* retained modes / sensors ONE launch handles; callers go in column groups beyond      */
+#define SPR_MAX_R_WIDE 1024  /* ... the widest basis the placement / solve kernels accept (r <= m in the reference, :336) */
 
 int spr_abi_version(void);
 const char *spr_last_error(void);
@@ -101,6 +103,17 @@ int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx
 int spr_rowmean_stats_f64(const double *d_rowmean, int64_t n_rows, int64_t row0, int64_t n_points,
                           int32_t n_features, double *d_fstats, void *d_workspace, size_t workspace_bytes,
                           void *stream);   /* workspace: spr_rowstats_workspace(n_features) */
+/* m > 512 (any snapshot count, :272 accepts any X0): the columns are cut into slices of 256 (the last one 1..256 wide);
+ *   spr_rowstats_f64 first (row means of the full rows + feature statistics: one read of X), then, all with the row
+ *   means READ from d_rowmean (centre mode 2; 0 for rows taken as they are),
+ *   spr_stats_gram_f64 + finalize (ldg = m, origin = 256 i) on every slice i -> diagonal blocks,
+ *   spr_gram_cross_pair_f64 on every pair i < j: A = the 256 columns at col_a = 256 i, B = the w_b columns at
+ *   col_b = 256 j; block (col_a.., col_b..) and its mirror are written into the per-feature ldg x ldg matrices.
+ *   Workspace of a pair: spr_gram_cross_workspace(256 + w_b, n_features). */
+int spr_gram_cross_pair_f64(const double *d_X, int64_t n_rows, int32_t col_a, int32_t col_b, int32_t w_b,
+                            int32_t ldg, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features,
+                            int32_t center, double *d_rowmean, double *d_gram, void *d_workspace,
+                            size_t workspace_bytes, void *stream);
 
 /* ---- K3b : device-side spectrum for m <= spr_spectrum_max_m() (= 64) ------------------------
  * Replaces, for small snapshot counts, the host eigen-solve behind np.linalg.svd (:272), the block
@@ -245,7 +258,8 @@ int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t l
  *                    applies those picks.  d_mask / d_xyz may be NULL.
  * spr_qr_step        with d_xyz != NULL also drops the candidates closer than d_min to the step's pick. */
 #define SPR_QR_REC_LEN(r) ((r) + 3)
-size_t spr_qr_workspace(int64_t n_rows);
+size_t spr_qr_workspace(int64_t n_rows);                 /* r <= SPR_MAX_R */
+size_t spr_qr_workspace_r(int64_t n_rows, int32_t r);    /* any r <= SPR_MAX_R_WIDE (0 beyond) */
 int32_t spr_qr_batch(void);
 int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
                       const uint8_t *d_mask, void *stream);
@@ -310,6 +324,14 @@ int spr_solve_pinv_f64(const double *d_Theta, int32_t s, int32_t r, const double
                        double rcond, double *d_Ar, double *d_Ar_sigma, double *d_y0, double *d_info,
                        void *stream);
 
+/* r > SPR_MAX_R (the reference keeps any r <= m modes, :336): the same algorithm with its factor in a workspace of
+ * spr_solve_pinv_workspace(r, n_p) bytes (L2-resident; one 1024-thread workgroup per vector), r <= SPR_MAX_R_WIDE. */
+size_t spr_solve_pinv_workspace(int32_t r, int32_t n_p);
+int spr_solve_pinv_wide_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt, int32_t s_cnt,
+                            const double *d_scale, int32_t n_features, const double *d_y, int32_t n_p,
+                            double rcond, double *d_Ar, double *d_Ar_sigma, double *d_y0, double *d_info,
+                            void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- synthetic snapshot matrices (benchmark input) -------------------
  * X[i,j] = (f+1) * ( sum_k L[i,k] R[k,j] + eps * N[i,j] ) + 10 f, with L, N standard
  * normal from a counter-based generator keyed by (seed, GLOBAL row, column), so any row
@@ -340,6 +362,10 @@ int spr_rowstats_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, i
 int spr_gram_cross_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                        int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                        double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_gram_cross_pair_x32(const float *d_X, int64_t n_rows, int32_t col_a, int32_t col_b, int32_t w_b,
+                            int32_t ldg, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features,
+                            int32_t center, double *d_rowmean, double *d_gram, void *d_workspace,
+                            size_t workspace_bytes, void *stream);
 int spr_project_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                     int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
                     const double *d_rowmean, const double *d_W, int32_t r, float *d_Ur, int64_t ldu,

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get('SPR_HIP_LIBRARY') or os.path.join(_HERE, 'libspr_hip.
 SPR_MAX_M = 256
 SPR_MAX_M_WIDE = 512
 SPR_MAX_R = 128
+SPR_MAX_R_WIDE = 1024
 
 _i32, _i64, _u64, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 _p = C.c_void_p
@@ -40,6 +41,7 @@ PROTOTYPES = {
     'spr_rowstats_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     'spr_gram_cross_workspace': (_sz, [_i32, _i32]),
     'spr_gram_cross_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
+    'spr_gram_cross_pair_f64': (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
     'spr_rowmean_stats_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     'spr_spectrum_max_m': (_i32, []),
     'spr_spectrum_f64': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -57,6 +59,7 @@ PROTOTYPES = {
     'spr_fill_feature_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p]),
     'spr_reconstruct_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     'spr_qr_workspace': (_sz, [_i64]),
+    'spr_qr_workspace_r': (_sz, [_i64, _i32]),
     'spr_qr_batch': (_i32, []),
     'spr_mask_rows_f64': (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     'spr_qr_init_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
@@ -67,6 +70,8 @@ PROTOTYPES = {
     'spr_measure_csr_f64': (C.c_int, [_p, _p, _p, _i32, _p, _i64, _i32, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     'spr_solve_ols_f64': (C.c_int, [_p, _i32, _i32, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     'spr_solve_pinv_f64': (C.c_int, [_p, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _dbl, _p, _p, _p, _p, _p]),
+    'spr_solve_pinv_workspace': (_sz, [_i32, _i32]),
+    'spr_solve_pinv_wide_f64': (C.c_int, [_p, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _dbl, _p, _p, _p, _p, _p, _sz, _p]),
     'spr_synth_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p]),
     'spr_synth_gather_f64': (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p, _p]),
 }
@@ -82,7 +87,7 @@ PROTOTYPES['spr_project_x32_acc'] = (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64,
 
 # f32-storage twins: identical argument lists (the typed pointer is a void* here)
 for _f64, _x32 in (('spr_stats_gram_f64', 'spr_stats_gram_x32'), ('spr_rowstats_f64', 'spr_rowstats_x32'),
-                   ('spr_gram_cross_f64', 'spr_gram_cross_x32'), ('spr_project_f64', 'spr_project_x32'),
+                   ('spr_gram_cross_f64', 'spr_gram_cross_x32'), ('spr_gram_cross_pair_f64', 'spr_gram_cross_pair_x32'), ('spr_project_f64', 'spr_project_x32'),
                    ('spr_project_f64', 'spr_project_x32_f64out'),
                    ('spr_project_stream_f64', 'spr_project_stream_x32'),
                    ('spr_project_stream_f64', 'spr_project_stream_x32_f64out'),

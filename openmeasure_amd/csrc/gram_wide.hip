@@ -115,7 +115,7 @@ template <int NTJ, int VEC, typename TX, bool OWN>
 __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restrict__ X, int64_t ldx, int m,
                                                             int center, SegPlan plan,
                                                             double *__restrict__ rowmean,
-                                                            double *__restrict__ slab) {
+                                                            double *__restrict__ slab, int64_t gap) {
   constexpr int MTF = 16 + NTJ;                 // padded full width in tiles
   constexpr int MP = 16 * MTF + ((MTF % 2 == 0) ? 16 : 0);
   constexpr int KSTEPS = CR / 4;
@@ -146,11 +146,13 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
   const double *mean_in = OWN ? nullptr : rowmean;
   const int64_t nchunks = (hi - lo + CR - 1) / CR;
   int64_t c = wl;
-  tile.template load<VEC>(X, ldx, m, lo + c * CR, hi, wave, lane, mean_in);
+  // m here is the PANEL width 256 + wB; panel columns >= 256 sit `gap` elements further along the row (0 when the two
+  // slices are adjacent, as for m <= 512)
+  tile.template load<VEC>(X, ldx, m, lo + c * CR, hi, wave, lane, mean_in, CMA, gap);
   tile.template center_store<OWN>(lds[0], m, center, lo + c * CR, hi, wave, lane, OWN ? rowmean : nullptr, &st);
   int64_t cn = c + wpf;
   int64_t nrow0 = (cn < nchunks) ? lo + cn * CR : hi;
-  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in);
+  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in, CMA, gap);
   int buf = 0;
   const int frag = (lane >> 4) * MP + (lane & 15);
   while (c < nchunks) {
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
       for (int j = 0; j < NTJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[j], 0, 0, 0);
       if (k == 0) {
         tile.template center_store_pass<OWN>(0, nxt, m, center, nrow0, hi, wave, lane, OWN ? rowmean : nullptr, &st);
-        tile.template load_pass<VEC>(0, X, ldx, m, n2row0, hi, wave, lane, mean_in);
+        tile.template load_pass<VEC>(0, X, ldx, m, n2row0, hi, wave, lane, mean_in, CMA, gap);
       }
     }
     buf ^= 1;
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
 
 // grid (16 * NTJ tiles, n_features), 256 threads: fixed-order sum over the feature's block pairs
 template <int NTJ>
-__global__ __launch_bounds__(256) void gram_cross_finalize_kernel(const double *__restrict__ slab, int m, SegPlan plan,
-                                                                  double *__restrict__ gram) {
+__global__ __launch_bounds__(256) void gram_cross_finalize_kernel(const double *__restrict__ slab, int wB, SegPlan plan,
+                                                                  double *__restrict__ gram, int ldg, int oa, int ob) {
   const int f = blockIdx.y;
   const int ti = blockIdx.x / NTJ, tj = blockIdx.x % NTJ;
   int base = 0, wpf = 0, acc = 0;
@@ -206,11 +208,11 @@ __global__ __launch_bounds__(256) void gram_cross_finalize_kernel(const double *
   double s = 0.0;
   for (int p = 0; p < wpf; ++p) s += slab[((((int64_t)(base + p) * 16 + ti) * NTJ) + tj) * 256 + e];
   const int l = e & 63, reg = e >> 6;
-  const int gi = ti * 16 + (l >> 4) + 4 * reg, gj = CMA + tj * 16 + (l & 15);
-  if (gj < m) {
-    double *G = gram + (int64_t)f * m * m;
-    G[(int64_t)gi * m + gj] = s;
-    G[(int64_t)gj * m + gi] = s;
+  const int gi = oa + ti * 16 + (l >> 4) + 4 * reg, bj = tj * 16 + (l & 15), gj = ob + bj;
+  if (bj < wB) {                                  // block (oa.., ob..) of the per-feature ldg x ldg matrix, and its mirror
+    double *G = gram + (int64_t)f * ldg * ldg;
+    G[(int64_t)gi * ldg + gj] = s;
+    G[(int64_t)gj * ldg + gi] = s;
   }
 }
 
@@ -223,10 +225,12 @@ int plan_wgs(SegPlan &plan, int64_t n_rows, int64_t row0, int64_t n_points, int3
   return seg_total_wgs(plan);
 }
 
+// X points at column colA of the rows; the panel is [A = 256 columns at colA | B = wB columns at colB]
 template <int NTJ, typename TX>
-int launch_cross(const TX *X, int64_t n_rows, int m, int64_t ldx, int64_t row0, int64_t n_points,
+int launch_cross(const TX *X, int64_t n_rows, int wB, int64_t ldx, int64_t row0, int64_t n_points,
                  int32_t n_features, int center, double *rowmean, double *gram, void *ws, size_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, int64_t gap, int ldg, int oa, int ob) {
+  const int m = CMA + wB;
   SegPlan plan;
   const int pairs = plan_wgs(plan, n_rows, row0, n_points, n_features, CR, 1);   // one workgroup per CU: 2 flavours share them
   // halve the pair count so that pairs * 2 workgroups still fit one per CU
@@ -235,14 +239,14 @@ int launch_cross(const TX *X, int64_t n_rows, int m, int64_t ldx, int64_t row0, 
   (void)pairs;
   const size_t need = (size_t)npairs * 16 * NTJ * 256 * sizeof(double);
   SPR_REQUIRE(ws_bytes >= need, SPR_E_WORKSPACE, "spr_gram_cross_f64: workspace %zu < %zu", ws_bytes, need);
-  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
+  const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && (gap % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
   double *slab = static_cast<double *>(ws);
-#define GXK(V, O) hipLaunchKernelGGL((gram_cross_kernel<NTJ, V, TX, O>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan, rowmean, slab)
+#define GXK(V, O) hipLaunchKernelGGL((gram_cross_kernel<NTJ, V, TX, O>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan, rowmean, slab, gap)
   if (center == 1) { if (vec_ok) GXK(1, true); else GXK(0, true); }
   else { if (vec_ok) GXK(1, false); else GXK(0, false); }
 #undef GXK
   SPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gram_cross_finalize_kernel<NTJ>, dim3(16 * NTJ, n_features), dim3(256), 0, st, slab, m, plan, gram);
+  hipLaunchKernelGGL(gram_cross_finalize_kernel<NTJ>, dim3(16 * NTJ, n_features), dim3(256), 0, st, slab, wB, plan, gram, ldg, oa, ob);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
@@ -317,18 +321,22 @@ extern "C" size_t spr_gram_cross_workspace(int32_t m, int32_t n_features) {
 }
 
 template <typename TX>
-static int gram_cross_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
-                            int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
-                            double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
+static int gram_cross_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t col_a, int32_t col_b, int32_t w_b,
+                            int32_t ldg, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features, int32_t center,
+                            double *d_rowmean, double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
   SPR_REQUIRE(d_X && d_rowmean && d_gram && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
-  SPR_REQUIRE(n_rows > 0 && m > CMA && m <= 512 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
+  SPR_REQUIRE(n_rows > 0 && col_a >= 0 && col_b >= col_a + CMA && w_b > 0 && w_b <= CMA && ldx >= col_b + w_b &&
+                  ldg >= col_b + w_b && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
-              SPR_E_INVALID, "%s: bad shape (m must be in (256, 512])", who);
+              SPR_E_INVALID, "%s: bad shape (A = 256 columns at col_a, B = 1..256 columns at col_b >= col_a + 256)", who);
   SPR_REQUIRE(center >= 0 && center <= 2, SPR_E_INVALID, "%s: centre mode must be 0, 1 (own means, written) or 2 (external means)", who);
+  SPR_REQUIRE(center != 1 || (col_a == 0 && col_b == CMA && ldg == CMA + w_b), SPR_E_INVALID,
+              "%s: centre mode 1 forms the means of the panel's rows: the panel must be the whole row", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int ntj = (m - CMA + 15) / 16;
-#define GX(N) return launch_cross<N, TX>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_gram, \
-                                         d_workspace, workspace_bytes, st)
+  const int ntj = (w_b + 15) / 16;
+  const int64_t gap = (int64_t)col_b - col_a - CMA;
+#define GX(N) return launch_cross<N, TX>(d_X + col_a, n_rows, w_b, ldx, row0, n_points, n_features, center, d_rowmean, d_gram, \
+                                         d_workspace, workspace_bytes, st, gap, ldg, col_a, col_b)
   if (ntj <= 4) GX(4);
   if (ntj <= 8) GX(8);
   if (ntj <= 12) GX(12);
@@ -339,13 +347,35 @@ static int gram_cross_entry(const char *who, const TX *d_X, int64_t n_rows, int3
 extern "C" int spr_gram_cross_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                                   int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                                   double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
-  return gram_cross_entry("spr_gram_cross_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean,
-                          d_gram, d_workspace, workspace_bytes, stream);
+  SPR_REQUIRE(m > CMA && m <= 2 * CMA, SPR_E_INVALID, "spr_gram_cross_f64: m must be in (256, 512]");
+  return gram_cross_entry("spr_gram_cross_f64", d_X, n_rows, 0, CMA, m - CMA, m, ldx, row0, n_points, n_features, center,
+                          d_rowmean, d_gram, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int spr_gram_cross_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                                   int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                                   double *d_gram, void *d_workspace, size_t workspace_bytes, void *stream) {
-  return gram_cross_entry("spr_gram_cross_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean,
-                          d_gram, d_workspace, workspace_bytes, stream);
+  SPR_REQUIRE(m > CMA && m <= 2 * CMA, SPR_E_INVALID, "spr_gram_cross_x32: m must be in (256, 512]");
+  return gram_cross_entry("spr_gram_cross_x32", d_X, n_rows, 0, CMA, m - CMA, m, ldx, row0, n_points, n_features, center,
+                          d_rowmean, d_gram, d_workspace, workspace_bytes, stream);
+}
+
+// any two column slices: A = [col_a, col_a + 256), B = [col_b, col_b + w_b) of rows that are ldx wide; the block
+// (col_a.., col_b..) and its mirror go into per-feature ldg x ldg matrices.  centre 0 / 2 (external means) only.
+extern "C" int spr_gram_cross_pair_f64(const double *d_X, int64_t n_rows, int32_t col_a, int32_t col_b, int32_t w_b,
+                                       int32_t ldg, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features,
+                                       int32_t center, double *d_rowmean, double *d_gram, void *d_workspace,
+                                       size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(center != 1, SPR_E_INVALID, "spr_gram_cross_pair_f64: centre mode 0 or 2");
+  return gram_cross_entry("spr_gram_cross_pair_f64", d_X, n_rows, col_a, col_b, w_b, ldg, ldx, row0, n_points, n_features,
+                          center, d_rowmean, d_gram, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int spr_gram_cross_pair_x32(const float *d_X, int64_t n_rows, int32_t col_a, int32_t col_b, int32_t w_b,
+                                       int32_t ldg, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features,
+                                       int32_t center, double *d_rowmean, double *d_gram, void *d_workspace,
+                                       size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(center != 1, SPR_E_INVALID, "spr_gram_cross_pair_x32: centre mode 0 or 2");
+  return gram_cross_entry("spr_gram_cross_pair_x32", d_X, n_rows, col_a, col_b, w_b, ldg, ldx, row0, n_points, n_features,
+                          center, d_rowmean, d_gram, d_workspace, workspace_bytes, stream);
 }

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
     const int64_t *__restrict__ indptr, const int64_t *__restrict__ indices, const double *__restrict__ vals,
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
     const double *__restrict__ rowmean, const double *__restrict__ scale, int64_t n_points, int n_features,
-    double *__restrict__ Theta, double *__restrict__ cnt, double *__restrict__ scl) {
+    double *__restrict__ Theta, int ldt, double *__restrict__ cnt, double *__restrict__ scl) {
   __shared__ double part[MS_WAVES][SPR_MAX_R + 2];
   const int row = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(MS_THREADS) void measure_csr_kernel(
   for (int k = threadIdx.x; k <= SPR_MAX_R + 1; k += MS_THREADS) {
     double s = 0.0;
     for (int w = 0; w < MS_WAVES; ++w) s += part[w][k];
-    if (k < r) Theta[(int64_t)row * r + k] = s;
+    if (k < r) Theta[(int64_t)row * ldt + k] = s;
     if (k == SPR_MAX_R) cnt[row] = s;
     if (k == SPR_MAX_R + 1 && scl) scl[row] = s;
   }
@@ -64,13 +64,16 @@ static int measure_entry(const char *who, const int64_t *d_indptr, const int64_t
               "%s: NULL pointer", who);
   SPR_REQUIRE(s > 0 && n_rows > 0 && r > 0 && ldu >= r && row0 >= 0, SPR_E_INVALID,
               "%s: bad shape s=%d n_rows=%lld r=%d", who, s, (long long)n_rows, r);
-  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "%s: r=%d > %d not built", who, r, SPR_MAX_R);
   SPR_REQUIRE(!d_scl || (d_scale && n_points > 0 && n_features > 0), SPR_E_INVALID,
               "%s: scl output needs the per-feature scale and layout", who);
-  hipLaunchKernelGGL(measure_csr_kernel<TU>, dim3(s), dim3(MS_THREADS), 0, static_cast<hipStream_t>(stream), d_indptr,
-                     d_indices, d_vals, d_Ur, n_rows, (int)r, ldu, row0, d_rowmean, d_scale, n_points, (int)n_features,
-                     d_Theta, d_cnt, d_scl);
-  SPR_LAUNCH_CHECK();
+  // 128 columns of Ur per launch; a wider basis goes in column groups (cnt / scl come out the same every time)
+  for (int g0 = 0; g0 < r; g0 += SPR_MAX_R) {
+    const int rg = (r - g0 < SPR_MAX_R) ? r - g0 : SPR_MAX_R;
+    hipLaunchKernelGGL(measure_csr_kernel<TU>, dim3(s), dim3(MS_THREADS), 0, static_cast<hipStream_t>(stream), d_indptr,
+                       d_indices, d_vals, d_Ur + g0, n_rows, rg, ldu, row0, d_rowmean, d_scale, n_points, (int)n_features,
+                       d_Theta + g0, (int)r, d_cnt, d_scl);
+    SPR_LAUNCH_CHECK();
+  }
   return SPR_OK;
 }
 

@@ -363,6 +363,111 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_direct_kernel(
   top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
 }
 
+// Refresh / init sweep for a basis wider than 128 columns (r <= SPR_MAX_R_WIDE; the reference pivots Ur^T for any r <= m,
+// :739): the register-direct form above with a RUN-TIME loop over the 16-column groups of a row -- eight groups (128
+// columns) of the wave's 16-row block are in registers at a time, the next eight are requested before these are
+// multiplied -- and the <= 16 directions in LDS instead of registers: image Ql[((g 4 + t) 4 + kk) 16 + li] =
+// Q[li][16 g + 4 kk + t], so the 64 lanes of a step read 64 consecutive doubles (conflict-free ds_read_b64).  Same row ->
+// wave -> lane assignment, arithmetic order per row and candidate lists as the other two forms.  VEC 0: any r / alignment
+// (scalar loads, columns >= r contribute zeros).
+template <int NGMAX, int VEC, typename TU, bool INIT>
+__global__ __launch_bounds__(QR_THREADS) void qr_refresh_wide_kernel(
+    const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
+    const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
+  constexpr int R = 64, SG = 8;                             // rows per workgroup step; groups per register batch
+  constexpr int SPW = INIT ? 16 : 4;
+  __shared__ double smem[2 * (QR_THREADS / 64) * SPW * QR_TOPT];
+  __shared__ double Ql[INIT ? 16 : NGMAX * 256];
+  double *const sval = smem;
+  long long *const sidx = reinterpret_cast<long long *>(smem + (QR_THREADS / 64) * SPW * QR_TOPT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kk = lane >> 4;
+  const int ng = (r + 15) / 16;
+  using P4 = typename std::conditional<std::is_same<TU, float>::value, float4, double4>::type;
+
+  if (!INIT) {
+    for (int e = threadIdx.x; e < ng * 256; e += QR_THREADS) {
+      const int j = e & 15, k4 = (e >> 4) & 3, t = (e >> 6) & 3, g = e >> 8;
+      const int k = 16 * g + 4 * k4 + t;
+      Ql[e] = (j < nq && k < r) ? Q[(int64_t)j * r + k] : 0.0;
+    }
+    __syncthreads();
+  }
+  TopList top;
+  top.init();
+  const int64_t npanels = (n_rows + R - 1) / R;
+  auto load_batch = [&](const TU *rp, int g0, P4 (&dst)[SG]) {
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      const int g = g0 + u < ng ? g0 + u : ng - 1;          // past the last group: a harmless re-read, never multiplied
+      const int c0 = 16 * g + 4 * kk;
+      if (VEC) {
+        dst[u] = *reinterpret_cast<const P4 *>(rp + c0);
+      } else {
+        dst[u].x = c0 < r ? rp[c0] : (TU)0;         dst[u].y = c0 + 1 < r ? rp[c0 + 1] : (TU)0;
+        dst[u].z = c0 + 2 < r ? rp[c0 + 2] : (TU)0; dst[u].w = c0 + 3 < r ? rp[c0 + 3] : (TU)0;
+      }
+    }
+  };
+  for (int64_t c = blockIdx.x; c < npanels; c += gridDim.x) {
+    int64_t row = c * R + wave * 16 + li;
+    row = row < n_rows ? row : n_rows - 1;                  // rows past the end re-read the last row; never stored
+    const TU *rp = Ur + row * ldu;
+    const int64_t brow = c * R + wave * 16 + kk;            // this lane's first output row of the block
+    double old[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t rr = brow + 4 * i;
+      old[i] = INIT ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];
+    }
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    P4 cur[SG], nxt[SG];
+    load_batch(rp, 0, cur);
+    for (int g0 = 0; g0 < ng; g0 += SG) {
+      load_batch(rp, g0 + SG, nxt);
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        if (g0 + u < ng) {                                  // wave-uniform
+          const double a4[4] = {(double)cur[u].x, (double)cur[u].y, (double)cur[u].z, (double)cur[u].w};
+          const double *ql = Ql + (int64_t)(g0 + u) * 256 + kk * 16 + li;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], INIT ? a4[t] : ql[64 * t], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SG; ++u) cur[u] = nxt[u];
+    }
+    if (INIT) {
+      const double dv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rr = brow + 4 * i;
+        const bool mine = (li == kk + 4 * i) && (rr < n_rows);
+        if (mine) nrm[rr] = dv[i];
+        top.insert(dv[i], row0 + rr, mine);
+      }
+    } else {
+      const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
+                            group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rr = brow + 4 * i;
+        const bool mine = (li == 0) && (rr < n_rows);
+        double v = old[i] - d2[i];
+        v = v < 0.0 ? 0.0 : v;
+        v = old[i] < 0.0 ? -1.0 : v;
+        if (mine) nrm[rr] = v;
+        top.insert(v, row0 + rr, mine);
+      }
+    }
+  }
+  const bool owner = INIT ? ((li & 3) == kk) : (li == 0);
+  const int slot = INIT ? (kk * 4 + (li >> 2)) : kk;
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
+}
+
 // grid = sweep blocks: copy each block's top rows into the compact candidate arrays
 template <typename TU>
 __global__ __launch_bounds__(QR_THREADS) void qr_gather_kernel(
@@ -442,7 +547,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
     const double *__restrict__ recs, int n_rec, const double *__restrict__ taus, int n_tau, int first, int r,
     int step, double *__restrict__ Q, int64_t *__restrict__ piv, double *__restrict__ gap,
     double *__restrict__ okflag) {
-  __shared__ double v[SPR_MAX_R], c[SPR_MAX_R];
+  __shared__ double v[SPR_MAX_R_WIDE], c[SPR_MAX_R_WIDE];
   __shared__ double red[QR_THREADS / 64];
   __shared__ int win;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -534,6 +639,33 @@ __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
   }
 }
 
+// the same for rows longer than 128 entries: 64 lanes per row, each walks its column pairs
+__global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_wide_kernel(
+    const double *__restrict__ cand_U, int n_cand, int r, int ldc, const int64_t *__restrict__ cand_idx,
+    const double *__restrict__ q, const int64_t *__restrict__ piv_ptr, double *__restrict__ cand_res,
+    const double *__restrict__ xyz, int dim, int64_t n_points, double d_min) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t piv = *piv_ptr;
+  double pc[3] = {0.0, 0.0, 0.0};
+  if (xyz)
+    for (int d = 0; d < dim; ++d) pc[d] = xyz[(piv % n_points) * dim + d];
+  for (int c = blockIdx.x * (QR_THREADS / 64) + wave; c < n_cand; c += gridDim.x * (QR_THREADS / 64)) {
+    const double *u = cand_U + (int64_t)c * ldc;
+    double d = 0.0;
+    for (int k = lane; k < r; k += 64) d += u[k] * q[k];
+    d = group_sum_t<64>(d);
+    if (lane == 0) {
+      const double old = cand_res[c];
+      double v = old - d * d;
+      v = v < 0.0 ? 0.0 : v;
+      if (old < 0.0) v = old;
+      if (cand_idx[c] == piv) v = -1.0;
+      if (xyz && within(xyz + (cand_idx[c] % n_points) * dim, pc, dim, d_min)) v = -1.0;
+      cand_res[c] = v;
+    }
+  }
+}
+
 __global__ void qr_mark_kernel(const int64_t *__restrict__ piv, int n, int64_t row0, int64_t n_rows,
                                double *__restrict__ nrm) {
   const int t = threadIdx.x;
@@ -594,21 +726,23 @@ int sweep_grid(int64_t n_rows) {
   return (int)(steps < cap ? steps : cap);
 }
 
-// workspace carve-up
+// workspace carve-up (the candidate rows are as wide as the basis: at least SPR_MAX_R columns are always reserved, so the
+// layout for r <= 128 is the one spr_qr_workspace() has always described)
 struct QrWs {
   double *tops;       // [QR_MAX_BLOCKS][QR_TOPT][2]
   int64_t *cand_idx;  // [NC]
   double *cand_res;   // [NC]
-  double *cand_U;     // [NC][<= SPR_MAX_R]
+  double *cand_U;     // [NC][max(r + (r & 1), SPR_MAX_R)]
   double *tau;        // [1]
   static constexpr int64_t NC = (int64_t)QR_MAX_BLOCKS * QR_TOPT;
-  static size_t bytes() { return sizeof(double) * ((size_t)NC * 2 + NC * 2 + NC * SPR_MAX_R + 8); }
-  explicit QrWs(void *p) {
+  static int64_t width(int r) { const int w = r + (r & 1); return w > SPR_MAX_R ? w : SPR_MAX_R; }
+  static size_t bytes(int r) { return sizeof(double) * ((size_t)NC * 2 + NC * 2 + NC * width(r) + 8); }
+  QrWs(void *p, int r) {
     double *d = static_cast<double *>(p);
     tops = d; d += NC * 2;
     cand_idx = reinterpret_cast<int64_t *>(d); d += NC;
     cand_res = d; d += NC;
-    cand_U = d; d += NC * SPR_MAX_R;
+    cand_U = d; d += NC * width(r);
     tau = d;
   }
 };
@@ -616,6 +750,19 @@ struct QrWs {
 template <typename TU, bool INIT>
 int launch_refresh(int grid, hipStream_t st, const TU *Ur, int64_t n_rows, int r, int64_t ldu, int vec_ok, int64_t row0,
                    const double *Qj, int nq, double *nrm, double *tops) {
+  if (r > SPR_MAX_R) {
+    const bool vec = (r % 16 == 0) && ((ldu * sizeof(TU)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(Ur) & 15) == 0);
+#define RW(NG, V) hipLaunchKernelGGL((qr_refresh_wide_kernel<NG, V, TU, INIT>), dim3(grid), dim3(QR_THREADS), 0, st, Ur, n_rows, r, ldu, row0, Qj, nq, nrm, tops)
+#define RWV(NG) do { if (vec) RW(NG, 1); else RW(NG, 0); } while (0)
+    if (INIT) RWV(16);                                        // no direction image in LDS: one instantiation serves all r
+    else if (r <= 256) RWV(16);
+    else if (r <= 512) RWV(32);
+    else RWV(64);
+#undef RWV
+#undef RW
+    SPR_LAUNCH_CHECK();
+    return SPR_OK;
+  }
   const int mtr = spr_round_mt(r);      // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
   const int lm = vec_ok ? ((r == 16 * mtr) ? 2 : 1) : 0;
   // register-direct form: whole 16-column groups, 16-byte aligned pieces (SPR_QR_DIRECT=0 keeps the LDS-panel form)
@@ -660,7 +807,7 @@ int check_ur(const char *who, const void *Ur, int64_t n_rows, int32_t r, int64_t
   SPR_REQUIRE(Ur != nullptr, SPR_E_INVALID, "%s: Ur is NULL", who);
   SPR_REQUIRE(n_rows > 0 && r > 0 && ldu >= r, SPR_E_INVALID, "%s: bad shape n_rows=%lld r=%d ldu=%lld", who,
               (long long)n_rows, r, (long long)ldu);
-  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "%s: r=%d > %d not built", who, r, SPR_MAX_R);
+  SPR_REQUIRE(r <= SPR_MAX_R_WIDE, SPR_E_UNSUPPORTED, "%s: r=%d > %d not built", who, r, SPR_MAX_R_WIDE);
   return SPR_OK;
 }
 
@@ -682,7 +829,12 @@ int build_candidates(const QrWs &w, int grid, const TU *Ur, int64_t n_rows, int 
 
 extern "C" size_t spr_qr_workspace(int64_t n_rows) {
   (void)n_rows;
-  return QrWs::bytes();
+  return QrWs::bytes(SPR_MAX_R);
+}
+
+extern "C" size_t spr_qr_workspace_r(int64_t n_rows, int32_t r) {
+  (void)n_rows;
+  return (r > 0 && r <= SPR_MAX_R_WIDE) ? QrWs::bytes(r) : 0;
 }
 
 extern "C" int32_t spr_qr_batch(void) { return QR_BATCH; }
@@ -719,11 +871,11 @@ static int qr_init_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_
   int rc = check_ur(who, d_Ur, n_rows, r, ldu);
   if (rc != SPR_OK) return rc;
   SPR_REQUIRE(d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
-  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "%s: workspace too small", who);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(r), SPR_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = sweep_grid(n_rows);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
-  QrWs w(d_workspace);
+  QrWs w(d_workspace, r);
   rc = launch_refresh<TU, true>(grid, st, d_Ur, n_rows, r, ldu, vec_ok, row0, nullptr, 0, d_nrm, w.tops);
   if (rc != SPR_OK) return rc;
   return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
@@ -752,11 +904,11 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
               "spr_qr_step_f64: NULL pointer");
   SPR_REQUIRE(!d_xyz || (xyz_dim >= 1 && xyz_dim <= 3 && n_points > 0), SPR_E_INVALID,
               "spr_qr_step_f64: xyz needs 1..3 columns and n_points > 0");
-  SPR_REQUIRE(n_rows > 0 && r > 0 && r <= SPR_MAX_R && step >= 0 && step < r && n_rec >= 1 && n_tau >= 1,
+  SPR_REQUIRE(n_rows > 0 && r > 0 && r <= SPR_MAX_R_WIDE && step >= 0 && step < r && n_rec >= 1 && n_tau >= 1,
               SPR_E_INVALID, "spr_qr_step_f64: bad r=%d step=%d n_rec=%d", r, step, n_rec);
-  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "spr_qr_step_f64: workspace too small");
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(r), SPR_E_WORKSPACE, "spr_qr_step_f64: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  QrWs w(d_workspace);
+  QrWs w(d_workspace, r);
   const int lpr = pick_lpr(r);
   const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows) * QR_TOPT;
   hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_recs, (int)n_rec, d_taus, (int)n_tau,
@@ -765,6 +917,17 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   const int rows_per_block = (QR_THREADS / 64) * (64 / lpr);
   int grid = (n_cand + rows_per_block - 1) / rows_per_block;
   if (grid > 256) grid = 256;
+  if (r > SPR_MAX_R) {
+    int gw = (n_cand + QR_THREADS / 64 - 1) / (QR_THREADS / 64);
+    if (gw > 1024) gw = 1024;
+    hipLaunchKernelGGL(qr_cand_downdate_wide_kernel, dim3(gw), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc,
+                       w.cand_idx, d_Q + (int64_t)step * r, d_piv + step, w.cand_res, d_xyz, (int)xyz_dim, n_points, d_min);
+    SPR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, (const double *)nullptr, 0, w.cand_idx,
+                       w.cand_res, w.cand_U, n_cand, (int)r, ldc, (double *)nullptr, d_rec);
+    SPR_LAUNCH_CHECK();
+    return SPR_OK;
+  }
 #define CD(L) hipLaunchKernelGGL(qr_cand_downdate_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q + (int64_t)step * r, d_piv + step, w.cand_res, d_xyz, (int)xyz_dim, n_points, d_min); break
   switch (lpr) {
     case 1: CD(1);
@@ -824,11 +987,11 @@ static int qr_refresh_entry(const char *who, const TU *d_Ur, int64_t n_rows, int
   if (rc != SPR_OK) return rc;
   SPR_REQUIRE(d_Q && d_piv && d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(j0 >= 0 && nq >= 1 && nq <= QR_BATCH && j0 + nq <= r, SPR_E_INVALID, "%s: bad j0=%d nq=%d", who, j0, nq);
-  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(), SPR_E_WORKSPACE, "%s: workspace too small", who);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(r), SPR_E_WORKSPACE, "%s: workspace too small", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = sweep_grid(n_rows);
   const int vec_ok = (r % 2 == 0) && (ldu % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Ur) & (2 * sizeof(TU) - 1)) == 0);
-  QrWs w(d_workspace);
+  QrWs w(d_workspace, r);
   hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + j0, (int)nq, row0, n_rows, d_nrm);
   SPR_LAUNCH_CHECK();
   rc = launch_refresh<TU, false>(grid, st, d_Ur, n_rows, (int)r, ldu, vec_ok, row0, d_Q + (int64_t)j0 * r, (int)nq, d_nrm, w.tops);

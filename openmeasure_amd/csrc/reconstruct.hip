@@ -29,8 +29,8 @@ constexpr int RM_PB = 16;   // coefficient vectors per pass (one MFMA tile of ro
 template <int MTR, int VEC, typename TU>
 __global__ __launch_bounds__(RM_THREADS) void reconstruct_mfma_kernel(
     const TU *__restrict__ Ur, int r, int64_t ldu, SegPlan plan, const double *__restrict__ rowmean,
-    const double *__restrict__ scale, const double *__restrict__ rowscale, const double *__restrict__ A, int np0,
-    int npb, double *__restrict__ out, int64_t ldo) {
+    const double *__restrict__ scale, const double *__restrict__ rowscale, const double *__restrict__ A, int64_t lda,
+    int np0, int npb, double *__restrict__ out, int64_t ldo, int accumulate) {
   constexpr int NW = RM_THREADS / 64, R = 64;
   constexpr int MPAD = 16 * MTR, MP = MPAD + 2, KSTEPS = MPAD / 4;
   using RT = RowTile<MTR, R, MP, NW, 16, TU>;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(RM_THREADS) void reconstruct_mfma_kernel(
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     const int k = 4 * ks + (lane >> 4), j = lane & 15;
-    vfrag[ks] = (j < npb && k < r) ? A[(int64_t)(np0 + j) * r + k] : 0.0;
+    vfrag[ks] = (j < npb && k < r) ? A[(int64_t)(np0 + j) * lda + k] : 0.0;
   }
   RT tile;
   const int64_t npanels = (hi - lo + R - 1) / R;
@@ -88,7 +88,11 @@ __global__ __launch_bounds__(RM_THREADS) void reconstruct_mfma_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int pv = 4 * q + (lane >> 4);
-      if (pv < npb && row < hi) out[(int64_t)(np0 + pv) * ldo + row] = rs * d[q] + mu;
+      if (pv < npb && row < hi) {
+        // accumulate: a further column group of a basis wider than one launch handles -- the centre is already in
+        double *o = out + (int64_t)(np0 + pv) * ldo + row;
+        *o = rs * d[q] + (accumulate ? *o : mu);
+      }
     }
     buf ^= 1;
     c = cn;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(RM_THREADS) void reconstruct_mfma_kernel(
 template <int MTR, typename TU>
 int launch_mfma(const TU *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0, int64_t n_points,
                 int32_t n_features, const double *rowmean, const double *scale, const double *rowscale,
-                const double *A, int32_t n_p, double *out, int64_t ldo, hipStream_t st) {
+                const double *A, int64_t lda, int32_t n_p, double *out, int64_t ldo, int accumulate, hipStream_t st) {
   const int cus = spr_cached_cus();
   SegPlan plan;
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
@@ -113,7 +117,7 @@ int launch_mfma(const TU *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t ro
   const int lm = vec_ok ? ((r == 16 * MTR) ? 2 : 1) : 0;
   for (int p0 = 0; p0 < n_p; p0 += RM_PB) {
     const int npb = (n_p - p0 < RM_PB) ? n_p - p0 : RM_PB;
-#define RM(LM) hipLaunchKernelGGL((reconstruct_mfma_kernel<MTR, LM, TU>), dim3(grid), dim3(RM_THREADS), 0, st, Ur, (int)r, ldu, plan, rowmean, scale, rowscale, A, p0, npb, out, ldo)
+#define RM(LM) hipLaunchKernelGGL((reconstruct_mfma_kernel<MTR, LM, TU>), dim3(grid), dim3(RM_THREADS), 0, st, Ur, (int)r, ldu, plan, rowmean, scale, rowscale, A, lda, p0, npb, out, ldo, accumulate)
     if (lm == 2) RM(2);
     else if (lm == 1) RM(1);
     else RM(0);
@@ -208,6 +212,29 @@ int launch(const double *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row
   return SPR_OK;
 }
 
+// r <= 128 per launch; a wider basis (r <= m in the reference, :336) goes in column groups of 128 that accumulate
+template <typename TU>
+int reconstruct_groups(const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0, int64_t n_points,
+                       int32_t n_features, const double *d_rowmean, const double *d_scale, const double *d_rowscale,
+                       const double *d_A, int32_t n_p, double *d_Xrec, int64_t ldo, hipStream_t st) {
+  for (int g0 = 0; g0 < r; g0 += SPR_MAX_R) {
+    const int rg = (r - g0 < SPR_MAX_R) ? r - g0 : SPR_MAX_R;
+    int rc = SPR_OK;
+#define RMF(MTV) rc = launch_mfma<MTV, TU>(d_Ur + g0, n_rows, rg, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A + g0, r, n_p, d_Xrec, ldo, g0 > 0, st); break
+    switch (spr_round_mt(rg)) {      // padded width of the group in 16-column tiles
+      case 1: RMF(1);
+      case 2: RMF(2);
+      case 3: RMF(3);
+      case 4: RMF(4);
+      case 6: RMF(6);
+      default: RMF(8);
+    }
+#undef RMF
+    if (rc != SPR_OK) return rc;
+  }
+  return SPR_OK;
+}
+
 }  // namespace
 
 extern "C" int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
@@ -221,20 +248,10 @@ extern "C" int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r
   SPR_REQUIRE(n_points > 0 && n_features > 0 && row0 >= 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
               SPR_E_INVALID, "spr_reconstruct_f64: bad feature layout");
-  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_reconstruct_f64: r=%d > %d not built", r, SPR_MAX_R);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (!SPR_RECONSTRUCT_VALU) {
-#define RMF(MTV) return launch_mfma<MTV, double>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
-    switch (spr_round_mt(r)) {       // padded width of Ur in 16-column tiles (r <= 128 -> <= 8)
-      case 1: RMF(1);
-      case 2: RMF(2);
-      case 3: RMF(3);
-      case 4: RMF(4);
-      case 6: RMF(6);
-      default: RMF(8);
-    }
-#undef RMF
-  }
+  if (!SPR_RECONSTRUCT_VALU || r > SPR_MAX_R)
+    return reconstruct_groups<double>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale,
+                                      d_A, n_p, d_Xrec, ldo, st);
   const int half = (r + 1) / 2;
 #define RC(L) return launch<L>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
   if (half <= 1) RC(1);
@@ -259,16 +276,6 @@ extern "C" int spr_reconstruct_u32(const float *d_Ur, int64_t n_rows, int32_t r,
   SPR_REQUIRE(n_points > 0 && n_features > 0 && row0 >= 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
               SPR_E_INVALID, "spr_reconstruct_u32: bad feature layout");
-  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "spr_reconstruct_u32: r=%d > %d not built", r, SPR_MAX_R);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-#define RMF(MTV) return launch_mfma<MTV, float>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A, n_p, d_Xrec, ldo, st)
-  switch (spr_round_mt(r)) {
-    case 1: RMF(1);
-    case 2: RMF(2);
-    case 3: RMF(3);
-    case 4: RMF(4);
-    case 6: RMF(6);
-    default: RMF(8);
-  }
-#undef RMF
+  return reconstruct_groups<float>(d_Ur, n_rows, r, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A,
+                                   n_p, d_Xrec, ldo, static_cast<hipStream_t>(stream));
 }

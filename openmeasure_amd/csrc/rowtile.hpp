@@ -80,9 +80,12 @@ struct RowTile {
   // VEC 0: any layout (8-byte loads); 1: rows 16-byte aligned, m even; 2: additionally m == 16*MT
   // (no column clamp, constant offsets).  Rows >= seg_hi re-read the last valid row
   // and columns >= m re-read column 0; center_store_pass discards both.
+  // split / gap: panel columns >= split come from `gap` elements further along the row -- a panel made of two column
+  // slices of a wider matrix that are not adjacent (the off-diagonal Gram blocks of m > 512, gram_wide.hip).
   template <int VEC>
   __device__ inline void load_pass(int it, const TX *__restrict__ X, int64_t ldx, int m, int64_t crow0,
-                                   int64_t seg_hi, int wave, int lane, const double *__restrict__ mean_in = nullptr) {
+                                   int64_t seg_hi, int wave, int lane, const double *__restrict__ mean_in = nullptr,
+                                   int split = 1 << 30, int64_t gap = 0) {
     const int grp = lane / LPR, lig = lane % LPR;
     int64_t lrow = crow0 + it * ROWS_PER_IT + wave * RPW + grp;
     lrow = lrow < seg_hi ? lrow : seg_hi - 1;
@@ -91,14 +94,15 @@ struct RowTile {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int col = 2 * (lig + v * LPR);
+      const int64_t g0 = col >= split ? gap : 0, g1 = col + 1 >= split ? gap : 0;
       Piece t;
       if (VEC == 2) {
-        t = *reinterpret_cast<const Piece *>(rp + col);               // m == MPAD: constant offsets
+        t = *reinterpret_cast<const Piece *>(rp + col + g0);          // m == MPAD: constant offsets
       } else if (VEC == 1) {
-        t = *reinterpret_cast<const Piece *>(rp + (col < m ? col : 0));
+        t = *reinterpret_cast<const Piece *>(rp + (col < m ? col + g0 : 0));
       } else {
-        t.x = rp[col < m ? col : 0];
-        t.y = rp[col + 1 < m ? col + 1 : 0];
+        t.x = rp[col < m ? col + g0 : 0];
+        t.y = rp[col + 1 < m ? col + 1 + g1 : 0];
       }
       pre[it][v] = t;
     }
@@ -149,9 +153,10 @@ struct RowTile {
 
   template <int VEC>
   __device__ inline void load(const TX *__restrict__ X, int64_t ldx, int m, int64_t crow0, int64_t seg_hi,
-                              int wave, int lane, const double *__restrict__ mean_in = nullptr) {
+                              int wave, int lane, const double *__restrict__ mean_in = nullptr, int split = 1 << 30,
+                              int64_t gap = 0) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) load_pass<VEC>(it, X, ldx, m, crow0, seg_hi, wave, lane, mean_in);
+    for (int it = 0; it < IT; ++it) load_pass<VEC>(it, X, ldx, m, crow0, seg_hi, wave, lane, mean_in, split, gap);
   }
 
   // one pass of mean -> centre -> LDS; optionally stores the row means and feeds the running

@@ -154,8 +154,6 @@ class HipEngine:
         fstats = self.empty((n_features, 3))
         gram = self.empty((n_features, m, m))
         nbytes = self.lib.spr_stats_gram_workspace(m, n_features)
-        if nbytes == 0:
-            raise NotImplementedError(f'stats_gram: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
         ws = self._workspace('gram', nbytes)
         tic, toc = self._timed('stats_gram')
         tic()
@@ -169,11 +167,12 @@ class HipEngine:
         return rowmean, fstats, gram
 
     def _stats_gram_wide(self, X, row0, n_points, n_features, center):
-        """256 < m <= 512: row means of the full rows first, then A^T A, B^T B (column slices of the symmetric
-        kernel with external means) and A^T B (cross kernel) into one (F, m, m) result -- see spr_hip.h."""
+        """m > 256: the columns go in slices of 256.  Two slices (m <= 512): A^T B first (cross kernel, which forms the
+        means of the full rows itself), then A^T A, B^T B (symmetric kernel on column slices with external means).
+        More slices: a row-statistics pass, then every diagonal block and every slice pair -- see spr_hip.h."""
         n, m, ld = self._check_matrix(X)
         if m > _lib.SPR_MAX_M_WIDE:
-            raise NotImplementedError(f'stats_gram: m={m} outside the built range (1..{_lib.SPR_MAX_M_WIDE})')
+            return self._stats_gram_slices(X, row0, n_points, n_features, center)
         F, mA, st = n_features, _lib.SPR_MAX_M, self._stream()
         mB = m - mA
         fstats = self.zeros((F, 3))
@@ -205,6 +204,44 @@ class HipEngine:
             _lib.check(self.lib.spr_stats_gram_finalize_f64(n, width, row0, n_points, F, _ptr(ws), ws.numel(),
                                                             _ptr(scratch), _ptr(gram), m, origin, st),
                        'spr_stats_gram_finalize_f64')
+        toc()
+        return rowmean, fstats, gram
+
+    def _stats_gram_slices(self, X, row0, n_points, n_features, center):
+        """m > 512: q = ceil(m / 256) column slices -- one row-statistics pass (means of the full rows), q symmetric
+        launches (diagonal blocks) and q (q - 1) / 2 slice-pair launches, all with external means."""
+        n, m, ld = self._check_matrix(X)
+        F, W, st = n_features, _lib.SPR_MAX_M, self._stream()
+        esz = X.element_size()
+        gram = self.empty((F, m, m))
+        tic, toc = self._timed('stats_gram')
+        tic()
+        if center:
+            rowmean, fstats = self.empty((n,)), self.empty((F, 3))
+            ws = self._workspace('rowstats', self.lib.spr_rowstats_workspace(F))
+            _lib.check(self._x('spr_rowstats', X)(_ptr(X), n, m, ld, row0, n_points, F, _ptr(rowmean), _ptr(fstats),
+                                                 _ptr(ws), ws.numel(), st), 'spr_rowstats_f64')
+        else:
+            rowmean, fstats = self.zeros((n,)), self.zeros((F, 3))
+        mode = 2 if center else 0
+        scratch = self.empty((F, 3))
+        slices = [(o, min(W, m - o)) for o in range(0, m, W)]
+        for origin, width in slices:
+            ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(width, F))
+            _lib.check(self._x('spr_stats_gram', X)(X.data_ptr() + origin * esz, n, width, ld, row0, n_points, F, mode,
+                                                   _ptr(rowmean), _ptr(ws), ws.numel(), st), 'spr_stats_gram_f64')
+            _lib.check(self.lib.spr_stats_gram_finalize_f64(n, width, row0, n_points, F, _ptr(ws), ws.numel(),
+                                                            _ptr(scratch), _ptr(gram), m, origin, st),
+                       'spr_stats_gram_finalize_f64')
+        wsx = self._workspace('cross', self.lib.spr_gram_cross_workspace(2 * W, F))
+        for i, (oa, _) in enumerate(slices):
+            for ob, wb in slices[i + 1:]:
+                _lib.check(self._x('spr_gram_cross_pair', X)(_ptr(X), n, oa, ob, wb, m, ld, row0, n_points, F, mode,
+                                                            _ptr(rowmean), _ptr(gram), _ptr(wsx), wsx.numel(), st),
+                           'spr_gram_cross_pair_f64')
+        if not center:
+            # un-centred statistics are not used by any caller (decomposition(X0) takes the Gram matrix only)
+            fstats.zero_()
         toc()
         return rowmean, fstats, gram
 
@@ -405,12 +442,14 @@ class HipEngine:
     def qr_begin(self, Ur, row0, n_steps):
         """Allocate the pivoting state; initial norms, candidate set, local record and tau."""
         n, r, ldu = self._check_matrix(Ur)
+        if r > _lib.SPR_MAX_R_WIDE:
+            raise NotImplementedError(f'placement: r={r} modes exceed the built range (1..{_lib.SPR_MAX_R_WIDE})')
         t = self.torch
         st = dict(Ur=Ur, n=n, r=r, ldu=ldu, row0=row0,
                   nrm=self.empty((n,)), rec=self.empty((r + 3,)), tau=self.empty((1,)),
                   Q=self.zeros((n_steps, r)), piv=self.zeros((n_steps,), dtype=t.int64),
                   gap=self.zeros((n_steps,)), ok=self.zeros((n_steps,)),
-                  ws=self._workspace('qr', self.lib.spr_qr_workspace(n)))
+                  ws=self._workspace('qr', self.lib.spr_qr_workspace_r(n, r)))
         _lib.check(self._u('spr_qr_init', Ur)(_ptr(Ur), n, r, ldu, row0, _ptr(st['nrm']), _ptr(st['rec']),
                                             _ptr(st['tau']), _ptr(st['ws']), st['ws'].numel(), self._stream()),
                    'spr_qr_init_f64')
@@ -477,6 +516,8 @@ class HipEngine:
         return (Theta, cnt) if scale is None else (Theta, cnt, scl)
 
     # ---- K8 + K9 -------------------------------------------------------------------------------
+    ols_max_r = _lib.SPR_MAX_R
+
     def solve_ols(self, Theta, cnt, scale, y):
         """y: (n_p, s, 3) device tensor. -> Ar (n_p,r), Ar_sigma (n_p,r), y0 (n_p,s,2), info (n_p,2)."""
         s, r = Theta.shape
@@ -499,6 +540,15 @@ class HipEngine:
         Ar_sigma = self.empty((n_p, r))
         y0 = self.empty((n_p, s, 2))
         info = self.empty((n_p, 4))
+        if r > _lib.SPR_MAX_R:                                # factor in a workspace instead of LDS
+            if r > _lib.SPR_MAX_R_WIDE:
+                raise NotImplementedError(f'solve: r={r} modes exceed the built range (1..{_lib.SPR_MAX_R_WIDE})')
+            ws = self._workspace('pinv', self.lib.spr_solve_pinv_workspace(r, n_p))
+            _lib.check(self.lib.spr_solve_pinv_wide_f64(_ptr(Theta.contiguous()), s, r, _ptr(cnt), cnt.shape[0],
+                                                        _ptr(scale), scale.shape[0], _ptr(y.contiguous()), n_p,
+                                                        float(rcond), _ptr(Ar), _ptr(Ar_sigma), _ptr(y0), _ptr(info),
+                                                        _ptr(ws), ws.numel(), self._stream()), 'spr_solve_pinv_wide_f64')
+            return Ar, Ar_sigma, y0, info
         _lib.check(self.lib.spr_solve_pinv_f64(_ptr(Theta.contiguous()), s, r, _ptr(cnt), cnt.shape[0], _ptr(scale),
                                                scale.shape[0], _ptr(y.contiguous()), n_p, float(rcond), _ptr(Ar),
                                                _ptr(Ar_sigma), _ptr(y0), _ptr(info), self._stream()),

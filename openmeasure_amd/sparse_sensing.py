@@ -1183,7 +1183,7 @@ class SPR(ROM):
             Yh[:, :, 2] = np.where(fid < 0, fid + self.n_features, fid)
         Y = eng.to_device(Yh)
         s, r = Theta_d.shape
-        if s >= r:
+        if s >= r and r <= getattr(eng, 'ols_max_r', r):      # the normal-equations kernel keeps its factor in LDS
             Ar_d, As_d, y0_d, info_d = eng.solve_ols(Theta_d, cnt_d, self._d['scale'], Y)
             info = eng.to_host(info_d)
             # the kernel's refinement step (corrected semi-normal equations) is as accurate as a QR solve while

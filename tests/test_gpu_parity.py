@@ -172,6 +172,7 @@ def test_upload_download_staging(eng):
     (10, 2, 5), (333, 3, 7), (257, 1, 16), (1000, 3, 33), (4099, 2, 48), (700, 4, 64),
     (513, 2, 80), (1200, 3, 128), (640, 2, 190), (900, 9, 256), (31, 1, 256),
     (400, 2, 257), (333, 3, 300), (500, 2, 384), (450, 4, 511), (260, 16, 512),
+    (300, 2, 513), (260, 3, 600), (200, 2, 1024), (150, 1, 1100),      # slice pairs (csrc/gram_wide.hip, any m)
 ])
 def test_stats_gram_vs_oracle(eng, n_points, F, m):
     X = synth_host(n_points, F, m, min(m, 12), 0.8, 1e-3, 1000 + m)
@@ -336,7 +337,8 @@ def test_project_precentred_large_means(eng):
     assert 1e-12 < e_epi < 1e-7, e_epi                         # the cancellation the pre-centred form avoids
 
 
-@pytest.mark.parametrize('n,r,n_p', [(20, 5, 1), (999, 5, 3), (4096, 32, 1), (5000, 64, 5), (3001, 128, 2), (777, 1, 1), (1234, 14, 2)])
+@pytest.mark.parametrize('n,r,n_p', [(20, 5, 1), (999, 5, 3), (4096, 32, 1), (5000, 64, 5), (3001, 128, 2), (777, 1, 1), (1234, 14, 2),
+                                     (2000, 129, 2), (1500, 300, 3), (900, 513, 1)])
 def test_reconstruct_vs_oracle(eng, n, r, n_p):
     rng = np.random.default_rng(n + r)
     F = 1 if n % 3 else 3
@@ -421,7 +423,8 @@ def test_duplicate_rows_tie_goes_to_lowest_index(eng):
     np.testing.assert_array_equal(piv, ref)
 
 
-@pytest.mark.parametrize('n,r,seed', [(200000, 32, 1), (50000, 64, 2), (3000, 14, 3), (700000, 8, 4)])
+@pytest.mark.parametrize('n,r,seed', [(200000, 32, 1), (50000, 64, 2), (3000, 14, 3), (700000, 8, 4),
+                                      (20000, 200, 5), (9000, 300, 6), (6000, 131, 7), (5000, 512, 8)])
 def test_pivots_candidate_set_vs_oracle(eng, n, r, seed):
     """orthonormal random basis: row norms are nearly uniform, so the candidate bound is tight and
     certification fails often -- the batches must still reproduce dgeqp3's order exactly"""
@@ -522,7 +525,8 @@ def _identity_problem(Theta, ys):
 
 
 @pytest.mark.parametrize('s_,r,rank', [(5, 12, 5), (12, 12, 9), (40, 17, 11), (200, 33, 33), (70, 64, 40), (300, 128, 100),
-                                      (130, 128, 128), (3, 128, 3), (1, 4, 1), (9, 1, 1)])
+                                      (130, 128, 128), (3, 128, 3), (1, 4, 1), (9, 1, 1),
+                                      (150, 200, 150), (200, 200, 160), (450, 300, 300), (300, 300, 300), (40, 513, 33)])
 def test_pinv_kernel_vs_oracle(eng, s_, r, rank):
     """spr_solve_pinv_f64 against np.linalg.pinv on random systems of prescribed rank (exact low rank through a
     product of thin factors; s < r, s = r, s > r; all four r classes of the kernel), weighted and unweighted."""
@@ -750,14 +754,10 @@ def test_kernels_on_row_shards(eng, n_points, F, m, r, world):
 
 @pytest.mark.parametrize('n_points,F,m,r', [(1, 1, 2, 1), (3, 2, 2, 2), (17, 1, 1, 1), (5, 3, 300, 2), (5, 3, 600, 2)])
 def test_tiny_and_out_of_range_shapes(eng, n_points, F, m, r):
-    """shapes far below one panel / one workgroup, and m beyond the built range (must fail loudly)"""
+    """shapes far below one panel / one workgroup, narrow and wide (slice pairs for m > 512: nothing is refused)"""
     rng = np.random.default_rng(n_points + m)
     X = rng.standard_normal((n_points * F, m)) + 3.0
     Xd = eng.to_device(X)
-    if m > 512:
-        with pytest.raises(NotImplementedError):
-            eng.stats_gram(Xd, 0, n_points, F)
-        return
     rowmean, fstats, gram = eng.stats_gram(Xd, 0, n_points, F)
     np.testing.assert_allclose(eng.to_host(rowmean), X.mean(axis=1), rtol=1e-14)
     c = X - X.mean(axis=1, keepdims=True)
@@ -896,3 +896,64 @@ def test_option_matrix_vs_oracle(eng, dtype, scale_type, axis_cnt, n_points, F, 
     Ur_ref = st['Ur'] * sg
     A_ref, _ = orc.predict_ols([y], orc.train_theta(Cd, Ur_ref, n), Cd, st['X_cnt'], st['X_scl'], n_points)
     assert rel_fro(x_rec, orc.reconstruct(A_ref, Ur_ref, st['X_cnt'], st['X_scl'])) <= REL_FRO
+
+
+@pytest.mark.parametrize('n_points,F,m,select,n_modes,k', [(500, 3, 600, 'number', 40, 80), (400, 2, 300, 'number', 200, 200),
+                                                         (300, 2, 1024, 'number', 16, 32), (260, 2, 520, 'variance', 99.9, 24)])
+def test_wide_shapes_end_to_end_vs_oracle(eng, n_points, F, m, select, n_modes, k):
+    """Shapes beyond one launch -- m > 512 (Gram as slice pairs, streamed-W projection) and r > 128 (column groups in
+    projection / measure / reconstruct, the wide sweep and solve kernels): fit -> optimal_placement -> train -> predict
+    -> reconstruct against the oracle; sensors exact and ordered, field 1e-6.  The reference accepts any m and any
+    r <= m (:272-279, :336, :739)."""
+    from openmeasure_amd.sparse_sensing import SPR
+    rho = 10 ** (-2.0 / max(k - 1, 1))                          # k designed modes over two decades, noise floor far below
+    X = synth_host(n_points, F, m, k, rho, 1e-6, 4000 + m)
+    n = n_points * F
+    st = orc.fit(X, F, select, n_modes)
+    r = st['r']
+    spr = SPR(X, F, None, engine=eng)
+    spr.fit(select_modes=select, n_modes=n_modes)
+    assert spr.r == r and spr.Ur.shape == (n, r)
+    np.testing.assert_allclose(spr.Sigma_r, st['Sigma_r'], rtol=1e-8)
+    # the subspace (the columns themselves are only defined up to rotations inside clusters of close singular values)
+    z = np.random.default_rng(1).standard_normal(n)
+    assert rel_fro(spr.Ur @ (spr.Ur.T @ z), st['Ur'] @ (st['Ur'].T @ z)) < 1e-8
+    C = spr.optimal_placement()
+    piv, _ = orc.qr_pivots(st['Ur'])
+    np.testing.assert_array_equal(spr.sensors_, piv)
+    assert C.shape == (r, n)
+    spr.train(C)
+    ys = []
+    for j in (0, 1):
+        y = np.zeros((r, 3)); y[:, 0] = X[piv, j] + (1e-3 if j else 0.0); y[:, 2] = piv // n_points
+        if j == 1:
+            y[:, 1] = 0.01 * (1.0 + np.arange(r) % 3)
+        ys.append(y)
+    A, As = spr.predict(ys)
+    Cd = np.zeros((r, n)); Cd[np.arange(r), piv] = 1.0
+    Theta_ref = orc.train_theta(Cd, st['Ur'], n)
+    A_ref, _ = orc.predict_ols(ys, Theta_ref, Cd, st['X_cnt'], st['X_scl'], n_points)
+    X_ref = orc.reconstruct(A_ref, st['Ur'], st['X_cnt'], st['X_scl'])
+    X_rec = spr.reconstruct(A)
+    assert X_rec.shape == (n, 2) and rel_fro(X_rec, X_ref) <= REL_FRO
+
+
+def test_all_modes_of_a_wide_matrix(eng):
+    """fit(select_modes='variance', n_modes=100) -- the option of the reference's own tests/test_rom.py:48-55 -- at m = 300:
+    every mode kept (r = m = 300, among them the null mode of the row centring), training snapshots reproduced through
+    reconstruct (tests/test_rom.py:82-85) and through placement -> train -> predict."""
+    from openmeasure_amd.sparse_sensing import SPR
+    n_points, F, m = 300, 2, 300
+    X = synth_host(n_points, F, m, 60, 0.9, 1e-2, 4242)
+    n = n_points * F
+    spr = SPR(X, F, None, engine=eng)
+    spr.fit(select_modes='variance', n_modes=100)
+    assert spr.r == m and spr.Ur.shape == (n, m) and spr.Ar.shape == (m, m)
+    X_rec = spr.reconstruct(spr.Ar[:3])
+    assert rel_fro(X_rec, X[:, :3]) <= REL_FRO
+    C = spr.optimal_placement()
+    assert C.shape == (m, n) and len(set(spr.sensors_.tolist())) == m
+    spr.train(C)
+    y = np.zeros((m, 3)); y[:, 0] = X[spr.sensors_, 5]; y[:, 2] = spr.sensors_ // n_points
+    a, _ = spr.predict(y)
+    assert rel_fro(spr.reconstruct(a)[:, 0], X[:, 5]) <= 1e-5

@@ -99,12 +99,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv, env_extra=None, timeout=None, relay=sys.stdout):
+def launch_ranks(n, argv, env_extra=None, timeout=None, relay=sys.stdout, grace=10.0):
     """Start `n` rank processes running `argv` (a full command line), one per GPU, with the torchrun environment
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for them.  The caller must not have touched
     the GPU: the children are fresh processes (never an exec of this one).  Rank 0's stdout is relayed line by line;
     the other ranks' stdout goes to stderr.  Returns the exit code: 0 when every rank succeeded, else the first
-    failing rank's code (the remaining ranks are terminated by PID)."""
+    failing rank's code; the remaining ranks get SIGTERM by PID and, `grace` seconds later, SIGKILL -- a rank stuck in a
+    collective must not hang the launcher."""
     port = _free_port()
     procs = []
     for rank in range(n):
@@ -129,6 +130,15 @@ def launch_ranks(n, argv, env_extra=None, timeout=None, relay=sys.stdout):
     th = threading.Thread(target=pump, daemon=True)
     th.start()
     live = set(range(n))
+    kill_at = None                                             # after a failure / timeout: SIGTERM now, SIGKILL at this time
+
+    def stop_others(why):
+        nonlocal kill_at
+        log(f'[launcher] {why}; stopping the other ranks')
+        for o in live:
+            procs[o].terminate()
+        kill_at = time.time() + grace
+
     while live:
         for r in sorted(live):
             code = procs[r].poll()
@@ -137,18 +147,43 @@ def launch_ranks(n, argv, env_extra=None, timeout=None, relay=sys.stdout):
             live.discard(r)
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 128 - code
-                log(f'[launcher] rank {r} exited with code {code}; stopping the other ranks')
-                for o in live:
-                    procs[o].terminate()
-        if t_end is not None and time.time() > t_end and live:
-            log('[launcher] timeout; stopping all ranks')
+                if kill_at is None:
+                    stop_others(f'rank {r} exited with code {code}')
+        if t_end is not None and time.time() > t_end and live and kill_at is None:
             rc = rc or 124
+            stop_others('timeout')
+        if kill_at is not None and time.time() > kill_at and live:
+            # a rank stuck inside a collective or the driver does not leave on SIGTERM: kill it, never wait forever
+            log(f'[launcher] ranks {sorted(live)} ignored SIGTERM for {grace:.0f} s: SIGKILL')
             for o in live:
-                procs[o].terminate()
-            t_end = None
+                procs[o].kill()
+            for o in list(live):
+                procs[o].wait()
+                live.discard(o)
+            rc = rc or 137
         time.sleep(0.05)
     th.join(timeout=5)
     return rc
+
+
+def count_gpus():
+    """AMD GPUs of this node WITHOUT touching the HIP runtime (the launcher parent must stay GPU-free: its children are
+    the only processes that may initialise the device): KFD topology nodes with a gfx target, else DRM render nodes.
+    None when neither is readable."""
+    import glob
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if nodes:
+        k = 0
+        for p in nodes:
+            try:
+                with open(p) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                k += int(props.get('gfx_target_version', '0')) != 0
+            except (OSError, ValueError):
+                pass
+        return k
+    rd = glob.glob('/dev/dri/renderD*')
+    return len(rd) if rd else None
 
 
 def parse_args(argv=None):
@@ -179,11 +214,10 @@ def parse_args(argv=None):
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU
-        # (device_count() below does not initialise it either).
-        import torch
-        have = torch.cuda.device_count()
-        if have < args.gpus and os.environ.get('SPR_BENCH_ONE_GPU') != '1':
+        # plain `python bench.py --gpus N`: become the launcher.  This process never touches the GPU or imports torch:
+        # the device count comes from sysfs
+        have = count_gpus()
+        if have is not None and have < args.gpus and os.environ.get('SPR_BENCH_ONE_GPU') != '1':
             log(f'bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)')
             sys.exit(2)
         sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
@@ -296,6 +330,11 @@ def run_rank(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = 1e3 * dt / args.steps
+    # never print a number for a run that computed garbage: spectrum, basis sample and field must be finite
+    fld = field if torch.is_tensor(field) else None
+    if not (np.all(np.isfinite(spr.S_[:s])) and bool(torch.isfinite(spr._d['Ur'][:4096].double()).all())
+            and (fld is None or bool(torch.isfinite(fld[..., ::max(1, fld.shape[-1] // 65536)]).all()))):
+        raise SystemExit('bench.py: non-finite spectrum / basis / field -- no result line')
     n_job = n_loc if share else n_glob            # rows this run actually processed (a share run: one rank's block)
     x_bytes = float(n_job) * m * B
     value = x_bytes / (dt / args.steps) / 1e9
@@ -397,19 +436,26 @@ def run_rank(args):
         Xo = Xs.astype(np.float64) if f32 else Xs
         xr_cpu, st_cpu = orc.fit_reconstruct_timed(Xo, F, s)
         t_cpu = time.perf_counter() - t1
-        blas = 'unknown'
+        blas, cores, note = 'unknown', 1, ''
         try:
             import threadpoolctl
-            info = threadpoolctl.threadpool_info()
+            info = [p for p in threadpoolctl.threadpool_info() if p.get('user_api') == 'blas']
+            # the oracle's time is LAPACK/BLAS time: `cores` = the threads that BLAS pool really ran with
             cores = max([p.get('num_threads', 1) for p in info] or [1])
             blas = '; '.join(sorted({f"{p.get('internal_api')} {p.get('version')} ({p.get('threading_layer', p.get('user_api'))}, "
-                                      f"{p.get('num_threads')} threads)" for p in info if p.get('user_api') == 'blas'})) or blas
+                                      f"{p.get('num_threads')} threads)" for p in info})) or blas
         except Exception:
-            cores = os.cpu_count()
+            pass
+        phys = _physical_cores()
+        if phys and cores < phys:
+            note = (f'; the BLAS build caps its pool at {cores} threads: {phys - cores} of the {phys} physical cores idle')
+        extrap = '' if cc == n_points else (f'; rate measured on this sample -- for the full {n_points}-cell workload it is an '
+                                            'EXTRAPOLATION, linear in n (fit and reconstruct are O(n) at fixed m, r)')
         cpu = dict(value=round(Xs.nbytes / t_cpu / 1e9, 4), unit='GB/s', cores=int(cores), kind='port',
-                   cpu_model=_cpu_model(), host_cpus=os.cpu_count(), blas=blas,
+                   cpu_model=_cpu_model(), host_cpus=os.cpu_count(), physical_cores=phys, blas=blas,
                    sample=f'{cc} cells x {F} features x {m} snapshots ({Xs.nbytes / 1e6:.0f} MB), s={s}: '
-                          f'oracle fit+reconstruct {t_cpu:.2f} s (same generator, first {cc} cells per feature)')
+                          f'oracle fit+reconstruct {t_cpu:.2f} s (same generator, first {cc} cells per feature)'
+                          + extrap + note)
         # parity on the same sample: GPU path vs oracle.  The oracle ran in f64 on the stored values widened, which is
         # what the reference computes for a float32 X as well (X_cnt / X_scl are float64: X0, U float64, :106-107, :169)
         Xs_in = DeviceMatrix(eng.to_device(Xs, dtype=torch.float32), basis='f32') if f32 else Xs
@@ -460,6 +506,25 @@ def run_rank(args):
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def _physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    phys = line.split(':', 1)[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':', 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 def _cpu_model():

@@ -46,7 +46,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix', 'PendingField']
+__all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix', 'PendingField', 'OneHotRows']
 
 _DEVICE_SPECTRUM_MAX_M = 24   # above this the single-workgroup Jacobi is slower than host dsyevd (csrc/spectrum.hip)
 # Gram route (fit): singular vectors come from the eigenvectors of X0^T X0, whose rounding error eps * sigma_1^2 reaches
@@ -113,6 +113,139 @@ class DeviceMatrix:
     @property
     def shape(self):
         return tuple(self.tensor.shape)
+
+
+class OneHotRows:
+    """The one-hot measurement matrix C of ``optimal_placement`` (reference :741-743: ``C = np.zeros((s, n));
+    C[j, P[j]] = 1``) held as its s row indices instead of s x n doubles -- 46 GB at BASELINE config 3, 819 GB at
+    config 5.  ``optimal_placement`` returns the plain ndarray while it is small (64 MiB) and this object above that;
+    it behaves like the dense matrix for everything the reference's documentation does with C (README.md:165-184):
+
+        np.argmax(C[i, :])          C @ x, C.dot(x)  (x of shape (n,) or (n, k))        C.shape, len(C)
+        np.argmax(C, axis=1)        spr.train(C)                                         np.asarray(C), C.toarray()
+
+    ``np.asarray`` / ``toarray`` build the dense matrix only below ``dense_limit`` bytes (MemoryError beyond: that
+    allocation is what this class exists to avoid); ``tocsr()`` gives a scipy.sparse matrix of any size.  ``rows`` are
+    the ordered global sensor rows (= ``spr.sensors_``).  A 1-D instance (shape (n,)) is what ``C[i, :]`` returns."""
+
+    dense_limit = 1 << 32
+    dtype = np.dtype(np.float64)
+    __array_priority__ = 20.0                                  # ndarray @ OneHotRows defers to __rmatmul__
+
+    def __init__(self, rows, n, _vector=False):
+        self.rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        self.n = int(n)
+        self._vector = bool(_vector)
+        if self._vector and self.rows.size != 1:
+            raise ValueError('a one-hot vector has exactly one non-zero')
+        if self.rows.size and (self.rows.min() < 0 or self.rows.max() >= self.n):
+            raise IndexError('sensor row outside [0, n)')
+
+    @property
+    def shape(self):
+        return (self.n,) if self._vector else (self.rows.size, self.n)
+
+    @property
+    def ndim(self):
+        return 1 if self._vector else 2
+
+    @property
+    def nnz(self):
+        return int(self.rows.size)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __repr__(self):
+        return f'OneHotRows(shape={self.shape}, rows={self.rows.tolist() if self.rows.size <= 16 else "..."})'
+
+    # ---- what NumPy asks for -------------------------------------------------------------------------------
+    def argmax(self, axis=None, out=None, **kw):
+        """np.argmax(C[i, :]) -> the sensor's row; np.argmax(C, axis=1) -> all of them (1-D); axis=None: flat index."""
+        if self._vector:
+            if axis not in (None, 0, -1):
+                raise np.exceptions.AxisError(axis, 1)
+            return np.int64(self.rows[0])
+        if axis in (1, -1):
+            return self.rows.copy()
+        if axis is None:                                       # first maximum of the flattened matrix: row 0's one
+            return np.int64(self.rows[0]) if self.rows.size else np.int64(0)
+        if axis in (0, -2):
+            raise MemoryError('argmax over axis 0 of the one-hot matrix needs its n columns; use tocsr()')
+        raise np.exceptions.AxisError(axis, 2)
+
+    def __array__(self, dtype=None, copy=None):
+        nbytes = 8 * self.n * (1 if self._vector else self.rows.size)
+        if nbytes > self.dense_limit:
+            raise MemoryError(f'dense form of this one-hot matrix needs {nbytes / 2 ** 30:.1f} GiB; use its row indices '
+                              '(.rows / np.argmax(C, axis=1)), C @ x, or C.tocsr()')
+        if self._vector:
+            out = np.zeros(self.n)
+            out[self.rows[0]] = 1.0
+        else:
+            out = np.zeros((self.rows.size, self.n))
+            out[np.arange(self.rows.size), self.rows] = 1.0
+        return out if dtype is None else out.astype(dtype, copy=False)
+
+    def toarray(self):
+        return self.__array__()
+
+    def tocsr(self):
+        import scipy.sparse as sp
+        s = self.rows.size
+        return sp.csr_matrix((np.ones(s), self.rows, np.arange(s + 1)), shape=(s, self.n))
+
+    def sum(self, axis=None):
+        if self._vector or axis is None:
+            return np.float64(self.rows.size)
+        if axis in (1, -1):
+            return np.ones(self.rows.size)
+        return np.bincount(self.rows, minlength=self.n).astype(np.float64)   # axis 0: (n,), allocated by request
+
+    # ---- indexing: C[i, :], C[i], C[i, j], C[a:b] ----------------------------------------------------------
+    def __getitem__(self, key):
+        if self._vector:
+            if isinstance(key, (int, np.integer)):
+                k = int(key) + (self.n if key < 0 else 0)
+                if not 0 <= k < self.n:
+                    raise IndexError('index out of range')
+                return np.float64(1.0 if k == self.rows[0] else 0.0)
+            return np.asarray(self)[key]
+        if isinstance(key, tuple):
+            if len(key) != 2:
+                raise IndexError('too many indices for a 2-D matrix')
+            ri, ci = key
+        else:
+            ri, ci = key, slice(None)
+        full_cols = isinstance(ci, slice) and ci == slice(None)
+        if isinstance(ri, (int, np.integer)):
+            row = self.rows[ri]                                # IndexError like ndarray when out of range
+            if full_cols:
+                return OneHotRows([row], self.n, _vector=True)
+            if isinstance(ci, (int, np.integer)):
+                k = int(ci) + (self.n if ci < 0 else 0)
+                return np.float64(1.0 if k == row else 0.0)
+            return np.asarray(OneHotRows([row], self.n, _vector=True))[ci]
+        if full_cols:
+            return OneHotRows(self.rows[ri], self.n)           # row slice / index array: still one-hot rows
+        return np.asarray(self)[key]                            # column subsets: dense (size-guarded)
+
+    # ---- products ------------------------------------------------------------------------------------------
+    def dot(self, x):
+        """C.dot(x) = the sampled entries x[rows] (reference :797, :573 and README.md:176)."""
+        x = np.asarray(x)
+        if x.ndim == 0 or x.shape[0] != self.n:
+            raise ValueError(f'shapes {self.shape} and {x.shape} not aligned')
+        return x[self.rows[0]] if self._vector else x[self.rows]
+
+    __matmul__ = dot
+
+    def __rmatmul__(self, a):
+        return np.asarray(a) @ np.asarray(self)                 # (k, s) @ (s, n): dense by nature, size-guarded
+
+    @property
+    def T(self):
+        return self.tocsr().T
 
 
 class PendingField:
@@ -480,11 +613,29 @@ class ROM:
         Xd = self._Xd()
         F = self.n_features
         tr_ = self._trace = _Trace(eng)
-        rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
-        tr_.mark('stats_gram')
-        gram = self._all_reduce(gram)
-        fs_d = self._all_gather(fstats)                      # (world, F, 3)
+        rowmean, gram, fs_d = self._gram_collective(Xd)
         self._merge_stats(gram, fs_d, rowmean, scale_type, axis_cnt)
+
+    def _gram_collective(self, Xd):
+        """The fused stats + Gram pass over the local rows and the ONE collective of fit(): an all-reduce (sum) of a
+        buffer [F m m Gram doubles | world x F x 3 statistics], every rank writing its (count, mean, M2) triples into
+        its own slot and zeros elsewhere, so the sum hands every rank all ranks' statistics in rank order (adding
+        zeros is exact) -- north_star: a single RCCL all-reduce for the Gram matrix.
+        Returns rowmean (n_local,), gram (F, m, m) summed over ranks, fstats_all (world, F, 3)."""
+        eng = self._engine()
+        F, m = self.n_features, Xd.shape[1]
+        if not self._dist():
+            rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+            self._trace.mark('stats_gram')
+            return rowmean, gram, fstats[None]
+        world, rank = self._world(), self._shard.rank
+        buf = eng.zeros((F * m * m + world * F * 3,))
+        rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+        self._trace.mark('stats_gram')
+        buf[:F * m * m].copy_(gram.reshape(-1))
+        buf[F * m * m + rank * F * 3:F * m * m + (rank + 1) * F * 3].copy_(fstats.reshape(-1))
+        self._all_reduce(buf)
+        return rowmean, buf[:F * m * m].view(F, m, m), buf[F * m * m:].view(world, F, 3)
 
     def _merge_stats(self, gram, fs_d, rowmean, scale_type, axis_cnt):
         """Per-feature Gram blocks (all-reduced) + per-rank feature statistics -> X_scl per feature and the Gram matrix
@@ -602,6 +753,10 @@ class ROM:
         eng = self._engine()
         if known is not None:
             indptr, indices, vals = known
+        elif isinstance(C, OneHotRows):
+            if C.ndim != 2:
+                raise ValueError('a measurement matrix has two dimensions')
+            indptr, indices, vals = np.arange(C.shape[0] + 1), C.rows, np.ones(C.shape[0])
         else:
             Cs = C.tocsr() if sp.issparse(C) else sp.csr_matrix(np.asarray(C, dtype=np.float64))
             Cs.sort_indices()
@@ -867,9 +1022,7 @@ class ROM:
         r = self._select_rank(None, m, 'number', n_modes)      # same TypeError / ValueError as the reference
         F = self.n_features
         tr_ = self._trace = _Trace(eng)
-        rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
-        gram = self._all_reduce(gram)
-        fs_all = self._all_gather(fstats)
+        rowmean, gram, fs_all = self._gram_collective(Xd)
         sp = eng.spectrum(gram, fs_all, scale_type, r)
         tr_.mark('stats_gram+spectrum')
         self._host.clear()
@@ -939,13 +1092,21 @@ class ROM:
             import torch.distributed as dist
             loc = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
                                   self._d['scale'], A_d)
-            out = eng.empty((n_p, world * n_loc))
-            works = [dist.all_gather_into_tensor(out[p], loc[p], group=self._shard.group, async_op=True)
-                     for p in range(n_p)]                     # one contiguous all-gather per column
-            if not to_host and not wait:
-                return PendingField(out, works, keep=(loc,))
-            for w in works:
-                w.wait()
+            # ONE all-gather for all n_p columns: rank q's (n_p, n_loc) block lands at stage[q]; for one column that is
+            # the field itself, for several the columns are put side by side afterwards (a device-side permute)
+            stage = eng.empty((world, n_p, n_loc))
+            work = dist.all_gather_into_tensor(stage.view(-1), loc.contiguous().view(-1), group=self._shard.group,
+                                               async_op=True)
+            if n_p == 1:
+                out = stage.view(1, world * n_loc)
+                if not to_host and not wait:
+                    return PendingField(out, [work], keep=(loc, stage))
+                work.wait()
+            else:
+                work.wait()
+                out = stage.permute(1, 0, 2).reshape(n_p, world * n_loc)
+                if not to_host and not wait:
+                    return PendingField(out)
         if not to_host:
             return out if wait else PendingField(out)
         return eng.to_host(out).T                             # (n, n_p), Fortran-ordered view
@@ -959,9 +1120,9 @@ class SPR(ROM):
 
     # ------------------------------------------------------------------ a6 optimal_placement
     def optimal_placement(self, calc_type='qr', n_sensors=10, mask=None, d_min=0., verbose=False):
-        """Reference :700-756.  Returns the one-hot measurement matrix C of shape (s, n):
-        a dense ndarray when it is small (< 64 MiB), a scipy.sparse CSR matrix otherwise.
-        The ordered global sensor rows are also kept in ``self.sensors_``."""
+        """Reference :700-756.  Returns the one-hot measurement matrix C of shape (s, n): the reference's dense ndarray
+        while it is small (64 MiB), a OneHotRows above that (46 GB dense at BASELINE config 3) -- same behaviour for
+        C[i, :], C @ x, np.argmax(C, axis=1), train(C).  The ordered global sensor rows are also in ``self.sensors_``."""
         if calc_type == 'gem':
             return self._placement_gem(n_sensors, mask, d_min)
         if calc_type != 'qr':
@@ -982,12 +1143,16 @@ class SPR(ROM):
         piv = eng.to_host(st['piv']).astype(np.int64)
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])
-        import scipy.sparse as sp
-        C = sp.csr_matrix((np.ones(s), piv, np.arange(s + 1)), shape=(s, n))
-        if s * n * 8 <= _DENSE_C_LIMIT:
-            C = C.toarray()
+        C = self._one_hot(piv, n)
         self._placed = (C, piv)
         return C
+
+    @staticmethod
+    def _one_hot(piv, n):
+        """(s, n) one-hot matrix of the picks (:741-743): the reference's dense ndarray while it is small, a OneHotRows
+        (same behaviour for the documented uses, s integers of storage) above _DENSE_C_LIMIT bytes."""
+        C = OneHotRows(piv, n)
+        return C.toarray() if len(piv) * n * 8 <= _DENSE_C_LIMIT else C
 
     def _placement_gem(self, n_sensors, mask, d_min):
         """calc_type='gem' (reference :586-698, :745-751): greedy maximisation of the conditional variance
@@ -1033,11 +1198,7 @@ class SPR(ROM):
         piv = eng.to_host(st['piv'])[1:].astype(np.int64)
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])[1:]
-        import scipy.sparse as sp
-        n = self._n_global
-        C = sp.csr_matrix((np.ones(s), piv, np.arange(s + 1)), shape=(s, n))
-        if s * n * 8 <= _DENSE_C_LIMIT:
-            C = C.toarray()
+        C = self._one_hot(piv, self._n_global)
         self._placed = (C, piv)
         return C
 

@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--scaling', default='strong')
     ap.add_argument('--fail-rank', type=int, default=-1)
     ap.add_argument('--hang-rank', type=int, default=-1)
+    ap.add_argument('--deaf', action='store_true', help='the hanging rank also ignores SIGTERM')
     ap.add_argument('--out', default='')
     args = ap.parse_args()
     import torch.distributed as dist
@@ -46,6 +47,9 @@ def main():
     dist.init_process_group('gloo', rank=rank, world_size=world)
     assert dist.get_world_size() == args.gpus
     if rank == args.hang_rank:
+        if args.deaf:
+            import signal
+            signal.signal(signal.SIGTERM, signal.SIG_IGN)
         time.sleep(600)
     wl = dict(cells=args.cells, features=3, m=10, s=4, scaling=args.scaling)
     plan = bench.shard_plan(wl, world, rank, 'auto')

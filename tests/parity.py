@@ -376,3 +376,45 @@ def run_gem_beyond_rank(engine, n_points, F, r, n_sensors, d_min, masked, seed, 
     np.testing.assert_array_equal(spr.sensors_[:r - 1], first)
     return spr
 
+
+
+def run_documented_idioms(g, engine, monkeypatch):
+    """The reference's documented use of the measurement matrix (README.md:160-184 and INTEGRATION.md) run twice: on
+    the dense ndarray optimal_placement returns while it is small, and on the OneHotRows it returns above the dense
+    limit (46 GB at BASELINE config 3) -- every line must behave the same."""
+    import openmeasure_amd.sparse_sensing as mod
+    X = g['X'].astype(np.float64)
+    n, m = X.shape
+    F = g['n_features']
+    n_cells = n // F
+    r = g['r']
+    x_test = X @ (np.arange(1, m + 1) / (m * (m + 1) / 2))         # a state in the span of the data
+    outs = []
+    for limit in (mod._DENSE_C_LIMIT, 0):
+        monkeypatch.setattr(mod, '_DENSE_C_LIMIT', limit)
+        spr = SPR(X.copy(), F, None, engine=engine)
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        C_qr = spr.optimal_placement()
+        assert isinstance(C_qr, np.ndarray if limit else mod.OneHotRows) and C_qr.shape == (r, n)
+        xz_sensors = np.zeros((r, 4))
+        for i in range(r):                                         # README.md:166-169
+            index = np.argmax(C_qr[i, :])
+            xz_sensors[i, 2] = index // n_cells
+            xz_sensors[i, 3] = index % n_cells
+        y_qr = np.ones((r, 3))
+        y_qr[:, 0] = C_qr @ x_test                                  # README.md:176
+        y_qr[:, 1] = 0.0
+        for i in range(r):                                          # README.md:178-179
+            y_qr[i, 2] = np.argmax(C_qr[i, :]) // n_cells
+        y2 = np.zeros((r, 3)); y2[:, 0] = C_qr.dot(x_test)
+        y2[:, 2] = np.argmax(C_qr, axis=1) // spr.n_points          # INTEGRATION.md (vectorised form of the loop)
+        np.testing.assert_array_equal(y2, y_qr)
+        assert np.asarray(C_qr).shape == (r, n) and np.asarray(C_qr).sum() == r
+        spr.train(C_qr)                                             # README.md:182
+        ap, sigmap = spr.predict(y_qr)
+        xp = spr.reconstruct(ap)
+        outs.append((xz_sensors, y_qr, spr.Theta.copy(), ap, xp, spr.sensors_.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    assert rel_fro(outs[1][4][:, 0], x_test) < 0.1 or r < 4          # a sane reconstruction, not only equal ones
+    return outs[1]

@@ -78,6 +78,31 @@ def test_launcher_propagates_a_failed_rank():
     assert not [ln for ln in out.getvalue().splitlines() if ln.startswith('{')]
 
 
+def test_launcher_kills_a_rank_that_ignores_sigterm():
+    """A rank stuck in a collective (here: one that ignores SIGTERM) must not hang the launcher: SIGKILL after the grace
+    period, non-zero exit code."""
+    import time
+    out = io.StringIO()
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [sys.executable, CHILD, '--gpus', '2', '--fail-rank', '1', '--hang-rank', '0', '--deaf'],
+                            timeout=240, relay=out, grace=2.0)
+    assert rc == 3 and time.time() - t0 < 120
+    rc = bench.launch_ranks(2, [sys.executable, CHILD, '--gpus', '2', '--hang-rank', '0', '--deaf'], timeout=20, relay=out,
+                            grace=2.0)
+    assert rc == 124                                          # timeout: terminate, then kill
+
+
+def test_launcher_parent_counts_gpus_without_hip():
+    """bench.py --gpus N as the launcher never imports torch or touches the HIP runtime: the device count is read from
+    sysfs (None on a machine without the driver)."""
+    import subprocess
+    code = ("import sys, bench; n = bench.count_gpus(); "
+            "assert 'torch' not in sys.modules, 'launcher parent imported torch'; print(n)")
+    p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.strip() == 'None' or int(p.stdout) >= 0
+
+
 def test_world_size_mismatch_is_an_error():
     import subprocess
     env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')

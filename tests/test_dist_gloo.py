@@ -276,3 +276,57 @@ def test_pipelined_field_gather_loop(tmp_path):
         np.testing.assert_allclose(o['f1'] - o['f0'], o['f2'] - o['f1'], rtol=0, atol=1e-9 * np.abs(o['f2']).max())
         np.testing.assert_array_equal(o['f2'], outs[0]['f2'])
     assert outs[0]['f2'].shape == (2, g['X'].shape[0])
+
+
+def _count_worker(rank, world, port, fixture, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden
+        from tests.numpy_engine import NumpyEngine
+        g = load_golden(fixture)
+        X = g['X']
+        n = X.shape[0]
+        n_loc = n // world
+        row0 = rank * n_loc
+        calls = []
+        real = {k: getattr(dist, k) for k in ('all_reduce', 'all_gather_into_tensor', 'all_gather', 'broadcast')}
+        for k, fn in real.items():
+            setattr(dist, k, (lambda name, f: (lambda *a, **kw: (calls.append(name), f(*a, **kw))[1]))(k, fn))
+        spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
+                  engine=NumpyEngine())
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        fit_calls = list(calls)
+        del calls[:]
+        X3 = spr.reconstruct(spr.Ar[:3])
+        rec_calls = list(calls)
+        del calls[:]
+        x1 = spr.reconstruct(spr.Ar[0], to_host=False, wait=False).wait()
+        rec1_calls = list(calls)
+        for k, fn in real.items():
+            setattr(dist, k, fn)
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), fit=np.array(fit_calls), rec=np.array(rec_calls),
+                 rec1=np.array(rec1_calls), X3=X3, x1=x1.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_one_collective_per_fit_and_per_reconstruct(tmp_path, world):
+    """north_star: 'a single RCCL all-reduce over xGMI for the Gram matrix and a final all-gather for the reconstructed
+    field' -- fit() issues exactly ONE collective (the per-rank statistics ride in rank-indexed slots of the Gram
+    buffer), reconstruct() exactly ONE all-gather whatever the number of coefficient vectors."""
+    from tests.conftest import load_golden
+    fixture = 'g3_num8'
+    g = load_golden(fixture)
+    mp.spawn(_count_worker, args=(world, _free_port(), fixture, str(tmp_path)), nprocs=world, join=True)
+    ref = (g['Ur'] @ g['Ar'][:3].T) * g['X_scl'] + g['X_cnt']
+    for r in range(world):
+        o = np.load(tmp_path / f'rank{r}.npz')
+        assert o['fit'].tolist() == ['all_reduce'], o['fit']
+        assert o['rec'].tolist() == ['all_gather_into_tensor'] and o['rec1'].tolist() == ['all_gather_into_tensor']
+        assert np.linalg.norm(o['X3'] - ref) <= 1e-6 * np.linalg.norm(ref)
+        np.testing.assert_allclose(o['x1'][0], o['X3'][:, 0], rtol=1e-12, atol=1e-12)

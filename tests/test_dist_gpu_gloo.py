@@ -70,3 +70,58 @@ def test_sharded_hip_path_two_ranks_one_gpu(tmp_path, fixture, world):
         np.testing.assert_allclose(o['A3'] * sg, g['Ar_pred3'], atol=1e-7 * np.abs(g['Ar_pred3']).max())
     if fixture == 'cond_1e7':
         assert int(outs[0]['passes']) >= 1                                  # the second-stage Gram pass ran, sharded
+
+
+def _synth_worker(rank, world, port, cells, F, m, s_, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import bench
+        from openmeasure_amd.engine import HipEngine
+        from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix, RowShard
+        from openmeasure_amd.synth import make_R
+        eng = HipEngine('cuda:0')
+        plan = bench.shard_plan(dict(cells=cells, features=F, scaling='strong'), world, rank)
+        R = eng.to_device(make_R(m, s_, seed=1234))
+        Xd = eng.synth(plan['n_loc'], m, plan['row0'], plan['n_points'], R, 1e-3, 1234)
+        spr = SPR(DeviceMatrix(Xd), F, None, shard=RowShard(plan['row0'], plan['n_glob']), engine=eng)
+        spr.fit(select_modes='number', n_modes=s_)
+        spr.optimal_placement()
+        x = spr.reconstruct(spr.Ar[:1], to_host=False, wait=False).wait()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'dist.npz'), piv=spr.sensors_, S=spr.S_, field=eng.to_host(x)[0], a=spr.Ar[0],
+                     sign=np.sign(spr.Ar[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_shaped_shards_four_ranks_one_gpu(tmp_path):
+    """BASELINE config 4 in miniature (same 9 features x 256 snapshots, 64 modes; 1/50 of the cells), generated on the
+    device per rank exactly as bench.py does it, FOUR ranks whose blocks start and end inside features: sensors equal to
+    the single-rank run's, field to 1e-12 -- the N-rank path with the real kernels (gloo carries the collectives)."""
+    import torch
+    import torch.multiprocessing as mp
+    from openmeasure_amd.engine import HipEngine
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    from openmeasure_amd.synth import make_R
+    cells, F, m, s_, world = 200_000, 9, 256, 64, 4
+    mp.spawn(_synth_worker, args=(world, _free_port(), cells, F, m, s_, str(tmp_path)), nprocs=world, join=True)
+    d = np.load(tmp_path / 'dist.npz')
+    eng = HipEngine('cuda:0')
+    R = eng.to_device(make_R(m, s_, seed=1234))
+    Xd = eng.synth(cells * F, m, 0, cells, R, 1e-3, 1234)
+    one = SPR(DeviceMatrix(Xd), F, None, engine=eng)
+    one.fit(select_modes='number', n_modes=s_)
+    one.optimal_placement()
+    np.testing.assert_array_equal(d['piv'], one.sensors_)
+    np.testing.assert_allclose(d['S'][:s_], one.S_[:s_], rtol=1e-11)
+    ref = eng.to_host(one.reconstruct(one.Ar[:1] * 1.0, to_host=False))[0]
+    # the same coefficient vector in each run's own sign convention reconstructs the same field
+    assert np.linalg.norm(d['field'] - ref) <= 1e-12 * np.linalg.norm(ref)
+    del Xd, one
+    torch.cuda.empty_cache()

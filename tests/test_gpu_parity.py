@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import spr_oracle as orc
-from tests.parity import (REL_FRO, align_signs, rel_fro, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style,
+from tests.parity import (REL_FRO, align_signs, rel_fro, run_documented_idioms, run_f32_storage, run_fixture, run_gem_fixture, run_gpr_style,
                           run_conditioning_guard, run_gem_beyond_rank, run_pinv_fixture)
 
 pytestmark = pytest.mark.gpu
@@ -860,6 +860,120 @@ def test_properties_at_config3_scale(eng):
     t.cuda.empty_cache()
 
 
+def _slab_pivot_check(eng, Ur_d, r, rows=1_500_000):
+    """the oracle (dgeqp3) can pivot a slab of the basis: the device picks restricted to that slab must agree with it"""
+    from openmeasure_amd.sparse_sensing import SPR
+    Uh = eng.to_host(Ur_d[:rows]).astype(np.float64)
+    sub = SPR(np.zeros((rows, r + 2)), 1, None, engine=eng)
+    sub.fit(basis=(Uh, np.eye(r + 2, r)))
+    sub.optimal_placement()
+    want, _ = orc.qr_pivots(Uh)
+    np.testing.assert_array_equal(sub.sensors_, want)
+
+
+def test_properties_at_config4_rank_block(eng):
+    """BASELINE config 4 as ONE rank of eight sees it, at full size: rank 3's block of the 10M-cell x 9 x 256 matrix --
+    global rows [33.75M, 45M), the end of feature 3 and the start of feature 4 -- through RowShard(partial=True) (what
+    bench.py --share-of 8 --share-rank 3 runs): finite spectrum, orthonormal basis ON THE BLOCK'S OWN ROWS (the fit of
+    a partial group is the fit of its rows), energy identity per feature segment, best-rank-r residual, reproducible
+    sensors and the slab-vs-dgeqp3 pivot check."""
+    import bench
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix, RowShard
+    from openmeasure_amd.synth import make_R
+    t = eng.torch
+    t.cuda.empty_cache()
+    wl = bench.WORKLOADS['c4']
+    F, m, r = wl['features'], wl['m'], wl['s']
+    plan = bench.shard_plan(wl, 8, 3)
+    n_points, n_glob, n_loc, row0 = plan['n_points'], plan['n_glob'], plan['n_loc'], plan['row0']
+    assert (row0, n_loc) == (33_750_000, 11_250_000) and row0 // n_points != (row0 + n_loc - 1) // n_points
+    R = eng.to_device(make_R(m, r, seed=1234))
+    Xd = eng.synth(n_loc, m, row0, n_points, R, 1e-3, 1234)
+    spr = SPR(DeviceMatrix(Xd), F, None, shard=RowShard(row0, n_glob, partial=True), engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    assert np.isfinite(spr.S_).all() and spr.S_[0] / spr.S_[r - 1] < 1e4
+    feats = sorted(set([row0 // n_points, (row0 + n_loc - 1) // n_points]))
+    absent = [f for f in range(F) if f not in feats]
+    np.testing.assert_array_equal(spr._scl_f[absent], 1.0)              # features without rows here take no part
+    Ur, mu, inv = spr._d['Ur'], spr._d['rowmean'], spr._d['inv_scale']
+    I = eng.to_host(Ur.T @ Ur)
+    assert np.abs(I - np.eye(r)).max() < 1e-9
+    cut = (feats[0] + 1) * n_points - row0                               # local row where feature 4 starts
+    energy = 0.0
+    for (a, b, f) in ((0, cut, feats[0]), (cut, n_loc, feats[1])):
+        x0 = (Xd[a:b] - mu[a:b, None]) * inv[f]
+        energy += float((x0 * x0).sum())
+        del x0
+    assert abs(energy - float(np.sum(spr.S_ ** 2))) <= 1e-10 * energy
+    rec = spr.reconstruct(spr.Ar[:1], to_host=False)
+    assert tuple(rec.shape) == (1, n_loc)
+    tail = np.sqrt(np.sum(spr.S_[r:] ** 2))
+    sc = spr._d['scale']
+    d = t.cat([(rec[0, :cut] - Xd[:cut, 0]) / sc[feats[0]], (rec[0, cut:] - Xd[cut:, 0]) / sc[feats[1]]])
+    assert float(t.linalg.norm(d)) <= 1.05 * tail
+    spr.optimal_placement()
+    p1 = spr.sensors_.copy()
+    spr.optimal_placement()
+    np.testing.assert_array_equal(p1, spr.sensors_)
+    assert len(set(p1.tolist())) == r and p1.min() >= row0 and p1.max() < row0 + n_loc and spr.pivot_gap_.min() > 1e-9
+    _slab_pivot_check(eng, Ur, r)
+    del Xd, spr, rec, d
+    t.cuda.empty_cache()
+
+
+def test_properties_at_config5_share(eng):
+    """BASELINE config 5 as ONE GPU of eight holds it, at full size: 6.25M cells x 16 features x 512 snapshots in f32
+    storage (100M rows, 204.8 GB) + f32 basis (51.2 GB), 128 modes: finite spectrum, orthonormal basis (to f32 rounding),
+    energy identity, best-rank-r residual of a training column, reproducible distinct sensors whose pivot gaps are far
+    above f32 rounding, slab-vs-dgeqp3 -- checked in 5M-row slices."""
+    import bench
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    from openmeasure_amd.synth import make_R
+    t = eng.torch
+    t.cuda.empty_cache()
+    free, _ = t.cuda.mem_get_info()
+    if free < 275e9:
+        pytest.skip(f'needs 275 GB of free HBM, {free / 1e9:.0f} GB available')
+    wl = bench.WORKLOADS['c5']
+    n_points, F, m, r = wl['cells'], wl['features'], wl['m'], wl['s']
+    n = n_points * F
+    R = eng.to_device(make_R(m, r, seed=1234))
+    Xd = eng.synth(n, m, 0, n_points, R, 1e-3, 1234, dtype=t.float32)
+    spr = SPR(DeviceMatrix(Xd, basis='f32'), F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    assert np.isfinite(spr.S_).all() and spr.S_[0] / spr.S_[r - 1] < 1e4
+    Ur, mu, inv = spr._d['Ur'], spr._d['rowmean'], spr._d['inv_scale']
+    assert Ur.dtype == t.float32 and tuple(Ur.shape) == (n, r)
+    step = 1_250_000                                                     # divides n_points: slices never straddle a feature
+    gram_u = t.zeros((r, r), dtype=t.float64, device=Ur.device)
+    energy = 0.0
+    for i0 in range(0, n, step):
+        u = Ur[i0:i0 + step].double()
+        gram_u += u.T @ u
+        x0 = (Xd[i0:i0 + step].double() - mu[i0:i0 + step, None]) * inv[i0 // n_points]
+        energy += float((x0 * x0).sum())
+        del x0, u
+    assert np.abs(eng.to_host(gram_u) - np.eye(r)).max() < 5e-6          # f32-rounded entries, 1e8 rows
+    assert abs(energy - float(np.sum(spr.S_ ** 2))) <= 1e-9 * energy
+    rec = spr.reconstruct(spr.Ar[:1], to_host=False)
+    tail = np.sqrt(np.sum(spr.S_[r:] ** 2))
+    err2 = 0.0
+    for i0 in range(0, n, 4 * step):
+        dd = (rec[0, i0:i0 + 4 * step] - Xd[i0:i0 + 4 * step, 0].double()) * inv[i0 // n_points]
+        err2 += float((dd * dd).sum())
+        del dd
+    assert np.sqrt(err2) <= 1.05 * tail + 1e-6 * np.sqrt(energy)       # + the f32 rounding of the stored basis
+    spr.optimal_placement()
+    p1 = spr.sensors_.copy()
+    spr.optimal_placement()
+    np.testing.assert_array_equal(p1, spr.sensors_)
+    assert len(set(p1.tolist())) == r
+    assert spr.pivot_gap_.min() > 1e-6, spr.pivot_gap_.min()            # far above f32 rounding of the basis (6e-8)
+    _slab_pivot_check(eng, Ur, r, rows=1_000_000)
+    del Xd, spr, rec
+    t.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
 @pytest.mark.parametrize('scale_type,axis_cnt', [('std', None), ('pareto', 1), ('range', None), ('median', 1), ('l2-norm', 1),
                                                  ('max', None), ('level', 1)])
@@ -957,3 +1071,107 @@ def test_all_modes_of_a_wide_matrix(eng):
     y = np.zeros((m, 3)); y[:, 0] = X[spr.sensors_, 5]; y[:, 2] = spr.sensors_ // n_points
     a, _ = spr.predict(y)
     assert rel_fro(spr.reconstruct(a)[:, 0], X[:, 5]) <= 1e-5
+
+
+@pytest.mark.parametrize('name', ['g2_num4', 'g3_num16', 'f32_g3_num8'])
+def test_documented_idioms_on_one_hot_rows(eng, name, monkeypatch):   # README.md:160-184 / INTEGRATION.md on both return types
+    from tests.conftest import load_golden
+    run_documented_idioms(load_golden(name), eng, monkeypatch)
+
+
+def test_one_hot_rows_returned_at_scale(eng):
+    """Above the dense limit optimal_placement hands back a OneHotRows (8 M rows x 32 sensors = 2 GB dense): the documented
+    idioms run on it without ever building the dense matrix, and train() takes it."""
+    import torch
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix, OneHotRows
+    from openmeasure_amd.synth import make_R
+    n_points, F, m, s_ = 2_000_000, 4, 64, 32
+    R = eng.to_device(make_R(m, s_, seed=5))
+    Xd = eng.synth(n_points * F, m, 0, n_points, R, 1e-3, 5)
+    spr = SPR(DeviceMatrix(Xd), F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=s_)
+    C = spr.optimal_placement()
+    assert isinstance(C, OneHotRows) and C.shape == (s_, n_points * F)
+    rows = np.argmax(C, axis=1)
+    np.testing.assert_array_equal(rows, spr.sensors_)
+    assert all(np.argmax(C[i, :]) == rows[i] for i in range(s_))
+    x = eng.to_host(Xd[:, 3])
+    y = np.zeros((s_, 3)); y[:, 0] = C @ x; y[:, 2] = rows // n_points
+    np.testing.assert_array_equal(y[:, 0], x[rows])
+    spr.train(C)
+    a, _ = spr.predict(y)
+    xr = spr.reconstruct(a)
+    assert rel_fro(xr[:, 0], x) < 1e-2                              # training column: rank-32 truncation error only
+    with pytest.raises(MemoryError):
+        OneHotRows(rows, 10 ** 10).toarray()
+    del Xd, spr
+    torch.cuda.empty_cache()
+
+
+def test_state_read_before_fit_raises_attribute_error(eng):       # reference: the attribute does not exist yet
+    from openmeasure_amd.sparse_sensing import SPR
+    X = np.random.default_rng(0).random((40, 6))
+    spr = SPR(X, 2, None, engine=eng)
+    for attr in ('Ur', 'X_cnt', 'X_scl', 'X0', 'Ar', 'Sigma_r', 'Vr'):
+        with pytest.raises(AttributeError):
+            getattr(spr, attr)
+    for call in (spr.optimal_placement, lambda: spr.reconstruct(np.ones(3)), lambda: spr.train(np.zeros((2, 40))),
+                 lambda: spr.unscale_data(np.ones(40))):
+        with pytest.raises(AttributeError):
+            call()
+
+
+@pytest.mark.parametrize('m', [12, 64, 300])
+def test_constant_feature_and_nan_raise_linalgerror(eng, m):
+    """A constant feature (X_scl = 0 -> X0 = 0/0, :169) and a NaN / Inf in X make np.linalg.svd raise LinAlgError at :272;
+    so must fit(), on the sync-free device route (m = 12: statistics, spectrum and projection enqueued before the
+    verdict comes back), on the host-spectrum route (m = 64) and on the wide path (m = 300)."""
+    from openmeasure_amd.sparse_sensing import SPR
+    rng = np.random.default_rng(m)
+    X = rng.standard_normal((600, m))
+    Xc = X.copy(); Xc[300:] = 3.0                                   # mean exact: X_scl = 0 exactly
+    Xn = X.copy(); Xn[77, 3] = np.nan
+    Xi = X.copy(); Xi[411, 0] = np.inf
+    for bad in (Xc, Xn, Xi):
+        spr = SPR(bad, 2, None, engine=eng)
+        with pytest.raises(np.linalg.LinAlgError):
+            with np.errstate(all='ignore'):
+                spr.fit(select_modes='number', n_modes=3)
+    ok = SPR(X, 2, None, engine=eng)                                # the same engine still works afterwards
+    ok.fit(select_modes='number', n_modes=3)
+    assert np.isfinite(ok.Sigma_r).all()
+
+
+@pytest.mark.parametrize('m,r', [(12, 5), (20, 8)])
+def test_device_fit_hands_over_without_second_read(eng, m, r):
+    """Small m (sync-free device route) with sigma_1/sigma_r far above 1e4: the route's verdict comes back bad, the host
+    route takes over from the Gram blocks already formed (refinement pass) and the sensors are the reference's."""
+    from openmeasure_amd.sparse_sensing import SPR
+    X = synth_host(2000, 3, m, m, 10 ** (-7.0 / (r - 1)), 1e-15, 600 + m)
+    st = orc.fit(X, 3, 'number', r)
+    assert st['Sigma_r'][0] / st['Sigma_r'][-1] > 1e6
+    spr = SPR(X, 3, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    assert spr.gram_refine_passes_ >= 1 and getattr(spr, '_device_fit_fallback_', False)
+    spr.optimal_placement()
+    np.testing.assert_array_equal(spr.sensors_, orc.qr_pivots(st['Ur'])[0])
+
+
+def test_partial_row_group_with_absent_features(eng):
+    """RowShard(partial=True) -- one rank's block of a larger job run alone (bench.py --share-of): features without rows
+    in the block take no part (scale 1, no Gram contribution) instead of poisoning the Gram matrix with 0/0; the fit
+    equals the fit of the same rows as a stand-alone matrix of the present features."""
+    from openmeasure_amd.sparse_sensing import SPR, RowShard
+    n_points, F, m, r = 900, 4, 40, 6
+    X = synth_host(n_points, F, m, 12, 0.7, 1e-3, 31)
+    row0, n_loc = 300, 1200                                         # rows of features 0 (tail) and 1 (head + most): 2, 3 absent
+    blk = np.ascontiguousarray(X[row0:row0 + n_loc])
+    spr = SPR(blk, F, None, shard=RowShard(row0, n_points * F, partial=True, force_collectives=False), engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    assert np.isfinite(spr.S_).all() and np.isfinite(spr.Ur).all()
+    np.testing.assert_array_equal(spr._scl_f[2:], 1.0)
+    # oracle on the same rows: feature 0's rows and feature 1's rows as two blocks of their own
+    a, b = blk[:600], blk[600:]
+    Xc = np.vstack([(a - a.mean(1, keepdims=True)) / np.std(a), (b - b.mean(1, keepdims=True)) / np.std(b)])
+    S_ref = np.linalg.svd(Xc, compute_uv=False)
+    np.testing.assert_allclose(spr.S_[:r], S_ref[:r], rtol=1e-9)

@@ -7,7 +7,7 @@ import scipy.sparse as sp
 
 from openmeasure_amd.sparse_sensing import ROM, SPR
 from tests.numpy_engine import NumpyEngine
-from tests.parity import (run_conditioning_guard, run_f32_storage, run_gem_beyond_rank, run_fixture, run_gem_fixture, run_gpr_style,
+from tests.parity import (run_conditioning_guard, run_documented_idioms, run_f32_storage, run_gem_beyond_rank, run_fixture, run_gem_fixture, run_gpr_style,
                           run_pinv_fixture)
 
 
@@ -243,3 +243,92 @@ def test_fit_with_given_basis(small):                  # :493-497
     assert spr2.r == 3
     np.testing.assert_allclose(spr2.Sigma_r, spr.Sigma_r)
     np.testing.assert_allclose(spr2.reconstruct(Ar[1]), spr.reconstruct(Ar[1]))
+
+
+@pytest.mark.parametrize('name', ['g2_num4', 'g3_num8', 'f32_g2_num4'])
+def test_documented_idioms_on_one_hot_rows(name, monkeypatch):        # README.md:160-184, INTEGRATION.md
+    from tests.conftest import load_golden
+    run_documented_idioms(load_golden(name), NumpyEngine(), monkeypatch)
+
+
+def test_one_hot_rows_matrix_semantics():
+    from openmeasure_amd.sparse_sensing import OneHotRows
+    rng = np.random.default_rng(3)
+    rows = np.array([7, 2, 11, 2])
+    C, D = OneHotRows(rows, 12), np.zeros((4, 12))
+    D[np.arange(4), rows] = 1.0
+    x, Xm = rng.standard_normal(12), rng.standard_normal((12, 3))
+    np.testing.assert_array_equal(np.asarray(C), D)
+    np.testing.assert_array_equal(C.toarray(), D)
+    np.testing.assert_array_equal(C.tocsr().toarray(), D)
+    np.testing.assert_array_equal(C @ x, D @ x)
+    np.testing.assert_array_equal(C.dot(Xm), D.dot(Xm))
+    np.testing.assert_array_equal(np.eye(4) @ C, D)
+    np.testing.assert_array_equal(np.argmax(C, axis=1), np.argmax(D, axis=1))
+    assert np.argmax(C) == np.argmax(D) and np.argmax(C[2, :]) == 11 and np.argmax(C[2]) == 11
+    assert C[1, 2] == 1.0 and C[1, 3] == 0.0 and C[-1, :].argmax() == 2
+    assert C.shape == D.shape and len(C) == 4 and C.ndim == 2 and C[0, :].shape == (12,) and C.dtype == D.dtype
+    np.testing.assert_array_equal(np.asarray(C[1:3]), D[1:3])
+    np.testing.assert_array_equal(np.asarray(C[0, :]), D[0, :])
+    np.testing.assert_array_equal(C[:, 2:9], D[:, 2:9])
+    np.testing.assert_array_equal(C.sum(axis=1), D.sum(axis=1))
+    np.testing.assert_array_equal(C.sum(axis=0), D.sum(axis=0))
+    assert C.sum() == D.sum() == 4
+    with pytest.raises(ValueError):
+        C @ np.ones(5)
+    with pytest.raises(IndexError):
+        C[4, :]
+    with pytest.raises(IndexError):
+        OneHotRows([12], 12)
+    big = OneHotRows([5, 10 ** 9], 2 * 10 ** 9)                     # config-5-sized: nothing dense may be built
+    with pytest.raises(MemoryError):
+        np.asarray(big)
+    assert np.argmax(big[1, :]) == 10 ** 9 and big.tocsr().shape == (2, 2 * 10 ** 9)
+
+
+def test_state_read_before_fit_raises_attribute_error(small):        # the reference's attributes do not exist yet
+    X, F, xyz = small
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    for attr in ('Ur', 'X_cnt', 'X_scl', 'X0', 'Ar', 'Sigma_r', 'Vr'):
+        with pytest.raises(AttributeError):
+            getattr(spr, attr)
+    with pytest.raises(AttributeError):
+        spr.optimal_placement()
+    with pytest.raises(AttributeError):
+        spr.reconstruct(np.ones(3))
+    with pytest.raises(AttributeError):
+        spr.train(np.zeros((2, X.shape[0])))
+    with pytest.raises(AttributeError):
+        spr.unscale_data(np.ones(X.shape[0]))
+
+
+@pytest.mark.parametrize('m', [12, 40])
+def test_constant_feature_and_nan_raise_linalgerror(m):            # :169 -> :272: nan X0 -> 'SVD did not converge'
+    rng = np.random.default_rng(m)
+    X = rng.standard_normal((60, m))
+    Xc = X.copy(); Xc[30:] = 3.0          # feature 1 constant (a value whose mean is exact): X_scl = 0 exactly, X0 = 0/0
+    Xn = X.copy(); Xn[7, 3] = np.nan
+    Xi = X.copy(); Xi[41, 0] = np.inf
+    for bad in (Xc, Xn, Xi):
+        spr = SPR(bad, 2, None, engine=NumpyEngine())
+        with pytest.raises(np.linalg.LinAlgError):
+            with np.errstate(all='ignore'):
+                spr.fit(select_modes='number', n_modes=3)
+
+
+def test_partial_row_group_with_absent_features():
+    """RowShard(partial=True): a block that holds rows of features 0 and 1 of F = 4 -- features 2 and 3 have no rows, take
+    no part (scale 1) and must not turn the Gram matrix into 0/0 (the merge on the host; csrc/combine.hip on the GPU)."""
+    from openmeasure_amd.sparse_sensing import RowShard
+    n_points, F, m, r = 900, 4, 40, 6
+    X = _synth(n_points, F, m, 12, 0.7, 1e-3, 31)
+    row0, n_loc = 300, 1200
+    blk = np.ascontiguousarray(X[row0:row0 + n_loc])
+    for scale_type in ('std', 'range'):                                 # device-merge scalings and the host-merge ones
+        spr = SPR(blk, F, None, shard=RowShard(row0, n_points * F, partial=True), engine=NumpyEngine())
+        spr.fit(scale_type=scale_type, select_modes='number', n_modes=r)
+        assert np.isfinite(spr.S_).all() and np.isfinite(spr.Ur).all()
+        np.testing.assert_array_equal(spr._scl_f[2:], 1.0)
+    a, b = blk[:600], blk[600:]
+    Xc = np.vstack([(a - a.mean(1, keepdims=True)) / (a.max() - a.min()), (b - b.mean(1, keepdims=True)) / (b.max() - b.min())])
+    np.testing.assert_allclose(spr.S_[:r], np.linalg.svd(Xc, compute_uv=False)[:r], rtol=1e-9)

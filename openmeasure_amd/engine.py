@@ -35,6 +35,8 @@ class HipEngine:
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         self._ws = {}
         self._timing = {}
+        import os
+        self._force_stream = os.environ.get('SPR_PROJECT_STREAM') == '1'   # A/B runs: streamed-W projection for every shape
         self._stage = None                                   # ring of pinned host staging buffers for small uploads
         self._dstage = None                                  # pinned landing buffer for small downloads
 
@@ -293,7 +295,7 @@ class HipEngine:
         xp = X.data_ptr() + i0 * ld * X.element_size()
         mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
         st = self._stream()
-        if m > _lib.SPR_MAX_M or (precenter and center):
+        if m > _lib.SPR_MAX_M or (precenter and center) or self._force_stream:
             name = 'spr_project_stream_f64' if not f32 else ('spr_project_stream_x32_f64out' if out_f64 else
                                                              'spr_project_stream_x32')
             nbytes = self.lib.spr_project_stream_workspace(m, q, int(f32))

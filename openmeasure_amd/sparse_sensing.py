@@ -305,10 +305,10 @@ class _Trace:
 _BLAS_CTL = None
 
 
-def _eigh_small(G):
-    """LAPACK dsyevd on the (m, m) Gram matrix with the BLAS pool capped: the problem is far too
-    small for a many-core pool (128 threads made it 10x slower on the GPU host).  The threadpoolctl
-    controller is built once -- discovering the loaded BLAS libraries costs more than the solve."""
+def _one_blas_thread():
+    """Context manager capping the BLAS pool at one thread: the m x m problems between the two passes over X are far too
+    small for a many-core pool (128 threads made the 256 x 256 eigen-solve 10x slower on the GPU host).  The
+    threadpoolctl controller is built once -- discovering the loaded BLAS libraries costs more than the solve."""
     global _BLAS_CTL
     if _BLAS_CTL is None:
         try:
@@ -317,9 +317,22 @@ def _eigh_small(G):
         except ImportError:                               # pragma: no cover
             _BLAS_CTL = False
     if not _BLAS_CTL:
-        return np.linalg.eigh(G)
-    with _BLAS_CTL.limit(limits=1, user_api='blas'):       # tools/eigh_probe.py: 1 thread is fastest for m <= 512
-        return np.linalg.eigh(G)
+        import contextlib
+        return contextlib.nullcontext()
+    return _BLAS_CTL.limit(limits=1, user_api='blas')       # tools/eigh_probe.py: 1 thread is fastest for m <= 512
+
+
+def _eigh_small(G):
+    """All eigenpairs of the symmetric (m, m) matrix G (ascending): LAPACK dsyevd called directly on one BLAS thread --
+    2.65 ms at m = 256 on the GPU host against 3.0 ms through np.linalg.eigh (and 4 ms / 95 ms at m = 256 / 512 with the
+    host's default 128-thread pool).  A route that computes only the r retained eigenvectors (dsytrd + dstemr + dormqr)
+    was tried in round 3 and dropped: 4.75 ms on that host, slower than dsyevd on everything."""
+    from scipy.linalg import lapack
+    with _one_blas_thread():
+        w, v, info = lapack.dsyevd(np.asarray(G, dtype=np.float64).T, compute_v=1, lower=1)   # G.T: Fortran view, no copy
+    if info != 0:
+        raise np.linalg.LinAlgError('Eigenvalues did not converge')
+    return w, v
 
 
 def pivot_loop(eng, st, s, all_gather=None, start=0, near=None):
@@ -835,6 +848,11 @@ class ROM:
             o += a.size
         return tuple(out)
 
+    @staticmethod
+    def _expvar(lam):
+        lam_pos = np.maximum(lam, 0.0)
+        return 100 * np.cumsum(lam_pos) / np.sum(lam_pos)      # :274-275
+
     def _spectrum(self, G):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
         if not np.all(np.isfinite(G)):
@@ -844,10 +862,8 @@ class ROM:
         lam, V = self._same_on_all_ranks(lam, V)
         lam = lam[::-1]
         V = _sign_fix(V[:, ::-1])
-        lam_pos = np.maximum(lam, 0.0)
-        S = np.sqrt(lam_pos)
-        exp_variance = 100 * np.cumsum(lam_pos) / np.sum(lam_pos)
-        return S, V, exp_variance
+        S = np.sqrt(np.maximum(lam, 0.0))
+        return S, V, self._expvar(lam)
 
     def _refine_spectrum(self, S, V, r, Xd, row0, n_points, n_features, inv_scale_d, rowmean_d, center):
         """Conditioning safeguard of the Gram route (hard part 1).
@@ -925,6 +941,7 @@ class ROM:
         floor = S[0] * np.sqrt(m * np.finfo(float).eps) if not self.gram_refine_passes_ else S[0] * m * np.finfo(float).eps
         S_safe = np.maximum(S[:r], floor if floor > 0 else 1.0)
         W = V[:, :r] / S_safe
+        self._trace.mark('W')
         W_d = eng.to_device(W)
         self._trace.mark('upload')
         self.precentered_ = bool(center and self._needs_precenter(S[0] / S_safe[-1]))

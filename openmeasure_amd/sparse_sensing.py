@@ -1246,12 +1246,20 @@ class SPR(ROM):
         Uc = Ua - Ua.mean(axis=1, keepdims=True)
         var_max = np.sum(Uc[0] ** 2) / (r - 1)                 # the first pick is the row of largest variance (:641)
         dprime = self._GEM_RIDGE * var_max / 4.0 * (r - 1)
-        lam, Qe = np.linalg.eigh(Uc.T @ Uc)
-        lam = np.maximum(lam, 0.0)
+        # spectral form of A = Uc^T Uc + d' I INSIDE the centred space (orthogonal to 1): eigen-decompose P Uc^T Uc P with
+        # P = I - 1 1^T / r and keep the r - 1 eigenvectors orthogonal to 1 -- also when the picked rows are numerically
+        # dependent (duplicated rows of Ur, a mask / d_min that leaves fewer than r - 1 independent rows): the null
+        # directions then simply carry lam = 0 and stay orthonormal instead of mixing with the 1-direction
         one = np.full(r, r ** -0.5)
-        Qe = Qe - np.outer(one, one @ Qe)                       # eigenvectors inside the centred space
-        keep = np.linalg.norm(Qe, axis=0) > 0.5                 # drops the eigenvector along 1
-        lam, Qe = lam[keep], Qe[:, keep] / np.linalg.norm(Qe[:, keep], axis=0)
+        P = np.eye(r) - np.outer(one, one)
+        lam, Qe = np.linalg.eigh(P @ (Uc.T @ Uc) @ P)
+        along = np.abs(one @ Qe)                                # exactly one eigenvector lies along 1 (eigenvalue 0)
+        keep = np.ones(r, dtype=bool)
+        keep[int(np.argmax(along))] = False
+        lam, Qe = np.maximum(lam[keep], 0.0), Qe[:, keep]
+        Qe = Qe - np.outer(one, one @ Qe)
+        Qe, _ = np.linalg.qr(Qe)                                # r - 1 orthonormal columns spanning the centred space
+        lam = np.maximum(np.einsum('ij,ij->j', Qe, (Uc.T @ Uc) @ Qe), 0.0)
         Ainv = (Qe / (lam + dprime)) @ Qe.T
         # residual array from scratch: v = |u_c|^2 - sum_k lam_k/(lam_k + d') (q_k.u)^2
         st2 = eng.qr_begin(Ur_d, self._row0, s + 1)
@@ -1262,8 +1270,14 @@ class SPR(ROM):
             for j0 in range(1, s_exact + 1, eng.qr_batch):
                 eng.qr_exclude(st2, xyz=near[0], n_points=near[1], j0=j0, nq=min(eng.qr_batch, s_exact + 1 - j0),
                                d_min=near[2])
-        dirs = np.vstack([one[None, :], (Qe * np.sqrt(lam / (lam + dprime))).T])
-        picks0 = np.concatenate([[-1], piv, -np.ones(dirs.shape[0] - 1 - s_exact, dtype=np.int64)])[:dirs.shape[0]]
+        dirs = np.vstack([one[None, :], (Qe * np.sqrt(lam / (lam + dprime))).T])     # r directions: centring + r - 1
+        # every picked row leaves the pool, whatever the number of directions: pad the pick list to the directions (and
+        # apply any picks beyond them with zero directions)
+        n_slots = max(dirs.shape[0], s_exact + 1)
+        picks0 = np.full(n_slots, -1, dtype=np.int64)
+        picks0[1:s_exact + 1] = piv
+        if n_slots > dirs.shape[0]:
+            dirs = np.vstack([dirs, np.zeros((n_slots - dirs.shape[0], r))])
         eng.qr_apply(st2, eng.to_device(dirs), eng.to_device(picks0, dtype=t.int64))
         sweeps = 1 + -(-dirs.shape[0] // eng.qr_batch)
         for j in range(s_exact + 1, s + 1):

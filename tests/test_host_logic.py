@@ -332,3 +332,19 @@ def test_partial_row_group_with_absent_features():
     a, b = blk[:600], blk[600:]
     Xc = np.vstack([(a - a.mean(1, keepdims=True)) / (a.max() - a.min()), (b - b.mean(1, keepdims=True)) / (b.max() - b.min())])
     np.testing.assert_allclose(spr.S_[:r], np.linalg.svd(Xc, compute_uv=False)[:r], rtol=1e-9)
+
+
+def test_gem_ridge_phase_with_dependent_picks():
+    """calc_type='gem' beyond r-1 sensors when the first r-1 picks are numerically dependent (rows of Ur that span only
+    part of the centred space, with exact duplicates): the ridge phase must neither raise nor pick a row twice."""
+    rng = np.random.default_rng(8)
+    n_points, F, r = 60, 2, 6
+    n = n_points * F
+    B = rng.standard_normal((3, r))                                  # rows of Ur live in a 3-dimensional subspace
+    Ur = rng.standard_normal((n, 3)) @ B
+    Ur[10] = Ur[3]; Ur[77] = Ur[3]                                   # exact duplicates
+    spr = SPR(rng.standard_normal((n, 4)), F, rng.random((n_points, 3)), engine=NumpyEngine())
+    spr.fit(basis=(Ur.copy(), np.eye(4, r)))
+    C = spr.optimal_placement(calc_type='gem', n_sensors=r + 3)
+    assert C.shape == (r + 3, n)
+    assert len(set(spr.sensors_.tolist())) == r + 3 and spr.sensors_.min() >= 0

@@ -346,13 +346,15 @@ int spr_synth_gather_f64(const int64_t *d_rows, int32_t n, int64_t n_points, int
                          uint64_t seed, double *d_out, void *stream);
 
 /* ---- f32 STORAGE (BASELINE config 5: 50M cells x 16 features x 512 snapshots does not fit 8 x 288 GB in f64) ----
- * The reference keeps X in whatever float dtype the caller passes (sparse_sensing.py:74) and its U then has that
- * dtype too (np.linalg.svd :272).  These entry points take the snapshot shard (suffix _x32) or the basis (suffix
- * _u32) as float, widen every element on load and do ALL arithmetic in f64 exactly like their _f64 twins -- same
- * arguments, same outputs (row means, statistics, Gram blocks, norms, Theta, fields stay double); only
- * spr_project_x32 writes float, the f64 result rounded once.  Two-element pieces: rows 8-byte aligned and an even
- * m / ld take the vector path.  Parity is therefore defined on the stored values: bit-exact sensors against the
- * oracle run on the same f32-rounded basis widened to f64. */
+ * The reference keeps X in whatever float dtype the caller passes (sparse_sensing.py:74); its X_cnt / X_scl are float64
+ * (np.zeros, :106-107), so X0 = (X - X_cnt)/X_scl (:169) and the U of its SVD (:272) are float64 whatever that dtype is.
+ * These entry points take the snapshot shard as float (suffix _x32), widen every element on load and do ALL arithmetic
+ * in f64 exactly like their _f64 twins -- same arguments, same outputs (row means, statistics, Gram blocks, norms, Theta,
+ * fields stay double).  The basis is float64 by default (spr_project_x32_f64out, spr_project_stream_x32_f64out); storing
+ * it as float as well is a STORAGE OPTION the reference does not have (spr_project_x32 / spr_project_stream_x32 write the
+ * f64 result rounded once; the _u32 twins read such a basis), for shards whose f64 basis would not fit.  Two-element
+ * pieces: rows 8-byte aligned and an even m / ld take the vector path.  With a float basis, parity of the sensors is
+ * checked against both the reference's choice (pivots of the f64 basis) and dgeqp3 on the stored basis widened to f64. */
 int spr_stats_gram_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                        int64_t n_points, int32_t n_features, int32_t center, double *d_rowmean,
                        void *d_workspace, size_t workspace_bytes, void *stream);

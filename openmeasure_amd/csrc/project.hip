@@ -42,8 +42,8 @@ constexpr int NW = 8;
 
 template <int MT> struct ProjRows { static constexpr int R = (MT >= 12) ? 32 : 64; };
 
-// TX: storage type of the snapshot shard, TU: storage type of the basis (f64, or f32 rounded from the f64 result --
-// the reference's own U has the dtype of its X); the arithmetic is f64 either way.
+// TX: storage type of the snapshot shard, TU: storage type of the basis -- f64 (the reference's U is float64 for any
+// dtype of X, :106-107, :169) or, as a storage option, f32 rounded once from the f64 result; the arithmetic is f64 either way.
 template <int MT, int RTILES, int VEC, typename TX, typename TU, bool ACCIN>
 __global__ __launch_bounds__(NW * 64) void project_kernel(
     const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
@@ -264,7 +264,7 @@ int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int
   // W-stationary form first (project_ws.hip): W in LDS, X straight into the MFMA operand registers, no barrier in the
   // loop -- 15 % faster where both pipes are loaded (m = 256, r = 64).  SPR_PROJECT_WS=0 forces the general kernel
   // (A/B measurements, and the parity tests run both).
-  if constexpr (std::is_same<TX, TU>::value) {
+  if constexpr (std::is_same<TX, TU>::value || std::is_same<TU, double>::value) {
     static const bool ws_on = [] { const char *e = getenv("SPR_PROJECT_WS"); return !(e && e[0] == '0'); }();
     if (ws_on && !d_acc_in && n_rows >= 4096) {
       const int rc = spr_project_ws<TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,

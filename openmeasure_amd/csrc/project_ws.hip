@@ -236,4 +236,8 @@ template int spr_project_ws<double, double>(const double *, int64_t, int32_t, in
 template int spr_project_ws<float, float>(const float *, int64_t, int32_t, int64_t, int64_t, int64_t, int32_t, int32_t,
                                           const double *, const double *, const double *, int32_t, float *, int64_t,
                                           int32_t, hipStream_t);
+// f32 shard, f64 basis: the default for a float32 X (the reference's U is float64 whatever the dtype of X)
+template int spr_project_ws<float, double>(const float *, int64_t, int32_t, int64_t, int64_t, int64_t, int32_t, int32_t,
+                                           const double *, const double *, const double *, int32_t, double *, int64_t,
+                                           int32_t, hipStream_t);
 #endif

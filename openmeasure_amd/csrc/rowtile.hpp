@@ -226,6 +226,64 @@ struct RowTile {
     }
   }
 
+  // ---- own-means fast lane of the m = 16 MT Gram kernels (centre mode 1, packed 16-byte-aligned rows, m == MPAD) -----
+  // Every f64 VALU instruction of the staging comes out of the f64 MFMA pipe's time (tools/coexec_probe.hip), so this
+  // pair does the same work as load_pass / center_store_pass with fewer of them: the row pointer is a per-lane offset
+  // added to a wave-uniform base (no 64-bit multiply per pass), the centre mode is a compile-time fact (no selects, no
+  // mean load), the per-feature statistics are taken afterwards from the n row means (no running sums in the loop).
+  // lane_off = (wave * RPW + grp) * ldx elements, computed once; ubase = X + crow0 * ldx (wave-uniform);
+  // rows_left = seg_hi - crow0 (wave-uniform, may be <= 0 for the past-the-end panel).
+  // EXT: the row means come from mean_in (centre mode 2: a column slice of a wider matrix, whose means are those of the
+  // full rows) -- loaded with the row, no row sum at all; else they are formed here and written (centre mode 1).
+  template <bool EXT>
+  __device__ inline void load_pass_own(int it, const TX *__restrict__ ubase, int64_t ldx, int64_t lane_off,
+                                       int64_t rows_left, int wave, int lane, const double *__restrict__ mean_in,
+                                       int64_t crow0) {
+    const int grp = lane / LPR, lig = lane % LPR;
+    const int64_t lrow = (int64_t)it * ROWS_PER_IT + wave * RPW + grp;          // row inside the panel
+    // rows past the segment end re-read the segment's last row (never stored): one compare + select on the offset
+    const int64_t last = rows_left > 0 ? rows_left - 1 : 0;
+    const bool in = lrow < rows_left;
+    const int64_t off = in ? lane_off + (int64_t)it * ROWS_PER_IT * ldx : last * ldx;
+    const TX *rp = ubase + off;
+    if (EXT) pmean[it] = mean_in[crow0 + (in ? lrow : last)];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) pre[it][v] = *reinterpret_cast<const Piece *>(rp + 2 * (lig + v * LPR));
+  }
+
+  template <bool FULL, bool EXT>   // FULL: the whole pass lies inside the segment (wave-uniform, chosen by the caller): no selects
+  __device__ inline void center_store_own(int it, double *__restrict__ lds, int64_t crow0, int64_t rows_left, int wave,
+                                          int lane, double *__restrict__ rowmean) {
+    const int grp = lane / LPR, lig = lane % LPR;
+    constexpr double inv_m = 1.0 / (double)MPAD;
+    const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
+    const bool rv = FULL || rloc < rows_left;
+    f64x2 w[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) w[v] = widen(pre[it][v]);
+    double mean;
+    if (EXT) {
+      mean = pmean[it];
+    } else {
+      double s = w[0].x + w[0].y;
+#pragma unroll
+      for (int v = 1; v < VPL; ++v) s += w[v].x + w[v].y;
+      s = group_sum_t<LPR>(s);
+      mean = s * inv_m;
+      if (rv && lig == 0) rowmean[crow0 + rloc] = mean;
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int col = 2 * (lig + v * LPR);
+      f64x2 c = {w[v].x - mean, w[v].y - mean};
+      if (!FULL) {                               // rows past the segment end (re-reads of its last row) contribute zeros
+        c.x = rv ? c.x : 0.0;
+        c.y = rv ? c.y : 0.0;
+      }
+      *reinterpret_cast<f64x2 *>(lds + rloc * MP + col) = c;
+    }
+  }
+
   // one pass of registers -> LDS without centring (the consumer removes the row mean
   // algebraically); invalid rows / padded columns are written as zeros
   __device__ inline void raw_store_pass(int it, double *__restrict__ lds, int m, int64_t crow0, int64_t seg_hi,

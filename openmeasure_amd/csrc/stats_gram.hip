@@ -13,6 +13,10 @@
 // so both operands of tile (ti,tj) are "16 consecutive doubles of panel row k0+(l>>4)":
 // conflict-free ds_read_b64 when consecutive rows sit 32 banks apart (MP == 16 mod 32).
 // The result lane map is col = l&15, row = (l>>4) + 4*reg.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "rowtile.hpp"
 
 #ifndef GRAM_ABLATE
@@ -192,6 +196,179 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
   }
 }
 
+__device__ inline void chan_merge(double &n, double &mu, double &m2, double nb, double mb, double sb) {
+  if (nb > 0.0) {
+    const double tot = n + nb, d = mb - mu;
+    mu += d * nb / tot;
+    m2 += sb + d * d * n * nb / tot;
+    n = tot;
+  }
+}
+
+// Own-means lane of gram_wave (centre mode 1, m == 16 MT, packed 16-byte-aligned rows: the shape of the BASELINE
+// workloads): the same tiles, operand reads and one-barrier pipeline, but the staging goes through load_pass_own /
+// center_store_own of rowtile.hpp (pointer offsets instead of a 64-bit row multiply, no centre-mode selects, no mean load,
+// no running statistics: gram_rowmean_stats_kernel forms those from the n row means afterwards).
+template <int MT, int U, typename TX, bool EXT>
+__device__ inline void gram_wave_own(const TX *__restrict__ X, int64_t ldx, int64_t lo, int64_t hi, int wl, int wpf, int ks,
+                                     int wave, int lane, double *__restrict__ lds0, double *__restrict__ lds1,
+                                     double *__restrict__ rowmean, double *__restrict__ slab) {
+  using S = GramShape<MT>;
+  using C = GramCfg<MT>;
+  constexpr int R = C::R, KS = C::KS, NW = C::NW, MP = S::MP, T = S::T;
+  constexpr int KROWS = R / KS, KSTEPS = KROWS / 4;
+  constexpr int RA = U, RB = MT - 1 - U;
+  constexpr int NA = MT - RA;
+  constexpr int NB = (RB != RA) ? MT - RB : 0;
+  using RT = RowTile<MT, R, MP, NW, C::LPRMAX, TX>;
+
+  f64x4 accA[NA];
+  f64x4 accB[NB > 0 ? NB : 1];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) accA[j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < NB; ++j) accB[j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  RT tile;
+  const int64_t nchunks = (hi - lo + R - 1) / R;
+  const int64_t lane_off = (int64_t)(wave * RT::RPW + lane / RT::LPR) * ldx;
+  auto base_of = [&](int64_t row0) { return X + row0 * ldx; };       // wave-uniform: scalar arithmetic
+  int64_t c = wl;
+  int64_t crow0 = lo + c * R;
+#pragma unroll
+  for (int it = 0; it < RT::IT; ++it) tile.template load_pass_own<EXT>(it, base_of(crow0), ldx, lane_off, hi - crow0, wave, lane, rowmean, crow0);
+  if (crow0 + R <= hi) {
+#pragma unroll
+    for (int it = 0; it < RT::IT; ++it) tile.template center_store_own<true, EXT>(it, lds0, crow0, hi - crow0, wave, lane, rowmean);
+  } else {
+#pragma unroll
+    for (int it = 0; it < RT::IT; ++it) tile.template center_store_own<false, EXT>(it, lds0, crow0, hi - crow0, wave, lane, rowmean);
+  }
+  int64_t cn = c + wpf;
+  int64_t nrow0 = (cn < nchunks) ? lo + cn * R : hi;
+#pragma unroll
+  for (int it = 0; it < RT::IT; ++it) tile.template load_pass_own<EXT>(it, base_of(nrow0 < hi ? nrow0 : lo), ldx, lane_off, hi - nrow0, wave, lane, rowmean, nrow0 < hi ? nrow0 : lo);
+  int buf = 0;
+  const int frag = (lane >> 4) * MP + (lane & 15) + ks * KROWS * MP + RA * 16;
+  while (c < nchunks) {
+    double *cur = buf ? lds1 : lds0;
+    double *nxt = buf ? lds0 : lds1;
+    const int64_t c2 = cn + wpf;
+    const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * R : hi;
+    const TX *n2base = base_of(n2row0 < hi ? n2row0 : lo);
+    const bool nfull = nrow0 + R <= hi;                    // wave-uniform
+    __syncthreads();
+    const double *p = cur + frag;
+    auto stage = [&](auto full_tag, int k) {
+      constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+      for (int it = 0; it < RT::IT; ++it)
+        if ((it * KSTEPS) / RT::IT == k) {
+          tile.template center_store_own<FULL, EXT>(it, nxt, nrow0, hi - nrow0, wave, lane, rowmean);
+          tile.template load_pass_own<EXT>(it, n2base, ldx, lane_off, hi - n2row0, wave, lane, rowmean, n2row0 < hi ? n2row0 : lo);   // panel c+2
+        }
+    };
+    if constexpr (C::DBUF) {
+      double op[2][NA];
+#pragma unroll
+      for (int j = 0; j < NA; ++j) op[0][j] = p[16 * j];
+#pragma unroll
+      for (int k = 0; k < KSTEPS; ++k) {
+        if (k + 1 < KSTEPS) {
+#pragma unroll
+          for (int j = 0; j < NA; ++j) op[(k + 1) & 1][j] = p[(k + 1) * 4 * MP + 16 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) accA[j] = GRAM_MFMA(op[k & 1][0], op[k & 1][j], accA[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) accB[j] = GRAM_MFMA(op[k & 1][RB - RA], op[k & 1][RB - RA + j], accB[j]);
+        if (nfull) stage(std::true_type{}, k); else stage(std::false_type{}, k);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KSTEPS; ++k) {
+        double op[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) op[j] = p[k * 4 * MP + 16 * j];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) accA[j] = GRAM_MFMA(op[0], op[j], accA[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) accB[j] = GRAM_MFMA(op[RB - RA], op[RB - RA + j], accB[j]);
+        if (nfull) stage(std::true_type{}, k); else stage(std::false_type{}, k);
+      }
+    }
+    buf ^= 1;
+    c = cn;
+    cn = c2;
+    nrow0 = n2row0;
+  }
+  double *sp = slab + ((int64_t)blockIdx.x * KS + ks) * T * 256 + lane;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    double *tp = sp + (int64_t)tri_index(MT, RA, RA + j) * 256;
+    tp[0] = accA[j].x; tp[64] = accA[j].y; tp[128] = accA[j].z; tp[192] = accA[j].w;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double *tp = sp + (int64_t)tri_index(MT, RB, RB + j) * 256;
+    tp[0] = accB[j].x; tp[64] = accB[j].y; tp[128] = accB[j].z; tp[192] = accB[j].w;
+  }
+}
+
+template <int MT, typename TX, bool EXT>
+__global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_own_kernel(
+    const TX *__restrict__ X, int64_t ldx, SegPlan plan, double *__restrict__ rowmean, double *__restrict__ slab) {
+  using S = GramShape<MT>;
+  using C = GramCfg<MT>;
+  constexpr int NU = S::NU;
+  __shared__ double lds[2][C::R * S::MP];
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int unit = wave % NU, ks = wave / NU;
+#define GRAM_UNIT(UV)                                                                                          \
+  case UV:                                                                                                     \
+    if constexpr (UV < NU)                                                                                     \
+      gram_wave_own<MT, UV, TX, EXT>(X, ldx, lo, hi, wl, wpf, ks, wave, lane, lds[0], lds[1], rowmean, slab);       \
+    break;
+  switch (unit) {
+    GRAM_UNIT(0) GRAM_UNIT(1) GRAM_UNIT(2) GRAM_UNIT(3) GRAM_UNIT(4) GRAM_UNIT(5) GRAM_UNIT(6) GRAM_UNIT(7)
+    default: break;
+  }
+#undef GRAM_UNIT
+}
+
+// Per-feature statistics (count, mean, M2) of the row means the own-means kernel has written, in the slot layout
+// gram_finalize_kernel merges: same grid and SegPlan as the Gram launch, block b reduces the means of its feature's rows
+// b, b + wpf, ... (256-row chunks) to ONE triple in its first slot (fixed order: reproducible) and zeroes its other slots.
+__global__ __launch_bounds__(256) void gram_rowmean_stats_kernel(const double *__restrict__ rowmean, SegPlan plan,
+                                                                 int slots_per_wg, double *__restrict__ stat_part) {
+  __shared__ double sn[4], smu[4], sm2[4];
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  RowStats st;
+  st.init();
+  for (int64_t row = lo + (int64_t)wl * 256 + threadIdx.x; row < hi; row += (int64_t)wpf * 256) st.push(rowmean[row], true);
+  double n = st.cnt, mu = st.mean(), m2 = st.m2();
+  for (int o = 32; o > 0; o >>= 1) {
+    const double on = __shfl_down(n, o, 64), om = __shfl_down(mu, o, 64), os = __shfl_down(m2, o, 64);
+    chan_merge(n, mu, m2, on, om, os);
+  }
+  if (lane == 0) { sn[wave] = n; smu[wave] = mu; sm2[wave] = m2; }
+  __syncthreads();
+  double *q = stat_part + (int64_t)blockIdx.x * slots_per_wg * 3;
+  if (threadIdx.x == 0) {
+    n = 0.0; mu = 0.0; m2 = 0.0;
+    for (int w = 0; w < 4; ++w) chan_merge(n, mu, m2, sn[w], smu[w], sm2[w]);
+    q[0] = n; q[1] = mu; q[2] = m2;
+  }
+  for (int e = 3 + threadIdx.x; e < slots_per_wg * 3; e += 256) q[e] = 0.0;
+}
+
 template <int MT, int VEC, typename TX>
 __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
     const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
@@ -220,15 +397,6 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
     default: break;
   }
 #undef GRAM_UNIT
-}
-
-__device__ inline void chan_merge(double &n, double &mu, double &m2, double nb, double mb, double sb) {
-  if (nb > 0.0) {
-    const double tot = n + nb, d = mb - mu;
-    mu += d * nb / tot;
-    m2 += sb + d * d * n * nb / tot;
-    n = tot;
-  }
 }
 
 // grid (T, n_features), 1024 threads: fixed-order sum of the slabs of feature f for one tile.
@@ -354,6 +522,27 @@ int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, in
 #define SG_LAUNCH(LM)                                                                                         \
   hipLaunchKernelGGL((stats_gram_kernel<MT, LM, TX>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m, \
                      center, plan, rowmean, stat_part, slab)
+  // own-means lane: centre mode 1 on packed, 16-byte-aligned rows of exactly 16 MT columns, MFMA-bound widths only
+  // (below m = 128 the pass is HBM-bound and the extra statistics launch would cost more than the VALU work it saves)
+  using RTL = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW, GramCfg<MT>::LPRMAX, TX>;
+  static const bool own_on = [] { const char *e = getenv("SPR_GRAM_OWN"); return !(e && e[0] == '0'); }();
+  if (MT >= 8 && lm == 2 && (center == 1 || center == 2) && own_on && (sizeof(TX) * ldx) % 16 == 0 &&
+      (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    if constexpr (MT >= 8) {
+      if (center == 1)
+        hipLaunchKernelGGL((stats_gram_own_kernel<MT, TX, false>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, plan,
+                           rowmean, slab);
+      else   // external means: a column slice of a wider matrix, centred with the means of the full rows
+        hipLaunchKernelGGL((stats_gram_own_kernel<MT, TX, true>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, plan,
+                           rowmean, slab);
+      SPR_LAUNCH_CHECK();
+      // statistics of the row means (own or external: the finalize call merges whatever the slots hold)
+      hipLaunchKernelGGL(gram_rowmean_stats_kernel, dim3(grid), dim3(256), 0, st, rowmean, plan, (int)RTL::ROWS_PER_IT,
+                         stat_part);
+      SPR_LAUNCH_CHECK();
+      return SPR_OK;
+    }
+  }
   if (lm == 2) SG_LAUNCH(2);
   else if (lm == 1) SG_LAUNCH(1);
   else SG_LAUNCH(0);

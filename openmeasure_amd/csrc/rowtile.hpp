@@ -238,7 +238,7 @@ struct RowTile {
   template <bool EXT>
   __device__ inline void load_pass_own(int it, const TX *__restrict__ ubase, int64_t ldx, int64_t lane_off,
                                        int64_t rows_left, int wave, int lane, const double *__restrict__ mean_in,
-                                       int64_t crow0) {
+                                       int64_t crow0, int split = 1 << 30, int64_t gap = 0) {
     const int grp = lane / LPR, lig = lane % LPR;
     const int64_t lrow = (int64_t)it * ROWS_PER_IT + wave * RPW + grp;          // row inside the panel
     // rows past the segment end re-read the segment's last row (never stored): one compare + select on the offset
@@ -248,7 +248,10 @@ struct RowTile {
     const TX *rp = ubase + off;
     if (EXT) pmean[it] = mean_in[crow0 + (in ? lrow : last)];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) pre[it][v] = *reinterpret_cast<const Piece *>(rp + 2 * (lig + v * LPR));
+    for (int v = 0; v < VPL; ++v) {
+      const int col = 2 * (lig + v * LPR);
+      pre[it][v] = *reinterpret_cast<const Piece *>(rp + col + (col >= split ? gap : 0));   // gap: see load_pass
+    }
   }
 
   template <bool FULL, bool EXT>   // FULL: the whole pass lies inside the segment (wave-uniform, chosen by the caller): no selects

@@ -18,7 +18,7 @@ for spec in "$@"; do
     rocprofv3 --pmc $ctr --output-format csv -d "$out/$ctr" -o run -- python3 bench.py --workload $wl $extra --steps 2 --warmup 1 --no-cpu > "$out/$ctr.json" 2> "$out/$ctr.err" || tail -3 "$out/$ctr.err"
   done
   python3 tools/pmc_summary.py $(find "$out" -name "*counter_collection.csv") > "$out/pmc_summary.txt" 2>&1
-  grep -E "stats_gram_kernel|project|reconstruct|gram_cross|rowstats" "$out/pmc_summary.txt" | cut -c1-200
+  grep -E "stats_gram|project|reconstruct|gram_cross|rowstats" "$out/pmc_summary.txt" | cut -c1-200
   f=$(find "$out/stats" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -8 "$f" | cut -c1-220
 done

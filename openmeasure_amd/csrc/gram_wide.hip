@@ -9,8 +9,6 @@
 // pass (rowstats_kernel: row means + per-feature Welford partials) and handed to the three Gram
 // launches as external means.  MFMA work is exactly the 528 tiles (136 + 136 + 256); X is read
 // 1 + 1 + 2 times instead of once, which at m > 256 is still far below the MFMA time.
-#include <stdlib.h>
-
 #include "rowtile.hpp"
 
 namespace {
@@ -113,10 +111,7 @@ constexpr int CMA = 256;     // width of A
 // OWN = true (centre mode 1): the row means are formed in this pass from the full rows the panel holds anyway (the
 // staging computes the row sums in every mode) and written to rowmean[] -- both flavours write the same bits --, so
 // the separate row-statistics pass over X is not needed; OWN = false: external means (mode 2) or none (mode 0).
-// FASTL: full-width packed panel (m == 256 + 16 NTJ, 16-byte-aligned rows) with centring (mode 1 or 2): the staging goes
-// through the own-means lane of rowtile.hpp (pointer offsets, compile-time centre mode, no running statistics) -- every
-// VALU instruction saved is MFMA time here: a 16-row panel only carries 64 MFMAs per wave.
-template <int NTJ, int VEC, typename TX, bool OWN, bool FASTL = false>
+template <int NTJ, int VEC, typename TX, bool OWN>
 __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restrict__ X, int64_t ldx, int m,
                                                             int center, SegPlan plan,
                                                             double *__restrict__ rowmean,
@@ -151,9 +146,21 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
   const double *mean_in = OWN ? nullptr : rowmean;
   const int64_t nchunks = (hi - lo + CR - 1) / CR;
   int64_t c = wl;
+  // m here is the PANEL width 256 + wB; panel columns >= 256 sit `gap` elements further along the row (0 when the two
+  // slices are adjacent, as for m <= 512)
+  tile.template load<VEC>(X, ldx, m, lo + c * CR, hi, wave, lane, mean_in, CMA, gap);
+  tile.template center_store<OWN>(lds[0], m, center, lo + c * CR, hi, wave, lane, OWN ? rowmean : nullptr, &st);
+  int64_t cn = c + wpf;
+  int64_t nrow0 = (cn < nchunks) ? lo + cn * CR : hi;
+  tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in, CMA, gap);
+  int buf = 0;
   const int frag = (lane >> 4) * MP + (lane & 15);
-  // the MFMA phase of one panel: wave's tile row of A against all NTJ tile columns of B; `stage` runs behind k-step 0
-  auto multiply = [&](const double *cur, auto &&stage) {
+  while (c < nchunks) {
+    double *cur = lds[buf];
+    double *nxt = lds[buf ^ 1];
+    const int64_t c2 = cn + wpf;
+    const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * CR : hi;
+    __syncthreads();
     const double *pa = cur + frag + 16 * ti;
     const double *pb = cur + frag + CMA;
 #pragma unroll
@@ -164,65 +171,15 @@ __global__ __launch_bounds__(CW * 64) void gram_cross_kernel(const TX *__restric
       for (int j = 0; j < NTJ; ++j) b[j] = pb[k * 4 * MP + 16 * j];
 #pragma unroll
       for (int j = 0; j < NTJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[j], 0, 0, 0);
-      if (k == 0) stage();
-    }
-  };
-  if constexpr (FASTL) {
-    constexpr bool EXT = !OWN;
-    const int64_t lane_off = (int64_t)(wave * RT::RPW + lane / RT::LPR) * ldx;
-    auto base_of = [&](int64_t row0) { return X + row0 * ldx; };
-    int64_t crow0 = lo + c * CR;
-    tile.template load_pass_own<EXT>(0, base_of(crow0), ldx, lane_off, hi - crow0, wave, lane, rowmean, crow0, CMA, gap);
-    if (crow0 + CR <= hi) tile.template center_store_own<true, EXT>(0, lds[0], crow0, hi - crow0, wave, lane, rowmean);
-    else tile.template center_store_own<false, EXT>(0, lds[0], crow0, hi - crow0, wave, lane, rowmean);
-    int64_t cn = c + wpf;
-    int64_t nrow0 = (cn < nchunks) ? lo + cn * CR : hi;
-    tile.template load_pass_own<EXT>(0, base_of(nrow0 < hi ? nrow0 : lo), ldx, lane_off, hi - nrow0, wave, lane, rowmean,
-                                     nrow0 < hi ? nrow0 : lo, CMA, gap);
-    int buf = 0;
-    while (c < nchunks) {
-      double *cur = lds[buf];
-      double *nxt = lds[buf ^ 1];
-      const int64_t c2 = cn + wpf;
-      const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * CR : hi;
-      const TX *n2base = base_of(n2row0 < hi ? n2row0 : lo);
-      const bool nfull = nrow0 + CR <= hi;
-      __syncthreads();
-      multiply(cur, [&]() {
-        if (nfull) tile.template center_store_own<true, EXT>(0, nxt, nrow0, hi - nrow0, wave, lane, rowmean);
-        else tile.template center_store_own<false, EXT>(0, nxt, nrow0, hi - nrow0, wave, lane, rowmean);
-        tile.template load_pass_own<EXT>(0, n2base, ldx, lane_off, hi - n2row0, wave, lane, rowmean,
-                                         n2row0 < hi ? n2row0 : lo, CMA, gap);
-      });
-      buf ^= 1;
-      c = cn;
-      cn = c2;
-      nrow0 = n2row0;
-    }
-  } else {
-    // m here is the PANEL width 256 + wB; panel columns >= 256 sit `gap` elements further along the row (0 when the two
-    // slices are adjacent, as for m <= 512)
-    tile.template load<VEC>(X, ldx, m, lo + c * CR, hi, wave, lane, mean_in, CMA, gap);
-    tile.template center_store<OWN>(lds[0], m, center, lo + c * CR, hi, wave, lane, OWN ? rowmean : nullptr, &st);
-    int64_t cn = c + wpf;
-    int64_t nrow0 = (cn < nchunks) ? lo + cn * CR : hi;
-    tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in, CMA, gap);
-    int buf = 0;
-    while (c < nchunks) {
-      double *cur = lds[buf];
-      double *nxt = lds[buf ^ 1];
-      const int64_t c2 = cn + wpf;
-      const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * CR : hi;
-      __syncthreads();
-      multiply(cur, [&]() {
+      if (k == 0) {
         tile.template center_store_pass<OWN>(0, nxt, m, center, nrow0, hi, wave, lane, OWN ? rowmean : nullptr, &st);
         tile.template load_pass<VEC>(0, X, ldx, m, n2row0, hi, wave, lane, mean_in, CMA, gap);
-      });
-      buf ^= 1;
-      c = cn;
-      cn = c2;
-      nrow0 = n2row0;
+      }
     }
+    buf ^= 1;
+    c = cn;
+    cn = c2;
+    nrow0 = n2row0;
   }
   // slab[(block >> 1)][ti][tj][reg][lane]   (the two flavours of a block pair write disjoint tile rows)
   double *sp = slab + (((int64_t)pair * 16 + ti) * NTJ) * 256 + lane;
@@ -284,13 +241,9 @@ int launch_cross(const TX *X, int64_t n_rows, int wB, int64_t ldx, int64_t row0,
   SPR_REQUIRE(ws_bytes >= need, SPR_E_WORKSPACE, "spr_gram_cross_f64: workspace %zu < %zu", ws_bytes, need);
   const int vec_ok = (m % 2 == 0) && (ldx % 2 == 0) && (gap % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & (2 * sizeof(TX) - 1)) == 0);
   double *slab = static_cast<double *>(ws);
-#define GXK(V, O, FL) hipLaunchKernelGGL((gram_cross_kernel<NTJ, V, TX, O, FL>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan, rowmean, slab, gap)
-  static const bool own_on = [] { const char *e = getenv("SPR_GRAM_OWN"); return !(e && e[0] == '0'); }();
-  const bool fastl = own_on && vec_ok && center != 0 && wB == 16 * NTJ && (sizeof(TX) * ldx) % 16 == 0 &&
-                     (sizeof(TX) * gap) % 16 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-  if (fastl) { if (center == 1) GXK(1, true, true); else GXK(1, false, true); }
-  else if (center == 1) { if (vec_ok) GXK(1, true, false); else GXK(0, true, false); }
-  else { if (vec_ok) GXK(1, false, false); else GXK(0, false, false); }
+#define GXK(V, O) hipLaunchKernelGGL((gram_cross_kernel<NTJ, V, TX, O>), dim3(2 * npairs), dim3(CW * 64), 0, st, X, ldx, m, center, plan, rowmean, slab, gap)
+  if (center == 1) { if (vec_ok) GXK(1, true); else GXK(0, true); }
+  else { if (vec_ok) GXK(1, false); else GXK(0, false); }
 #undef GXK
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_cross_finalize_kernel<NTJ>, dim3(16 * NTJ, n_features), dim3(256), 0, st, slab, wB, plan, gram, ldg, oa, ob);

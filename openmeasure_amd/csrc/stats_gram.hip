@@ -342,17 +342,25 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_own_kernel(
 
 // Per-feature statistics (count, mean, M2) of the row means the own-means kernel has written, in the slot layout
 // gram_finalize_kernel merges: same grid and SegPlan as the Gram launch, block b reduces the means of its feature's rows
-// b, b + wpf, ... (256-row chunks) to ONE triple in its first slot (fixed order: reproducible) and zeroes its other slots.
-__global__ __launch_bounds__(256) void gram_rowmean_stats_kernel(const double *__restrict__ rowmean, SegPlan plan,
-                                                                 int slots_per_wg, double *__restrict__ stat_part) {
-  __shared__ double sn[4], smu[4], sm2[4];
+// b, b + wpf, ... (1024-row chunks) to ONE triple in its first slot (fixed order: reproducible) and zeroes its other slots.
+constexpr int RS_THREADS = 1024;
+__global__ __launch_bounds__(RS_THREADS) void gram_rowmean_stats_kernel(const double *__restrict__ rowmean, SegPlan plan,
+                                                                        int slots_per_wg, double *__restrict__ stat_part) {
+  __shared__ double sn[RS_THREADS / 64], smu[RS_THREADS / 64], sm2[RS_THREADS / 64];
   int f, wl, wpf, base;
   int64_t lo, hi;
   if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a latency-bound read of 8 bytes per row: four independent rows in flight per thread, pushed in a fixed order
   RowStats st;
   st.init();
-  for (int64_t row = lo + (int64_t)wl * 256 + threadIdx.x; row < hi; row += (int64_t)wpf * 256) st.push(rowmean[row], true);
+  const int64_t step = (int64_t)wpf * RS_THREADS;
+  int64_t row = lo + (int64_t)wl * RS_THREADS + threadIdx.x;
+  for (; row + 3 * step < hi; row += 4 * step) {
+    const double a = rowmean[row], b = rowmean[row + step], c = rowmean[row + 2 * step], d = rowmean[row + 3 * step];
+    st.push(a, true); st.push(b, true); st.push(c, true); st.push(d, true);
+  }
+  for (; row < hi; row += step) st.push(rowmean[row], true);
   double n = st.cnt, mu = st.mean(), m2 = st.m2();
   for (int o = 32; o > 0; o >>= 1) {
     const double on = __shfl_down(n, o, 64), om = __shfl_down(mu, o, 64), os = __shfl_down(m2, o, 64);
@@ -363,10 +371,10 @@ __global__ __launch_bounds__(256) void gram_rowmean_stats_kernel(const double *_
   double *q = stat_part + (int64_t)blockIdx.x * slots_per_wg * 3;
   if (threadIdx.x == 0) {
     n = 0.0; mu = 0.0; m2 = 0.0;
-    for (int w = 0; w < 4; ++w) chan_merge(n, mu, m2, sn[w], smu[w], sm2[w]);
+    for (int w = 0; w < RS_THREADS / 64; ++w) chan_merge(n, mu, m2, sn[w], smu[w], sm2[w]);
     q[0] = n; q[1] = mu; q[2] = m2;
   }
-  for (int e = 3 + threadIdx.x; e < slots_per_wg * 3; e += 256) q[e] = 0.0;
+  for (int e = 3 + threadIdx.x; e < slots_per_wg * 3; e += RS_THREADS) q[e] = 0.0;
 }
 
 template <int MT, int VEC, typename TX>
@@ -537,7 +545,7 @@ int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, in
                            rowmean, slab);
       SPR_LAUNCH_CHECK();
       // statistics of the row means (own or external: the finalize call merges whatever the slots hold)
-      hipLaunchKernelGGL(gram_rowmean_stats_kernel, dim3(grid), dim3(256), 0, st, rowmean, plan, (int)RTL::ROWS_PER_IT,
+      hipLaunchKernelGGL(gram_rowmean_stats_kernel, dim3(grid), dim3(RS_THREADS), 0, st, rowmean, plan, (int)RTL::ROWS_PER_IT,
                          stat_part);
       SPR_LAUNCH_CHECK();
       return SPR_OK;

@@ -198,7 +198,7 @@ extern "C" int spr_feature_minmax_x32(const float *d_X, int64_t n_rows, int32_t 
 namespace {
 
 template <typename TX>
-__global__ __launch_bounds__(256) void colsums_kernel(const TX *__restrict__ X, int64_t ldx, int m, SegPlan plan,
+__global__ __launch_bounds__(256) void colsums_kernel(const TX *__restrict__ X, int64_t ldx, int m, int c0, SegPlan plan,
                                                       const double *__restrict__ rowmean, double *__restrict__ part) {
   int f, wl, wpf, base;
   int64_t lo, hi;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void colsums_kernel(const TX *__restrict__ X, 
     const double mu = rowmean[row];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int c = threadIdx.x + 256 * q;
+      const int c = c0 + threadIdx.x + 256 * q;                 // this launch covers columns [c0, c0 + 512)
       if (c < m) {
         const double d = (double)X[row * ldx + c] - mu;
         z[q] += d;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void colsums_kernel(const TX *__restrict__ X, 
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int c = threadIdx.x + 256 * q;
+    const int c = c0 + threadIdx.x + 256 * q;
     if (c < m) {
       part[((int64_t)blockIdx.x * 2 + 0) * m + c] = z[q];
       part[((int64_t)blockIdx.x * 2 + 1) * m + c] = w[q];
@@ -265,7 +265,7 @@ static int colsums_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t
                          int64_t n_points, int32_t n_features, const double *d_rowmean, double *d_out,
                          void *d_workspace, size_t workspace_bytes, void *stream) {
   SPR_REQUIRE(d_X && d_rowmean && d_out && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
-  SPR_REQUIRE(n_rows > 0 && m > 0 && m <= 512 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
+  SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m && row0 >= 0 && n_points > 0 && n_features > 0 &&
                   row0 + n_rows <= n_points * (int64_t)n_features,
               SPR_E_INVALID, "%s: bad shape", who);
   SPR_REQUIRE(workspace_bytes >= spr_colsums_workspace(m, n_features), SPR_E_WORKSPACE, "%s: workspace too small", who);
@@ -275,9 +275,11 @@ static int colsums_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t
   plan.total_wg = 4 * (cus > 0 ? cus : 256); plan.chunk_rows = 1;
   const int grid = seg_total_wgs(plan);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(colsums_kernel<TX>, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, plan, d_rowmean,
-                     static_cast<double *>(d_workspace));
-  SPR_LAUNCH_CHECK();
+  for (int c0 = 0; c0 < m; c0 += 512) {                        // 512 columns per launch, any m
+    hipLaunchKernelGGL(colsums_kernel<TX>, dim3(grid), dim3(256), 0, st, d_X, ldx, (int)m, c0, plan, d_rowmean,
+                       static_cast<double *>(d_workspace));
+    SPR_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(colsums_finalize_kernel, dim3(n_features), dim3(256), 0, st,
                      static_cast<const double *>(d_workspace), (int)m, plan, d_out);
   SPR_LAUNCH_CHECK();

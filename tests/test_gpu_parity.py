@@ -506,6 +506,7 @@ def test_conditioning_guard(eng, decades):                # sigma_1/sigma_r up t
         run_conditioning_guard(eng, decades, synth_host, shape=(600, 2, 300, 12))
         run_conditioning_guard(eng, decades, synth_host, shape=(900, 3, 160, 24))
         run_conditioning_guard(eng, 5, synth_host, f32=True, shape=(500, 2, 300, 9))
+        run_conditioning_guard(eng, decades, synth_host, shape=(400, 2, 600, 12))       # slice-pair Gram + streamed-W refinement
 
 
 @pytest.mark.parametrize('n_points,F,r,n_sensors,d_min,masked', [(150, 2, 5, 9, 0.0, False), (2000, 3, 16, 24, 0.03, True),
@@ -977,7 +978,7 @@ def test_properties_at_config5_share(eng):
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
 @pytest.mark.parametrize('scale_type,axis_cnt', [('std', None), ('pareto', 1), ('range', None), ('median', 1), ('l2-norm', 1),
                                                  ('max', None), ('level', 1)])
-@pytest.mark.parametrize('n_points,F,m,r', [(700, 3, 40, 9), (300, 4, 300, 12)])
+@pytest.mark.parametrize('n_points,F,m,r', [(700, 3, 40, 9), (300, 4, 300, 12), (200, 2, 600, 10)])
 def test_option_matrix_vs_oracle(eng, dtype, scale_type, axis_cnt, n_points, F, m, r):
     """Scalings x centring modes x storage precision x (narrow | column-split wide) snapshot counts, end to end
     against the oracle on the same stored values: statistics tight, sensors of the stored basis exact, fields 1e-6."""

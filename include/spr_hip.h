@@ -310,6 +310,14 @@ int spr_solve_ols_f64(const double *d_Theta, int32_t s, int32_t r, const double 
                       int32_t n_p, double *d_Ar, double *d_Ar_sigma, double *d_y0,
                       double *d_info, void *stream);
 
+/* r > SPR_MAX_R (up to SPR_MAX_R_WIDE): the same normal-equations solve with its matrices in a workspace of
+ * spr_solve_ols_workspace(s, r, n_p) bytes (L2-resident; one 1024-thread workgroup per vector), same outputs. */
+size_t spr_solve_ols_workspace(int32_t s, int32_t r, int32_t n_p);
+int spr_solve_ols_wide_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt,
+                           const double *d_scale, int32_t n_features, const double *d_y, int32_t n_p,
+                           double *d_Ar, double *d_Ar_sigma, double *d_y0, double *d_info, void *d_workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* ---- K9b : the same solve with the reference's pseudo-inverse semantics ---------------
  * np.linalg.pinv(W @ Theta) (:873, :877; SVD, rcond = 1e-15) returns the MINIMUM-NORM least-squares solution when
  * W Theta is rank deficient or has fewer rows than columns (s < r: every GEM placement, :660-668).  Same inputs and

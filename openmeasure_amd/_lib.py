@@ -69,6 +69,8 @@ PROTOTYPES = {
     'spr_qr_refresh_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'spr_measure_csr_f64': (C.c_int, [_p, _p, _p, _i32, _p, _i64, _i32, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     'spr_solve_ols_f64': (C.c_int, [_p, _i32, _i32, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
+    'spr_solve_ols_workspace': (_sz, [_i32, _i32, _i32]),
+    'spr_solve_ols_wide_f64': (C.c_int, [_p, _i32, _i32, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     'spr_solve_pinv_f64': (C.c_int, [_p, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _dbl, _p, _p, _p, _p, _p]),
     'spr_solve_pinv_workspace': (_sz, [_i32, _i32]),
     'spr_solve_pinv_wide_f64': (C.c_int, [_p, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _dbl, _p, _p, _p, _p, _p, _sz, _p]),

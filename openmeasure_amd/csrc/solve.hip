@@ -283,6 +283,165 @@ __global__ __launch_bounds__(SV_THREADS) void solve_ols_kernel(
   }
 }
 
+// ---- the same algorithm for r > 128 (r <= SPR_MAX_R_WIDE): the normal matrix no longer fits LDS, so the scaled augmented
+// matrix A = [W Theta | W y0 | y0_sigma] (s x (r+2)) and N = A^T A (r x r) live in a global workspace (L2-resident) and one
+// 1024-thread workgroup per vector works on them with plain FMA loops -- a basis this wide is rare (the reference keeps any
+// r <= m modes, :336), the point is that predict() stays in milliseconds there instead of falling to the SVD path.
+constexpr int SW_THREADS = 1024;
+
+__global__ __launch_bounds__(SW_THREADS) void solve_ols_wide_kernel(
+    const double *__restrict__ Theta, int s, int r, const double *__restrict__ cnt, const double *__restrict__ scale,
+    int n_features, const double *__restrict__ y_all, double *__restrict__ Ar, double *__restrict__ Ar_sigma,
+    double *__restrict__ y0_all, double *__restrict__ info, double *ws, int64_t ws_stride) {
+  const int nc = r + 2, LDN = r + 1;
+  double *A = ws + (int64_t)blockIdx.x * ws_stride;      // s x nc
+  double *N = A + (int64_t)s * nc;                        // r x LDN
+  double *rhs0 = N + (int64_t)r * LDN, *rhs1 = rhs0 + r, *sol0 = rhs1 + r, *sol1 = sol0 + r, *dsc = sol1 + r;
+  double *xs0 = dsc + r, *xs1 = xs0 + r, *res0 = xs1 + r, *res1 = res0 + s;   // residuals: s entries each
+  __shared__ int flags[2];
+  __shared__ double piv[2];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const double *y = y_all + (int64_t)p * s * 3;
+  if (tid < 2) flags[tid] = 0;
+  __syncthreads();
+  {
+    int any = 0;
+    for (int k = tid; k < s; k += SW_THREADS) any |= (y[3 * k + 1] != 0.0);
+    if (any) flags[0] = 1;
+  }
+  __syncthreads();
+  const bool weighted = flags[0] != 0;
+  // scale_vector (:571-582) and the rows of A
+  for (int k = tid; k < s; k += SW_THREADS) {
+    int f = (int)y[3 * k + 2];
+    f = f < 0 ? 0 : (f > n_features - 1 ? n_features - 1 : f);
+    const double scl = scale[f];
+    const double v0 = (y[3 * k] - cnt[k]) / scl, s0 = y[3 * k + 1] / scl;
+    const double w = weighted ? 1.0 / s0 : 1.0;
+    if (y0_all) {
+      y0_all[((int64_t)p * s + k) * 2] = v0;
+      y0_all[((int64_t)p * s + k) * 2 + 1] = s0;
+    }
+    A[(int64_t)k * nc + r] = w * v0;
+    A[(int64_t)k * nc + r + 1] = weighted ? s0 : 0.0;
+    res0[k] = w;                                          // the row weight, parked until the rows are scaled
+  }
+  __syncthreads();
+  for (int64_t e = tid; e < (int64_t)s * r; e += SW_THREADS) {
+    const int k = (int)(e / r), c = (int)(e - (int64_t)k * r);
+    A[(int64_t)k * nc + c] = res0[k] * Theta[e];
+  }
+  __syncthreads();
+  // N = A^T A (upper triangle computed, mirrored), rhs = A^T b for both right-hand sides
+  for (int64_t e = tid; e < (int64_t)r * nc; e += SW_THREADS) {
+    const int i = (int)(e / nc), j = (int)(e - (int64_t)i * nc);
+    if (j >= i) {
+      double acc = 0.0;
+      for (int k = 0; k < s; ++k) acc += A[(int64_t)k * nc + i] * A[(int64_t)k * nc + j];
+      if (j < r) { N[(int64_t)i * LDN + j] = acc; N[(int64_t)j * LDN + i] = acc; }
+      else if (j == r) rhs0[i] = acc;
+      else rhs1[i] = acc;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < r; j += SW_THREADS) {
+    const double d = N[(int64_t)j * LDN + j];
+    dsc[j] = (d > 0.0) ? 1.0 / sqrt(d) : 1.0;
+  }
+  __syncthreads();
+  for (int64_t e = tid; e < (int64_t)r * r; e += SW_THREADS) {
+    const int i = (int)(e / r), j = (int)(e - (int64_t)i * r);
+    N[(int64_t)i * LDN + j] *= dsc[i] * dsc[j];
+  }
+  for (int j = tid; j < r; j += SW_THREADS) { rhs0[j] *= dsc[j]; rhs1[j] *= dsc[j]; }
+  __syncthreads();
+  // Cholesky N' = L L^T, right-looking, in place (lower)
+  for (int j = 0; j < r; ++j) {
+    if (tid == 0) {
+      double d = N[(int64_t)j * LDN + j];
+      if (!(d > 0.0)) { flags[1] = 1; d = 1e-300; }
+      piv[0] = sqrt(d);
+      N[(int64_t)j * LDN + j] = piv[0];
+    }
+    __syncthreads();
+    const double djj = piv[0];
+    for (int i = j + 1 + tid; i < r; i += SW_THREADS) N[(int64_t)i * LDN + j] /= djj;
+    __syncthreads();
+    const int cntj = r - j - 1;
+    for (int64_t e = tid; e < (int64_t)cntj * cntj; e += SW_THREADS) {
+      const int a = (int)(e / cntj), b = (int)(e - (int64_t)a * cntj);
+      if (b <= a) {
+        const int i = j + 1 + a, k = j + 1 + b;
+        N[(int64_t)i * LDN + k] -= N[(int64_t)i * LDN + j] * N[(int64_t)k * LDN + j];
+      }
+    }
+    __syncthreads();
+  }
+  auto chol_solve = [&]() {     // L z = rhs, L^T x = z for both right-hand sides; the solution ends up in rhs
+    for (int j = 0; j < r; ++j) {
+      if (tid < 2) (tid ? sol1 : sol0)[j] = (tid ? rhs1 : rhs0)[j] / N[(int64_t)j * LDN + j];
+      __syncthreads();
+      for (int i = j + 1 + tid; i < r; i += SW_THREADS) {
+        const double l = N[(int64_t)i * LDN + j];
+        rhs0[i] -= l * sol0[j];
+        rhs1[i] -= l * sol1[j];
+      }
+      __syncthreads();
+    }
+    for (int j = r - 1; j >= 0; --j) {
+      if (tid < 2) (tid ? rhs1 : rhs0)[j] = (tid ? sol1 : sol0)[j] / N[(int64_t)j * LDN + j];
+      __syncthreads();
+      for (int i = tid; i < j; i += SW_THREADS) {
+        const double l = N[(int64_t)j * LDN + i];
+        sol0[i] -= l * rhs0[j];
+        sol1[i] -= l * rhs1[j];
+      }
+      __syncthreads();
+    }
+  };
+  chol_solve();
+  // one refinement step with the residual formed from A itself (corrected semi-normal equations)
+  for (int j = tid; j < r; j += SW_THREADS) { xs0[j] = rhs0[j]; xs1[j] = rhs1[j]; }
+  __syncthreads();
+  for (int k = tid; k < s; k += SW_THREADS) {
+    double d0 = 0.0, d1 = 0.0;
+    for (int c = 0; c < r; ++c) {
+      const double a = A[(int64_t)k * nc + c];
+      d0 += a * xs0[c] * dsc[c];
+      d1 += a * xs1[c] * dsc[c];
+    }
+    res0[k] = A[(int64_t)k * nc + r] - d0;
+    res1[k] = weighted ? A[(int64_t)k * nc + r + 1] - d1 : 0.0;
+  }
+  __syncthreads();
+  for (int c = tid; c < r; c += SW_THREADS) {
+    double g0 = 0.0, g1 = 0.0;
+    for (int k = 0; k < s; ++k) {
+      const double a = A[(int64_t)k * nc + c];
+      g0 += a * res0[k];
+      g1 += a * res1[k];
+    }
+    rhs0[c] = g0 * dsc[c];
+    rhs1[c] = g1 * dsc[c];
+  }
+  __syncthreads();
+  chol_solve();
+  for (int k = tid; k < r; k += SW_THREADS) {
+    Ar[(int64_t)p * r + k] = (rhs0[k] + xs0[k]) * dsc[k];
+    Ar_sigma[(int64_t)p * r + k] = weighted ? fabs((rhs1[k] + xs1[k]) * dsc[k]) : 0.0;
+  }
+  if (tid == 0) {
+    double dmax = 0.0, dmin = 1e300;
+    for (int j = 0; j < r; ++j) {
+      const double d = N[(int64_t)j * LDN + j];
+      if (d > dmax) dmax = d;
+      if (d < dmin) dmin = d;
+    }
+    info[2 * p] = (double)flags[1];
+    info[2 * p + 1] = (dmax / dmin) * (dmax / dmin);
+  }
+}
+
 }  // namespace
 
 extern "C" int spr_solve_ols_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt,
@@ -303,6 +462,30 @@ extern "C" int spr_solve_ols_f64(const double *d_Theta, int32_t s, int32_t r, co
   else if (need <= 5) SV(5);
   else SV(9);
 #undef SV
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+// r > SPR_MAX_R: same semantics and outputs, matrices in a workspace of spr_solve_ols_workspace(s, r, n_p) bytes
+extern "C" size_t spr_solve_ols_workspace(int32_t s, int32_t r, int32_t n_p) {
+  if (r <= SPR_MAX_R || r > SPR_MAX_R_WIDE || s <= 0 || n_p <= 0) return 0;
+  return sizeof(double) * (size_t)n_p * ((size_t)s * (r + 2) + (size_t)r * (r + 1) + 7 * (size_t)r + 2 * (size_t)s);
+}
+
+extern "C" int spr_solve_ols_wide_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt,
+                                      const double *d_scale, int32_t n_features, const double *d_y, int32_t n_p,
+                                      double *d_Ar, double *d_Ar_sigma, double *d_y0, double *d_info, void *d_workspace,
+                                      size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_Theta && d_cnt && d_scale && d_y && d_Ar && d_Ar_sigma && d_info && d_workspace, SPR_E_INVALID,
+              "spr_solve_ols_wide_f64: NULL pointer");
+  SPR_REQUIRE(s > 0 && r > 0 && n_p > 0 && n_features > 0, SPR_E_INVALID, "spr_solve_ols_wide_f64: bad shape");
+  SPR_REQUIRE(r <= SPR_MAX_R_WIDE, SPR_E_UNSUPPORTED, "spr_solve_ols_wide_f64: r=%d > %d not built", r, SPR_MAX_R_WIDE);
+  const size_t per = (size_t)s * (r + 2) + (size_t)r * (r + 1) + 7 * (size_t)r + 2 * (size_t)s;
+  SPR_REQUIRE(workspace_bytes >= sizeof(double) * per * (size_t)n_p, SPR_E_WORKSPACE,
+              "spr_solve_ols_wide_f64: workspace too small");
+  hipLaunchKernelGGL(solve_ols_wide_kernel, dim3(n_p), dim3(SW_THREADS), 0, static_cast<hipStream_t>(stream), d_Theta,
+                     (int)s, (int)r, d_cnt, d_scale, (int)n_features, d_y, d_Ar, d_Ar_sigma, d_y0, d_info,
+                     static_cast<double *>(d_workspace), (int64_t)per);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }

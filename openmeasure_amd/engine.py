@@ -518,7 +518,7 @@ class HipEngine:
         return (Theta, cnt) if scale is None else (Theta, cnt, scl)
 
     # ---- K8 + K9 -------------------------------------------------------------------------------
-    ols_max_r = _lib.SPR_MAX_R
+    ols_max_r = _lib.SPR_MAX_R_WIDE
 
     def solve_ols(self, Theta, cnt, scale, y):
         """y: (n_p, s, 3) device tensor. -> Ar (n_p,r), Ar_sigma (n_p,r), y0 (n_p,s,2), info (n_p,2)."""
@@ -528,6 +528,13 @@ class HipEngine:
         Ar_sigma = self.empty((n_p, r))
         y0 = self.empty((n_p, s, 2))
         info = self.empty((n_p, 2))
+        if r > _lib.SPR_MAX_R:                                # matrices in a workspace instead of LDS
+            ws = self._workspace('ols', self.lib.spr_solve_ols_workspace(s, r, n_p))
+            _lib.check(self.lib.spr_solve_ols_wide_f64(_ptr(Theta.contiguous()), s, r, _ptr(cnt), _ptr(scale),
+                                                       scale.shape[0], _ptr(y.contiguous()), n_p, _ptr(Ar),
+                                                       _ptr(Ar_sigma), _ptr(y0), _ptr(info), _ptr(ws), ws.numel(),
+                                                       self._stream()), 'spr_solve_ols_wide_f64')
+            return Ar, Ar_sigma, y0, info
         _lib.check(self.lib.spr_solve_ols_f64(_ptr(Theta.contiguous()), s, r, _ptr(cnt), _ptr(scale),
                                               scale.shape[0], _ptr(y.contiguous()), n_p, _ptr(Ar), _ptr(Ar_sigma),
                                               _ptr(y0), _ptr(info), self._stream()), 'spr_solve_ols_f64')

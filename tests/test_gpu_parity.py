@@ -1177,3 +1177,30 @@ def test_partial_row_group_with_absent_features(eng):
     Xc = np.vstack([(a - a.mean(1, keepdims=True)) / np.std(a), (b - b.mean(1, keepdims=True)) / np.std(b)])
     S_ref = np.linalg.svd(Xc, compute_uv=False)
     np.testing.assert_allclose(spr.S_[:r], S_ref[:r], rtol=1e-9)
+
+
+@pytest.mark.parametrize('s_,r,cond', [(200, 200, 10.0), (450, 300, 1e3), (129, 129, 5.0), (1100, 1024, 30.0)])
+def test_solve_ols_wide_vs_oracle(eng, s_, r, cond):
+    """Normal equations + Cholesky + one refinement step for r > 128 (spr_solve_ols_wide_f64: matrices in a workspace):
+    weighted and unweighted right-hand sides against the oracle's SVD pseudo-inverse (:873-878)."""
+    rng = np.random.default_rng(s_ + r)
+    Uq, _ = np.linalg.qr(rng.standard_normal((s_, r)))
+    Vq, _ = np.linalg.qr(rng.standard_normal((r, r)))
+    Theta = (Uq * np.logspace(0, -np.log10(cond), r)) @ Vq.T
+    a_true = rng.standard_normal(r)
+    ys = []
+    for weighted in (False, True):
+        y = np.zeros((s_, 3))
+        y[:, 0] = Theta @ a_true + 1e-3 * rng.standard_normal(s_)
+        if weighted:
+            y[:, 1] = 0.05 * (1.0 + rng.random(s_))
+        ys.append(y)
+    Ar, As, y0, info = eng.solve_ols(eng.to_device(Theta), eng.to_device(np.zeros(s_)), eng.to_device(np.ones(1)),
+                                     eng.to_device(np.stack(ys)))
+    Ar, As, info = eng.to_host(Ar), eng.to_host(As), eng.to_host(info)
+    assert not info[:, 0].any() and np.all(info[:, 1] < 1e13)
+    A_ref, S_ref = _identity_problem(Theta, ys)
+    for k in range(2):
+        assert np.linalg.norm(Ar[k] - A_ref[k]) <= 1e-9 * cond * np.linalg.norm(A_ref[k]), (k, info[k])
+    assert np.linalg.norm(As[1] - S_ref[1]) <= 1e-9 * cond * np.linalg.norm(S_ref[1]) and not As[0].any()
+    np.testing.assert_allclose(eng.to_host(y0)[1, :, 1], ys[1][:, 1])

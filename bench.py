@@ -423,6 +423,23 @@ def run_rank(args):
         extra = dict(optimal_placement_ms=round(t_place, 3), train_ms=round(t_train, 3), predict_ms=round(t_pred, 3),
                      min_pivot_gap=float(spr.pivot_gap_.min()), pivot_sweeps=int(spr.pivot_sweeps_),
                      timing='median of 3 calls after 2 warm-up calls')
+        extra['placement_from_row_norms'] = bool(spr.placement_from_norms_)
+        # A/B of ROM.placement_norms (the squared row norms fit() leaves for the placement): what the projection pays for
+        # writing them, what the placement saves by not reading the basis for them.  Default "auto" first, then off.
+        def fit_only():
+            spr.fit(select_modes='number', n_modes=s)
+        t_fit = timed3(fit_only)
+        spr.placement_norms = False
+        fit_only()
+        t_fit_off = timed3(fit_only)
+        spr.optimal_placement()
+        t_place_off = timed3(spr.optimal_placement)
+        assert not spr.placement_from_norms_ and np.array_equal(piv_first, spr.sensors_), 'placement differs without norms'
+        extra.update(fit_ms=round(t_fit, 3), fit_without_row_norms_ms=round(t_fit_off, 3),
+                     optimal_placement_without_row_norms_ms=round(t_place_off, 3),
+                     pivot_sweeps_without_row_norms=int(spr.pivot_sweeps_))
+        del spr.placement_norms                                # back to the class default
+        fit_only()
 
     cpu = None
     parity = None

@@ -169,6 +169,26 @@ int spr_project_stream_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t
                            const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
                            void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- K4 + the first sweep of K6 : projection that also leaves the squared row norms of the basis ---------------
+ * optimal_placement (:739) starts from |Ur[i, :]|^2 of every row; the plain route reads all of Ur once more for them
+ * (spr_qr_init_*).  These variants write d_rownorm2[n_rows] -- the norms of the values AS STORED, i.e. rounded to the
+ * basis type first -- from the accumulators of the projection that stores d_Ur, and spr_qr_init_norms_* starts the
+ * pivoting from that vector (8 bytes per row instead of r values).  Same arguments and results otherwise.
+ * spr_project_norms_*        only the W-stationary form produces norms (m = 128 / 192 / 256 packed rows, 16-byte aligned,
+ *                            r <= 64, n_rows >= 4096): spr_project_norms_supported() says whether a shape qualifies;
+ *                            SPR_E_UNSUPPORTED and nothing launched otherwise.
+ * spr_project_stream_norms_* every shape spr_project_stream_* takes (any m, r <= SPR_MAX_R per call). */
+int32_t spr_project_norms_supported(int32_t m, int32_t r, int64_t n_rows, int64_t ldx, const void *d_X,
+                                    int32_t x_is_f32);
+int spr_project_norms_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                          int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                          const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                          double *d_rownorm2, void *stream);
+int spr_project_stream_norms_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                 int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                                 const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                                 double *d_rownorm2, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- K2 / K11 as stand-alone calls (ROM.scale_data's return value, ROM.unscale_data) --
  * spr_scale_rows:  X0 = (X - rowmean) * inv_scale[feature]   (:169), n_rows x m.
  * spr_unscale:     x  = scale[feature] * x0 + rowmean        (:235), n_rows; with d_rowscale != NULL
@@ -266,6 +286,11 @@ int spr_mask_rows_f64(double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
 int spr_qr_init_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
                     int64_t row0, double *d_nrm, double *d_rec, double *d_tau,
                     void *d_workspace, size_t workspace_bytes, void *stream);
+/* spr_qr_init with the squared row norms given (d_nrm0, written by spr_project_norms_* / spr_project_stream_norms_* for this
+ * very d_Ur; not modified): no pass over the basis.  d_nrm is the working vector the steps down-date. */
+int spr_qr_init_norms_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                          const double *d_nrm0, double *d_nrm, double *d_rec, double *d_tau,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_recs, int32_t n_rec,
                     const double *d_taus, int32_t n_tau, int32_t first, double *d_Q,
                     int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
@@ -401,6 +426,23 @@ int spr_project_stream_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, i
                                   int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
                                   const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
                                   void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_project_norms_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                          int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                          const double *d_rowmean, const double *d_W, int32_t r, float *d_Ur, int64_t ldu,
+                          double *d_rownorm2, void *stream);
+int spr_project_norms_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                 int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                                 const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                                 double *d_rownorm2, void *stream);
+int spr_project_stream_norms_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                 int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                                 const double *d_rowmean, const double *d_W, int32_t r, float *d_Ur, int64_t ldu,
+                                 double *d_rownorm2, void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_project_stream_norms_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                        int64_t n_points, int32_t n_features, int32_t center,
+                                        const double *d_inv_scale, const double *d_rowmean, const double *d_W,
+                                        int32_t r, double *d_Ur, int64_t ldu, double *d_rownorm2, void *d_workspace,
+                                        size_t workspace_bytes, void *stream);
 int spr_scale_rows_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                        int64_t n_points, int32_t n_features, const double *d_rowmean,
                        const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream);
@@ -425,6 +467,9 @@ int spr_mask_rows_u32(float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
 int spr_qr_init_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
                     int64_t row0, double *d_nrm, double *d_rec, double *d_tau,
                     void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_init_norms_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                          const double *d_nrm0, double *d_nrm, double *d_rec, double *d_tau,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_qr_refresh_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
                        const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq,
                        double *d_nrm, double *d_rec, double *d_tau,

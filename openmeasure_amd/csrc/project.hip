@@ -242,7 +242,7 @@ template <typename TX, typename TU>
 int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
                   int32_t n_features, int32_t center, const double *d_inv_scale, const double *d_rowmean,
                   const double *d_W, int32_t r, TU *d_Ur, int64_t ldu, int32_t accumulate, void *stream,
-                  const double *d_acc_in = nullptr, int64_t lda = 0) {
+                  const double *d_acc_in = nullptr, int64_t lda = 0, double *d_rownorm2 = nullptr) {
   SPR_REQUIRE(!d_acc_in || (accumulate && lda >= r), SPR_E_INVALID, "%s: acc_in needs accumulate = 1 and lda >= r", who);
   SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && (d_rowmean || !center), SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "%s: bad shape", who);
@@ -268,10 +268,14 @@ int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int
     static const bool ws_on = [] { const char *e = getenv("SPR_PROJECT_WS"); return !(e && e[0] == '0'); }();
     if (ws_on && !d_acc_in && n_rows >= 4096) {
       const int rc = spr_project_ws<TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
-                                            d_rowmean, d_W, r, d_Ur, ldu, accumulate, st);
+                                            d_rowmean, d_W, r, d_Ur, ldu, accumulate, d_rownorm2, st);
       if (rc != SPR_E_UNSUPPORTED) return rc;
     }
   }
+  // the general kernel spreads a row's columns over several waves: no row norms from it (spr_project_stream_norms_*
+  // takes every shape)
+  SPR_REQUIRE(!d_rownorm2, SPR_E_UNSUPPORTED, "%s: row norms only come from the W-stationary form (m = 128/192/256 packed, "
+              "r <= 64); use spr_project_stream_norms_* for m=%d r=%d", who, m, r);
 #define PJ(MTV) return launch_rt<MTV, TX, TU>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, d_acc_in, lda, st)
   switch (spr_round_mt(m)) {
     case 1: PJ(1);
@@ -325,4 +329,44 @@ extern "C" int spr_project_x32_acc(const float *d_X, int64_t n_rows, int32_t m, 
   SPR_REQUIRE(d_acc_in != nullptr, SPR_E_INVALID, "spr_project_x32_acc: acc_in is NULL");
   return project_entry("spr_project_x32_acc", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
                        d_rowmean, d_W, r, d_Ur, ldu, 1, stream, d_acc_in, lda);
+}
+
+// ---- K4 + first sweep of K6: the projection that also leaves the squared norms of the rows it stores --------------
+// d_rownorm2[n_rows] = |Ur[i, :]|^2 of the STORED values (rounded to the basis type first), for spr_qr_init_norms_*.
+// Only the W-stationary form produces them: SPR_E_UNSUPPORTED (and nothing launched) for any other shape -- ask
+// spr_project_norms_supported first, or call spr_project_stream_norms_*, which takes every shape.
+extern "C" int32_t spr_project_norms_supported(int32_t m, int32_t r, int64_t n_rows, int64_t ldx, const void *d_X,
+                                               int32_t x_is_f32) {
+  const char *e = getenv("SPR_PROJECT_WS");
+  if (e && e[0] == '0') return 0;
+  const size_t es = x_is_f32 ? sizeof(float) : sizeof(double);
+  return (m == 128 || m == 192 || m == 256) && r >= 1 && r <= 64 && n_rows >= 4096 && (es * ldx) % 16 == 0 &&
+         (reinterpret_cast<uintptr_t>(d_X) & 15) == 0;
+}
+
+extern "C" int spr_project_norms_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                     int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                                     const double *d_rowmean, const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                                     double *d_rownorm2, void *stream) {
+  SPR_REQUIRE(d_rownorm2, SPR_E_INVALID, "spr_project_norms_f64: NULL norm vector");
+  return project_entry("spr_project_norms_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                       d_rowmean, d_W, r, d_Ur, ldu, 0, stream, nullptr, 0, d_rownorm2);
+}
+
+extern "C" int spr_project_norms_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                     int64_t n_points, int32_t n_features, int32_t center, const double *d_inv_scale,
+                                     const double *d_rowmean, const double *d_W, int32_t r, float *d_Ur, int64_t ldu,
+                                     double *d_rownorm2, void *stream) {
+  SPR_REQUIRE(d_rownorm2, SPR_E_INVALID, "spr_project_norms_x32: NULL norm vector");
+  return project_entry("spr_project_norms_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                       d_rowmean, d_W, r, d_Ur, ldu, 0, stream, nullptr, 0, d_rownorm2);
+}
+
+extern "C" int spr_project_norms_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                            int64_t n_points, int32_t n_features, int32_t center,
+                                            const double *d_inv_scale, const double *d_rowmean, const double *d_W,
+                                            int32_t r, double *d_Ur, int64_t ldu, double *d_rownorm2, void *stream) {
+  SPR_REQUIRE(d_rownorm2, SPR_E_INVALID, "spr_project_norms_x32_f64out: NULL norm vector");
+  return project_entry("spr_project_norms_x32_f64out", d_X, n_rows, m, ldx, row0, n_points, n_features, center,
+                       d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, 0, stream, nullptr, 0, d_rownorm2);
 }

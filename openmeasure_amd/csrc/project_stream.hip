@@ -96,11 +96,12 @@ __global__ void ps_image_kernel(const double *__restrict__ W, int m, int r, int 
     }
 }
 
-template <int RT, int VEC, bool FULLK, bool PRE, typename TX, typename TU>
+// NRM: the squared norms of the rows of Ur AS STORED (rounded to TU first) also go to nrm2[] (spr_qr_init_norms_*)
+template <int RT, int VEC, bool FULLK, bool PRE, typename TX, typename TU, bool NRM>
 __global__ __launch_bounds__(PS_THREADS) void project_stream_kernel(
     const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan, const double *__restrict__ inv_scale,
     const double *__restrict__ rowmean, const double *__restrict__ img, const double *__restrict__ wbar_g, int nch,
-    int r, TU *__restrict__ Ur, int64_t ldu) {
+    int r, TU *__restrict__ Ur, int64_t ldu, double *__restrict__ nrm2) {
   constexpr int KC = PsK<TX>::KC, NJ = KC / 16, NB = PS_NB;
   constexpr int LDW = 16 * RT;                               // doubles per k-row of the image (a multiple of 32: see project_ws.hip)
   constexpr int CHUNK = KC * LDW;                            // doubles per chunk
@@ -243,11 +244,16 @@ __global__ __launch_bounds__(PS_THREADS) void project_stream_kernel(
       }
       const bool full = (blk0 + 16 <= hi) && (r == 16 * RT);   // wave-uniform: whole block inside, no padded column
       TU *up = Ur + (blk0 + kk) * ldu + li;
+      double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ct = 0; ct < RT; ++ct) {
         const double wbar = centre_epi ? wbar_g[16 * ct + li] : 0.0;
         const double s[4] = {(acc[b][ct].x - mu[0] * wbar) * isc, (acc[b][ct].y - mu[1] * wbar) * isc,
                              (acc[b][ct].z - mu[2] * wbar) * isc, (acc[b][ct].w - mu[3] * wbar) * isc};
+        if (NRM) {                                           // padded columns hold exact zeros (zero columns of the image)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const double v = (double)(TU)s[i]; q[i] = fma(v, v, q[i]); }
+        }
         if (full) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) up[4 * i * ldu + 16 * ct] = (TU)s[i];
@@ -255,6 +261,13 @@ __global__ __launch_bounds__(PS_THREADS) void project_stream_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (blk0 + kk + 4 * i < hi) up[4 * i * ldu + 16 * ct] = (TU)s[i];
+        }
+      }
+      if (NRM) {                                             // the 16 lanes of a row hold its 16 RT columns: one DPP butterfly
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double t = group_sum_t<16>(q[i]);
+          if (li == i && blk0 + kk + 4 * i < hi) nrm2[blk0 + kk + 4 * i] = t;
         }
       }
     }
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(PS_THREADS) void project_stream_kernel(
 template <int RT, typename TX, typename TU>
 int ps_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features,
               int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r, TU *Ur, int64_t ldu,
-              double *ws, hipStream_t st) {
+              double *ws, double *nrm2, hipStream_t st) {
   constexpr int KC = PsK<TX>::KC, NC = 16 * RT;
   const int nch = (m + KC - 1) / KC;
   double *img = ws, *wbar = ws + (size_t)nch * KC * NC;
@@ -282,13 +295,15 @@ int ps_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
   const bool vec = (m % 4 == 0) && ((sizeof(TX) * ldx) % 16 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   const bool fullk = vec && (m % KC == 0);
   const bool pre = center == 2;
-#define PSK(V, FK, PR)                                                                                                   \
-  hipLaunchKernelGGL((project_stream_kernel<RT, V, FK, PR, TX, TU>), dim3(grid), dim3(PS_THREADS), 0, st, X, ldx, (int)m, \
-                     center, plan, inv_scale, rowmean, img, wbar, nch, (int)r, Ur, ldu)
+#define PSKN(V, FK, PR, NR)                                                                                                  \
+  hipLaunchKernelGGL((project_stream_kernel<RT, V, FK, PR, TX, TU, NR>), dim3(grid), dim3(PS_THREADS), 0, st, X, ldx, (int)m, \
+                     center, plan, inv_scale, rowmean, img, wbar, nch, (int)r, Ur, ldu, nrm2)
+#define PSK(V, FK, PR) do { if (nrm2) PSKN(V, FK, PR, true); else PSKN(V, FK, PR, false); } while (0)
   if (fullk) { if (pre) PSK(1, true, true); else PSK(1, true, false); }
   else if (vec) { if (pre) PSK(1, false, true); else PSK(1, false, false); }
   else { if (pre) PSK(0, false, true); else PSK(0, false, false); }
 #undef PSK
+#undef PSKN
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
@@ -305,7 +320,8 @@ size_t ps_workspace(int32_t m, int32_t r) {
 template <typename TX, typename TU>
 int ps_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
              int32_t n_features, int32_t center, const double *d_inv_scale, const double *d_rowmean, const double *d_W,
-             int32_t r, TU *d_Ur, int64_t ldu, void *d_workspace, size_t workspace_bytes, void *stream) {
+             int32_t r, TU *d_Ur, int64_t ldu, void *d_workspace, size_t workspace_bytes, void *stream,
+             double *d_rownorm2 = nullptr) {
   SPR_REQUIRE(d_X && d_inv_scale && d_W && d_Ur && d_workspace && (d_rowmean || !center), SPR_E_INVALID, "%s: NULL pointer", who);
   SPR_REQUIRE(n_rows > 0 && m > 0 && ldx >= m, SPR_E_INVALID, "%s: bad shape", who);
   SPR_REQUIRE(r > 0 && ldu >= r, SPR_E_INVALID, "%s: bad r=%d (m=%d ldu=%lld)", who, r, m, (long long)ldu);
@@ -321,9 +337,9 @@ int ps_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t 
   double *ws = static_cast<double *>(d_workspace);
   if (r <= 64)
     return ps_launch<4, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r,
-                                d_Ur, ldu, ws, st);
+                                d_Ur, ldu, ws, d_rownorm2, st);
   return ps_launch<8, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r,
-                              d_Ur, ldu, ws, st);
+                              d_Ur, ldu, ws, d_rownorm2, st);
 }
 
 }  // namespace
@@ -355,4 +371,38 @@ extern "C" int spr_project_stream_x32_f64out(const float *d_X, int64_t n_rows, i
                                              size_t workspace_bytes, void *stream) {
   return ps_entry("spr_project_stream_x32_f64out", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
                   d_rowmean, d_W, r, d_Ur, ldu, d_workspace, workspace_bytes, stream);
+}
+
+// ---- the same launches, also leaving the squared norms of the rows they store (d_rownorm2[n_rows], of the values rounded
+// to the basis type): the first sweep of optimal_placement then reads 8 bytes per row instead of the whole basis
+// (spr_qr_init_norms_*).  Every shape the plain entry points take.
+extern "C" int spr_project_stream_norms_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                            int64_t n_points, int32_t n_features, int32_t center,
+                                            const double *d_inv_scale, const double *d_rowmean, const double *d_W,
+                                            int32_t r, double *d_Ur, int64_t ldu, double *d_rownorm2, void *d_workspace,
+                                            size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_rownorm2, SPR_E_INVALID, "spr_project_stream_norms_f64: NULL norm vector");
+  return ps_entry("spr_project_stream_norms_f64", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                  d_rowmean, d_W, r, d_Ur, ldu, d_workspace, workspace_bytes, stream, d_rownorm2);
+}
+
+extern "C" int spr_project_stream_norms_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                            int64_t n_points, int32_t n_features, int32_t center,
+                                            const double *d_inv_scale, const double *d_rowmean, const double *d_W,
+                                            int32_t r, float *d_Ur, int64_t ldu, double *d_rownorm2, void *d_workspace,
+                                            size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_rownorm2, SPR_E_INVALID, "spr_project_stream_norms_x32: NULL norm vector");
+  return ps_entry("spr_project_stream_norms_x32", d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,
+                  d_rowmean, d_W, r, d_Ur, ldu, d_workspace, workspace_bytes, stream, d_rownorm2);
+}
+
+extern "C" int spr_project_stream_norms_x32_f64out(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                                   int64_t n_points, int32_t n_features, int32_t center,
+                                                   const double *d_inv_scale, const double *d_rowmean,
+                                                   const double *d_W, int32_t r, double *d_Ur, int64_t ldu,
+                                                   double *d_rownorm2, void *d_workspace, size_t workspace_bytes,
+                                                   void *stream) {
+  SPR_REQUIRE(d_rownorm2, SPR_E_INVALID, "spr_project_stream_norms_x32_f64out: NULL norm vector");
+  return ps_entry("spr_project_stream_norms_x32_f64out", d_X, n_rows, m, ldx, row0, n_points, n_features, center,
+                  d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, d_workspace, workspace_bytes, stream, d_rownorm2);
 }

@@ -64,10 +64,13 @@ __device__ inline double ws_elem(const WsPiece<TX> &p, int t) {
   else return (double)(t == 0 ? p.x : t == 1 ? p.y : t == 2 ? p.z : p.w);
 }
 
-template <int MT, int RT, int VEC, typename TX, typename TU>
+// NRM: the squared norms of the rows of Ur AS STORED (rounded to TU first) also go to nrm2[] -- what the first sweep of
+// optimal_placement would otherwise read all of Ur again for (qr_pivot.hip, spr_qr_init_norms_*).
+template <int MT, int RT, int VEC, typename TX, typename TU, bool NRM>
 __global__ __launch_bounds__(WS_WAVES * 64) void project_ws_kernel(
     const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan, const double *__restrict__ inv_scale,
-    const double *__restrict__ rowmean, const double *__restrict__ W, int r, TU *__restrict__ Ur, int64_t ldu) {
+    const double *__restrict__ rowmean, const double *__restrict__ W, int r, TU *__restrict__ Ur, int64_t ldu,
+    double *__restrict__ nrm2) {
   constexpr int K = 16 * MT, NJ = MT;                 // NJ pieces of 16 columns per row
   constexpr int NC = WsLds<RT>::NC, LDW = WsLds<RT>::LDW;
   __shared__ double Wl[K * LDW];
@@ -164,10 +167,15 @@ __global__ __launch_bounds__(WS_WAVES * 64) void project_ws_kernel(
     {
       const bool full = (blk0 + 16 <= hi) && (r == NC);     // wave-uniform: whole block inside the segment, no padded column
       TU *up = Ur + (blk0 + kk) * ldu + li;                  // element (row 0 of this lane, column tile 0)
+      double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ct = 0; ct < RT; ++ct) {
         const double s[4] = {acc[ct].x - mu[0] * wbar[ct], acc[ct].y - mu[1] * wbar[ct],
                              acc[ct].z - mu[2] * wbar[ct], acc[ct].w - mu[3] * wbar[ct]};
+        if (NRM) {                                           // padded columns hold exact zeros (zero rows of the image)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const double v = (double)(TU)s[i]; q[i] = fma(v, v, q[i]); }
+        }
         if (full) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) up[4 * i * ldu + 16 * ct] = (TU)s[i];
@@ -175,6 +183,13 @@ __global__ __launch_bounds__(WS_WAVES * 64) void project_ws_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (blk0 + kk + 4 * i < hi) up[4 * i * ldu + 16 * ct] = (TU)s[i];
+        }
+      }
+      if (NRM) {                                             // the 16 lanes of a row hold its 16 RT columns: one DPP butterfly
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double t = group_sum_t<16>(q[i]);
+          if (li == i && blk0 + kk + 4 * i < hi) nrm2[blk0 + kk + 4 * i] = t;
         }
       }
     }
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(WS_WAVES * 64) void project_ws_kernel(
 template <int MT, int RT, typename TX, typename TU>
 int ws_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features,
               int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r, TU *Ur,
-              int64_t ldu, int accumulate, hipStream_t st) {
+              int64_t ldu, int accumulate, double *nrm2, hipStream_t st) {
   const int cus = spr_cached_cus();
   SegPlan plan;
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
@@ -196,8 +211,12 @@ int ws_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
   // stays on the general kernel
   const bool vec = (m == 16 * MT) && ((sizeof(TX) * ldx) % 16 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   if (!vec) return SPR_E_UNSUPPORTED;
-  hipLaunchKernelGGL((project_ws_kernel<MT, RT, 1, TX, TU>), dim3(grid), dim3(WS_WAVES * 64), 0, st, X, ldx, (int)m,
-                     center, plan, inv_scale, rowmean, W, (int)r, Ur, ldu);
+  if (nrm2)
+    hipLaunchKernelGGL((project_ws_kernel<MT, RT, 1, TX, TU, true>), dim3(grid), dim3(WS_WAVES * 64), 0, st, X, ldx, (int)m,
+                       center, plan, inv_scale, rowmean, W, (int)r, Ur, ldu, nrm2);
+  else
+    hipLaunchKernelGGL((project_ws_kernel<MT, RT, 1, TX, TU, false>), dim3(grid), dim3(WS_WAVES * 64), 0, st, X, ldx, (int)m,
+                       center, plan, inv_scale, rowmean, W, (int)r, Ur, ldu, nrm2);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
@@ -211,7 +230,8 @@ int ws_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
 template <typename TX, typename TU>
 int spr_project_ws(const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
                    int32_t n_features, int32_t center, const double *d_inv_scale, const double *d_rowmean,
-                   const double *d_W, int32_t r, TU *d_Ur, int64_t ldu, int32_t accumulate, hipStream_t st) {
+                   const double *d_W, int32_t r, TU *d_Ur, int64_t ldu, int32_t accumulate, double *d_rownorm2,
+                   hipStream_t st) {
   if (accumulate) return SPR_E_UNSUPPORTED;          // second column slice of a wide X: general kernel
   const int mt = spr_round_mt(m);
   const int need = (r + 15) / 16;
@@ -219,7 +239,7 @@ int spr_project_ws(const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_
 #define WS(MTV, RTV)                                                                                             \
   if (mt == MTV && rt == RTV)                                                                                    \
     return ws_launch<MTV, RTV, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale,   \
-                                        d_rowmean, d_W, r, d_Ur, ldu, accumulate, st)
+                                        d_rowmean, d_W, r, d_Ur, ldu, accumulate, d_rownorm2, st)
 #ifdef PROJ_WS_LAB
   WS(16, 4);
 #else
@@ -231,13 +251,13 @@ int spr_project_ws(const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_
 
 template int spr_project_ws<double, double>(const double *, int64_t, int32_t, int64_t, int64_t, int64_t, int32_t, int32_t,
                                             const double *, const double *, const double *, int32_t, double *, int64_t,
-                                            int32_t, hipStream_t);
+                                            int32_t, double *, hipStream_t);
 #ifndef PROJ_WS_LAB
 template int spr_project_ws<float, float>(const float *, int64_t, int32_t, int64_t, int64_t, int64_t, int32_t, int32_t,
                                           const double *, const double *, const double *, int32_t, float *, int64_t,
-                                          int32_t, hipStream_t);
+                                          int32_t, double *, hipStream_t);
 // f32 shard, f64 basis: the default for a float32 X (the reference's U is float64 whatever the dtype of X)
 template int spr_project_ws<float, double>(const float *, int64_t, int32_t, int64_t, int64_t, int64_t, int32_t, int32_t,
                                            const double *, const double *, const double *, int32_t, double *, int64_t,
-                                           int32_t, hipStream_t);
+                                           int32_t, double *, hipStream_t);
 #endif

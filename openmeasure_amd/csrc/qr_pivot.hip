@@ -469,6 +469,46 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_wide_kernel(
 }
 
 // grid = sweep blocks: copy each block's top rows into the compact candidate arrays
+// First "sweep" of a placement whose squared row norms already exist (written by the projection that stored the basis,
+// spr_project_norms_* / spr_project_stream_norms_*): 8 bytes per row are read instead of the whole basis.  nrm0 is copied
+// to the working vector nrm (the steps down-date it) and every workgroup leaves the QR_TOPT largest rows of ITS panels --
+// the same panel -> workgroup assignment as the sweep kernels (panel c belongs to workgroup c mod grid), so candidate
+// set and tau are those an init sweep over the same values would have drawn.  Wave w takes every fourth panel of the
+// workgroup, four panels per wave in flight; a lane meets its rows in increasing order (what TopList's tie rule needs).
+__global__ __launch_bounds__(QR_THREADS) void qr_tops_from_norms_kernel(const double *__restrict__ nrm0, int64_t n_rows,
+                                                                        int64_t row0, double *__restrict__ nrm,
+                                                                        double *__restrict__ tops) {
+  constexpr int R = 64, NWV = QR_THREADS / 64, SPW = 64;
+  __shared__ double smem[2 * NWV * SPW * QR_TOPT];
+  double *const sval = smem;
+  long long *const sidx = reinterpret_cast<long long *>(smem + NWV * SPW * QR_TOPT);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  TopList top;
+  top.init();
+  const int64_t npanels = (n_rows + R - 1) / R;
+  const int64_t stride = (int64_t)gridDim.x * NWV;
+  int64_t c = blockIdx.x + (int64_t)wave * gridDim.x;
+  for (; (c + 3 * stride + 1) * R <= n_rows; c += 4 * stride) {   // four panels, the furthest one complete
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = nrm0[(c + u * stride) * R + lane];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t row = (c + u * stride) * R + lane;
+      nrm[row] = v[u];
+      top.insert(v[u], row0 + row, true);
+    }
+  }
+  for (; c < npanels; c += stride) {
+    const int64_t row = c * R + lane;
+    const bool mine = row < n_rows;
+    const double v = nrm0[mine ? row : n_rows - 1];
+    if (mine) nrm[row] = v;
+    top.insert(v, row0 + row, mine);
+  }
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, true, lane);
+}
+
 template <typename TU>
 __global__ __launch_bounds__(QR_THREADS) void qr_gather_kernel(
     const double *__restrict__ tops, const TU *__restrict__ Ur, int r, int64_t ldu, int64_t row0,
@@ -893,6 +933,39 @@ extern "C" int spr_qr_init_u32(const float *d_Ur, int64_t n_rows, int32_t r, int
                                size_t workspace_bytes, void *stream) {
   return qr_init_entry("spr_qr_init_u32", d_Ur, n_rows, r, ldu, row0, d_nrm, d_rec, d_tau, d_workspace, workspace_bytes,
                        stream);
+}
+
+// ---- the same start from squared row norms that already exist (d_nrm0, left by spr_project_norms_* /
+// spr_project_stream_norms_* when it stored d_Ur): no pass over the basis.  d_nrm0 is not modified.
+template <typename TU>
+static int qr_init_norms_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                               const double *d_nrm0, double *d_nrm, double *d_rec, double *d_tau, void *d_workspace,
+                               size_t workspace_bytes, void *stream) {
+  int rc = check_ur(who, d_Ur, n_rows, r, ldu);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_nrm0 && d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
+  SPR_REQUIRE(d_nrm0 != d_nrm, SPR_E_INVALID, "%s: the given norms and the working vector must be different buffers", who);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(r), SPR_E_WORKSPACE, "%s: workspace too small", who);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = sweep_grid(n_rows);
+  QrWs w(d_workspace, r);
+  hipLaunchKernelGGL(qr_tops_from_norms_kernel, dim3(grid), dim3(QR_THREADS), 0, st, d_nrm0, n_rows, row0, d_nrm, w.tops);
+  SPR_LAUNCH_CHECK();
+  return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st);
+}
+
+extern "C" int spr_qr_init_norms_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                     const double *d_nrm0, double *d_nrm, double *d_rec, double *d_tau,
+                                     void *d_workspace, size_t workspace_bytes, void *stream) {
+  return qr_init_norms_entry("spr_qr_init_norms_f64", d_Ur, n_rows, r, ldu, row0, d_nrm0, d_nrm, d_rec, d_tau,
+                             d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int spr_qr_init_norms_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                     const double *d_nrm0, double *d_nrm, double *d_rec, double *d_tau,
+                                     void *d_workspace, size_t workspace_bytes, void *stream) {
+  return qr_init_norms_entry("spr_qr_init_norms_u32", d_Ur, n_rows, r, ldu, row0, d_nrm0, d_nrm, d_rec, d_tau,
+                             d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_recs, int32_t n_rec,

@@ -25,6 +25,8 @@ def _ptr(t):
 class HipEngine:
     name = 'hip-gfx950'
 
+    supports_row_norms = True      # project(norms=...) / qr_begin(norms=...): see ROM.placement_norms
+
     def __init__(self, device=None):
         import torch
         self.torch = torch
@@ -284,38 +286,60 @@ class HipEngine:
 
     # ---- K4 --------------------------------------------------------------------------------
     def _project_group(self, X, i0, rows, row0, n_points, n_features, inv_scale, Wg, rowmean, center, out_ptr, ldu,
-                       out_f64, precenter):
+                       out_f64, precenter, norms=None):
         """One column group (q <= SPR_MAX_R columns of W, packed m x q) of the projection of rows [i0, i0+rows) of X,
         written at out_ptr with row stride ldu.  m <= 256: W-stationary / register-resident kernels (spr_project_*);
         wider X, or row means that must be removed before the multiplication: the streamed-W kernel, one launch over
-        the full contraction length (spr_project_stream_*)."""
+        the full contraction length (spr_project_stream_*).  ``norms``: a (rows,) float64 tensor that receives the squared
+        norms of the stored rows (spr_project_norms_* where the W-stationary kernel takes the shape, the streamed-W
+        kernel for every other one)."""
         n, m, ld = self._check_matrix(X)
         q = Wg.shape[1]
         f32 = X.dtype == self.torch.float32
         xp = X.data_ptr() + i0 * ld * X.element_size()
         mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
         st = self._stream()
-        if m > _lib.SPR_MAX_M or (precenter and center) or self._force_stream:
-            name = 'spr_project_stream_f64' if not f32 else ('spr_project_stream_x32_f64out' if out_f64 else
-                                                             'spr_project_stream_x32')
+        sfx = '_f64' if not f32 else ('_x32_f64out' if out_f64 else '_x32')
+        stream = m > _lib.SPR_MAX_M or (precenter and center) or self._force_stream
+        if norms is not None and not stream:
+            stream = not self.lib.spr_project_norms_supported(m, q, rows, ld, xp, int(f32))
+        if stream:
+            name = ('spr_project_stream' if norms is None else 'spr_project_stream_norms') + sfx
             nbytes = self.lib.spr_project_stream_workspace(m, q, int(f32))
             ws = self._workspace('pstream', nbytes)
+            extra = () if norms is None else (_ptr(norms),)
             _lib.check(getattr(self.lib, name)(xp, rows, m, ld, row0 + i0, n_points, n_features,
                                                (2 if precenter else 1) if center else 0, _ptr(inv_scale), mean_p,
-                                               _ptr(Wg), q, out_ptr, ldu, _ptr(ws), ws.numel(), st), name)
+                                               _ptr(Wg), q, out_ptr, ldu, *extra, _ptr(ws), ws.numel(), st), name)
+        elif norms is not None:
+            name = 'spr_project_norms' + sfx
+            _lib.check(getattr(self.lib, name)(xp, rows, m, ld, row0 + i0, n_points, n_features, int(bool(center)),
+                                               _ptr(inv_scale), mean_p, _ptr(Wg), q, out_ptr, ldu, _ptr(norms), st), name)
         else:
-            name = 'spr_project_f64' if not f32 else ('spr_project_x32_f64out' if out_f64 else 'spr_project_x32')
+            name = 'spr_project' + sfx
             _lib.check(getattr(self.lib, name)(xp, rows, m, ld, row0 + i0, n_points, n_features, int(bool(center)),
                                                _ptr(inv_scale), mean_p, _ptr(Wg), q, out_ptr, ldu, 0, st), name)
 
+    def project_writes_norms(self, X, r, center=True, precenter=False):
+        """Does the projection kernel this shape takes ANYWAY produce row norms (project(norms=...) then costs no change
+        of kernel)?  True for the W-stationary and the streamed-W kernel, False where the general kernel runs."""
+        n, m, ld = self._check_matrix(X)
+        if r > _lib.SPR_MAX_R:
+            return False
+        if m > _lib.SPR_MAX_M or (precenter and center) or self._force_stream:
+            return True
+        return bool(self.lib.spr_project_norms_supported(m, r, n, ld, X.data_ptr(), int(X.dtype == self.torch.float32)))
+
     def project(self, X, row0, n_points, n_features, inv_scale, W, center=True, out=None, rowmean=None,
-                basis_dtype=None, precenter=False):
+                basis_dtype=None, precenter=False, norms=None):
         """Ur = ((X - rowmean) W) / X_scl ; W is (m,r) on the device. -> (n, r) tensor, row stride even.
         ``out``: a previous result of the same shape to overwrite (keeps one basis buffer alive).
         ``rowmean``: the row means from stats_gram (required when center=True).
         ``basis_dtype``: storage type of the result; default float64 (the reference's U is float64 whatever the dtype
         of X, sparse_sensing.py:106-107, :169, :272); torch.float32 only for a float32 X (storage option).
         ``precenter``: subtract the row means before the multiplication instead of in the epilogue.
+        ``norms``: a (n,) float64 tensor to receive the squared norms of the rows as stored (r <= 128 only: one column
+        group) -- what qr_begin(norms=...) starts a placement from without reading the basis again.
         Any m; r > 128 goes in column groups of 128 (each one more read of X)."""
         if center and rowmean is None:
             raise ValueError('project(center=True) needs the row means of the Gram pass')
@@ -336,11 +360,13 @@ class HipEngine:
         tic()
         Wc = W.contiguous()
         G = _lib.SPR_MAX_R
+        if norms is not None and (r > G or tuple(norms.shape) != (n,) or norms.dtype != t.float64):
+            raise ValueError('project(norms=...): a float64 vector with one entry per row, r <= 128')
         for g0 in range(0, r, G):
             qg = min(G, r - g0)
             Wg = Wc if qg == r else Wc[:, g0:g0 + qg].contiguous()
             self._project_group(X, 0, n, row0, n_points, n_features, inv_scale, Wg, rowmean, center,
-                                buf.data_ptr() + g0 * buf.element_size(), ldu, dt == t.float64, precenter)
+                                buf.data_ptr() + g0 * buf.element_size(), ldu, dt == t.float64, precenter, norms)
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf
 
@@ -441,8 +467,10 @@ class HipEngine:
     def qr_batch(self):
         return int(self.lib.spr_qr_batch())
 
-    def qr_begin(self, Ur, row0, n_steps):
-        """Allocate the pivoting state; initial norms, candidate set, local record and tau."""
+    def qr_begin(self, Ur, row0, n_steps, norms=None):
+        """Allocate the pivoting state; initial norms, candidate set, local record and tau.  ``norms``: the squared row
+        norms project(norms=...) left when it stored this very Ur -- the start then reads them (8 bytes per row) instead
+        of sweeping the basis; the vector itself is not modified."""
         n, r, ldu = self._check_matrix(Ur)
         if r > _lib.SPR_MAX_R_WIDE:
             raise NotImplementedError(f'placement: r={r} modes exceed the built range (1..{_lib.SPR_MAX_R_WIDE})')
@@ -452,6 +480,13 @@ class HipEngine:
                   Q=self.zeros((n_steps, r)), piv=self.zeros((n_steps,), dtype=t.int64),
                   gap=self.zeros((n_steps,)), ok=self.zeros((n_steps,)),
                   ws=self._workspace('qr', self.lib.spr_qr_workspace_r(n, r)))
+        if norms is not None:
+            if tuple(norms.shape) != (n,) or norms.dtype != t.float64:
+                raise ValueError('qr_begin(norms=...): a float64 vector with one entry per row of Ur')
+            _lib.check(self._u('spr_qr_init_norms', Ur)(_ptr(Ur), n, r, ldu, row0, _ptr(norms), _ptr(st['nrm']),
+                                                      _ptr(st['rec']), _ptr(st['tau']), _ptr(st['ws']),
+                                                      st['ws'].numel(), self._stream()), 'spr_qr_init_norms_f64')
+            return st
         _lib.check(self._u('spr_qr_init', Ur)(_ptr(Ur), n, r, ldu, row0, _ptr(st['nrm']), _ptr(st['rec']),
                                             _ptr(st['tau']), _ptr(st['ws']), st['ws'].numel(), self._stream()),
                    'spr_qr_init_f64')

@@ -404,6 +404,14 @@ class ROM:
     # ------------------------------------------------------------------ lazily fetched fit results
     _LAZY = ('Ar', 'Sigma_r', 'Vr', 'exp_variance_', 'S_', '_scl_f', '_var_f')
 
+    #: Squared row norms of the basis as a by-product of fit(): the projection that stores Ur also leaves |Ur[i, :]|^2 of
+    #: every row it wrote (8 bytes per row), and optimal_placement('qr') starts from that vector instead of reading the
+    #: whole basis once more (one sweep of 46 GB less at BASELINE config 3; same sensors).  None ("auto", the default of
+    #: SPR): whenever the projection kernel the shape takes anyway produces them at no measurable cost (the W-stationary
+    #: and the streamed-W kernel: every BASELINE shape but config 1/2); True: always (m <= 256 shapes outside the
+    #: W-stationary kernel's range then run the streamed-W kernel); False (ROM, whose users never place sensors): never.
+    placement_norms = False
+
     def __getattr__(self, name):
         # only reached when normal lookup fails: results of the sync-free device fit (m <= 64) stay in HBM
         # until somebody reads them
@@ -458,6 +466,16 @@ class ROM:
                 # a float32 snapshot matrix stays float32 in HBM (storage only, see DeviceMatrix)
                 self._d['X'] = eng.to_device(self.X, dtype=eng.torch.float32 if self.X.dtype == np.float32 else None)
         return self._d['X']
+
+    def _norms_buffer(self, Xd, r, precenter=False):
+        """The vector the projection writes the squared row norms to (see placement_norms), or None."""
+        eng = self._engine()
+        want = self.placement_norms
+        if want is False or r > 128 or not getattr(eng, 'supports_row_norms', False):
+            return None
+        if want is None and not eng.project_writes_norms(Xd, r, True, precenter):
+            return None
+        return eng.empty((Xd.shape[0],))
 
     def _basis_dtype(self):
         """storage type of Ur: float64 (the reference's, for any dtype of X) unless DeviceMatrix(basis='f32')"""
@@ -518,6 +536,7 @@ class ROM:
     def Ur(self, value):
         # subclasses written against the reference assign the result of decomposition() (gpr.py:386):
         # that array already has its device twin; anything else is uploaded
+        self._d.pop('nrm0', None)                             # row norms of the basis fit() stored, not of this one
         last = self.__dict__.get('_last_decomp')
         if last is not None and value is last[0]:
             self._d['Ur'] = last[1]
@@ -945,9 +964,13 @@ class ROM:
         W_d = eng.to_device(W)
         self._trace.mark('upload')
         self.precentered_ = bool(center and self._needs_precenter(S[0] / S_safe[-1]))
+        nrm0 = self._norms_buffer(Xd, r, self.precentered_ and center)
+        kw = {} if nrm0 is None else {'norms': nrm0}
         Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, W_d,
                            center=center, out=self._d.pop('Ur', None), rowmean=self._d.get('rowmean'),
-                           basis_dtype=self._basis_dtype(), precenter=self.precentered_)
+                           basis_dtype=self._basis_dtype(), precenter=self.precentered_, **kw)
+        if nrm0 is not None:
+            self._d['nrm0'] = nrm0
         self._trace.mark('project')
         Ar = V[:, :r] * S[:r]                                # A = (diag(S) Vt).T  (:273)
         return Ur_d, Ar, exp_variance[:r], S, r, V[:, :r]
@@ -962,6 +985,7 @@ class ROM:
             G = self._G
             self._trace = _Trace(eng)
             self._d.pop('Ur', None)
+            self._d.pop('nrm0', None)
             Ur_d, Ar, expv, _, r, _ = self._basis_from_gram(G, select_modes, n_modes, True, self._d['inv_scale'])
         else:
             X0d = eng.to_device(X0)
@@ -994,7 +1018,7 @@ class ROM:
         self.scale_type = scale_type
         for k in ROM._LAZY + ('C', 'Theta', '_pending'):
             self.__dict__.pop(k, None)
-        for k in ('cnt', 'Theta'):                            # a new basis invalidates the trained measurement state
+        for k in ('cnt', 'Theta', 'nrm0'):                    # a new basis invalidates the trained measurement state
             self._d.pop(k, None)
         took = self._device_fit(scale_type, axis_cnt, select_modes, n_modes, basis)
         if took is True:
@@ -1046,8 +1070,12 @@ class ROM:
         self._d['rowmean'] = rowmean
         self._d['scale'] = sp['scale']
         self._d['inv_scale'] = sp['inv_scale']
+        nrm0 = self._norms_buffer(Xd, r)
+        kw = {} if nrm0 is None else {'norms': nrm0}
         self._d['Ur'] = eng.project(Xd, self._row0, self.n_points, F, sp['inv_scale'], sp['W'], center=True,
-                                    out=self._d.pop('Ur', None), rowmean=rowmean, basis_dtype=self._basis_dtype())
+                                    out=self._d.pop('Ur', None), rowmean=rowmean, basis_dtype=self._basis_dtype(), **kw)
+        if nrm0 is not None:
+            self._d['nrm0'] = nrm0
         tr_.mark('project')
         # the only download of this path: the two singular values that decide whether the Gram route was good enough,
         # the Jacobi verdict (sweeps, off^2, diag^2) and the feature statistics -- fetched after the projection has been
@@ -1132,6 +1160,8 @@ class ROM:
 class SPR(ROM):
     """Sparse Placement for Reconstruction (reference: SPR, sparse_sensing.py:513-901)."""
 
+    placement_norms = None      # "auto": see ROM.placement_norms
+
     def __init__(self, X, n_features, xyz, shard=None, engine=None):
         super().__init__(X, n_features, xyz, shard=shard, engine=engine)
 
@@ -1153,10 +1183,16 @@ class SPR(ROM):
                 raise IndexError('mask must be a boolean array with one entry per (local) row')
             eng.mask_rows(Ur_d, eng.to_device(mask.astype(np.uint8), dtype=eng.torch.uint8))   # :737-738
             self._host.pop('Ur', None)
+            self._d.pop('nrm0', None)                         # rows were zeroed: the norms fit() left no longer hold
         s = self.r
-        st = eng.qr_begin(Ur_d, self._row0, s)
+        nrm0 = self._d.get('nrm0')                            # left by fit() under placement_norms, for this very basis
+        self.placement_from_norms_ = nrm0 is not None and nrm0.shape[0] == Ur_d.shape[0]
+        if self.placement_from_norms_:
+            st = eng.qr_begin(Ur_d, self._row0, s, norms=nrm0)
+        else:
+            st = eng.qr_begin(Ur_d, self._row0, s)
         sweeps = pivot_loop(eng, st, s, self._all_gather if self._dist() else None)
-        self.pivot_sweeps_ = sweeps
+        self.pivot_sweeps_ = sweeps - int(self.placement_from_norms_)   # passes over the basis (the start read none)
         piv = eng.to_host(st['piv']).astype(np.int64)
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])

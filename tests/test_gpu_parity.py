@@ -317,6 +317,103 @@ def test_project_stream_random_shapes(eng, seed):
     assert np.abs(U0 - ref0).max() <= tol * np.abs(ref0).max(), (m, r, 'uncentred')
 
 
+@pytest.mark.parametrize('n_points,F,m,r,f32,f32_basis,pre', [
+    (9000, 3, 256, 64, False, False, False),     # W-stationary kernel (config 3/4 shape)
+    (5000, 2, 128, 30, False, False, False),     # W-stationary, padded column tile
+    (4100, 2, 192, 64, True, True, False),       # W-stationary, f32 shard and basis: norms of the ROUNDED rows
+    (4100, 2, 192, 33, True, False, False),      # W-stationary, f32 shard, f64 basis
+    (1000, 2, 256, 64, False, False, False),     # fewer than 4096 rows: not W-stationary -> streamed-W kernel
+    (3000, 4, 64, 32, False, False, False),      # config-2 shape: streamed-W kernel
+    (1500, 9, 41, 14, False, False, False),      # config-1 shape: odd m, scalar loads
+    (2000, 16, 512, 128, True, True, False),     # config-5 shape
+    (2500, 2, 300, 40, False, False, True),      # pre-centred operand
+    (999, 3, 600, 128, True, False, False)])
+def test_project_row_norms(eng, n_points, F, m, r, f32, f32_basis, pre):
+    """project(norms=...) (spr_project_norms_* / spr_project_stream_norms_*): the vector holds the squared norms of the
+    rows of Ur as STORED -- for an f32 basis of the rounded values, not of the f64 accumulators --, the basis itself is
+    bitwise the one the plain call writes; ragged last block, shard starting inside a feature."""
+    import torch
+    rng = np.random.default_rng(m * 1000 + r)
+    n = n_points * F
+    row0 = n // 5
+    n_loc = n - row0 - 7
+    X = rng.standard_normal((n_loc, m)) * 2.0 + rng.standard_normal((n_loc, 1)) * 5.0
+    if f32:
+        X = X.astype(np.float32).astype(np.float64)
+    Xd = eng.to_device(X.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(X)
+    mu = eng.to_device(X.mean(axis=1))
+    isc = eng.to_device(1.0 / (0.5 + rng.random(F)))
+    W = eng.to_device(rng.standard_normal((m, r)) / np.sqrt(m))
+    bd = torch.float32 if f32_basis else None
+    nrm = eng.empty((n_loc,))
+    nrm.fill_(-7.0)
+    U = eng.project(Xd, row0, n_points, F, isc, W, rowmean=mu, basis_dtype=bd, precenter=pre, norms=nrm)
+    U_plain = eng.project(Xd, row0, n_points, F, isc, W, rowmean=mu, basis_dtype=bd, precenter=pre)
+    if not (eng.lib.spr_project_norms_supported(m, r, n_loc, Xd.stride(0), Xd.data_ptr(), int(f32)) == 0 and m <= 256
+            and not pre):
+        # same kernel with and without the norm epilogue: bitwise the same basis (a shape that only takes the
+        # streamed-W kernel BECAUSE norms were asked for is compared to the general kernel's result instead)
+        assert torch.equal(U, U_plain)
+    else:
+        assert float((U.double() - U_plain.double()).abs().max()) <= 1e-12 * float(U_plain.double().abs().max())
+    ref = (U.double() ** 2).sum(dim=1)
+    got = eng.to_host(nrm)
+    np.testing.assert_allclose(got, eng.to_host(ref), rtol=2e-15 * max(r, 8), atol=0.0)
+
+
+@pytest.mark.parametrize('n_points,F,m,r,f32_basis', [(20000, 4, 256, 64, False), (20000, 4, 64, 32, False),
+                                                    (18362, 9, 41, 14, False), (6000, 16, 512, 128, True),
+                                                    (3000, 2, 300, 100, False)])
+def test_placement_from_fused_norms(eng, n_points, F, m, r, f32_basis):
+    """ROM.placement_norms: fit() leaves the squared row norms, optimal_placement() starts from them -- one pass over the
+    basis fewer, the same ordered sensors and gaps as the plain route (and as the oracle), also through a mask (which
+    zeroes rows: the stored norms are dropped), a re-fit and an assigned basis."""
+    import torch
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    rho = 10 ** (-3 / (r - 1))
+    X = synth_host(n_points, F, m, min(m, 2 * r), rho, 1e-3, 5 + m)
+    if f32_basis:
+        Xin = DeviceMatrix(eng.to_device(X.astype(np.float32), dtype=torch.float32), basis='f32')
+    else:
+        Xin = X
+    plain = SPR(Xin, F, None, engine=eng)
+    plain.placement_norms = False
+    plain.fit(select_modes='number', n_modes=r)
+    plain.optimal_placement()
+    assert plain.placement_from_norms_ is False
+    auto = SPR(Xin, F, None, engine=eng)                       # default: norms where the shape's own kernel writes them
+    auto.fit(select_modes='number', n_modes=r)
+    auto.optimal_placement()
+    assert auto.placement_from_norms_ is (m > 256 or (m, r) == (256, 64))
+    np.testing.assert_array_equal(auto.sensors_, plain.sensors_)
+    fused = SPR(Xin, F, None, engine=eng)
+    fused.placement_norms = True
+    fused.fit(select_modes='number', n_modes=r)
+    fused.optimal_placement()
+    assert fused.placement_from_norms_ is True
+    np.testing.assert_array_equal(fused.sensors_, plain.sensors_)
+    np.testing.assert_allclose(fused.pivot_gap_, plain.pivot_gap_, rtol=1e-9, atol=1e-14)
+    assert fused.pivot_sweeps_ == plain.pivot_sweeps_ - 1
+    if not f32_basis:
+        np.testing.assert_array_equal(fused.sensors_, orc.qr_pivots(orc.fit(X, F, 'number', r)['Ur'])[0])
+    fused.optimal_placement()                                  # the stored vector is not consumed
+    assert fused.placement_from_norms_ is True
+    np.testing.assert_array_equal(fused.sensors_, plain.sensors_)
+    mask = np.ones(X.shape[0], dtype=bool)
+    mask[plain.sensors_[:3]] = False
+    fused.optimal_placement(mask=mask)                         # rows zeroed in place (:737-738): norms no longer valid
+    assert fused.placement_from_norms_ is False
+    plain.optimal_placement(mask=mask)
+    np.testing.assert_array_equal(fused.sensors_, plain.sensors_)
+    fused.fit(select_modes='number', n_modes=r)                # a new fit leaves new norms
+    fused.optimal_placement()
+    assert fused.placement_from_norms_ is True
+    fused.placement_norms = False
+    fused.fit(select_modes='number', n_modes=max(r - 1, 1))
+    fused.optimal_placement()
+    assert fused.placement_from_norms_ is False and len(fused.sensors_) == max(r - 1, 1)
+
+
 def test_project_precentred_large_means(eng):
     """Row means 1e6 times the fluctuation (pressure / temperature fields): removing the mean in the epilogue,
     x.W - mean (1^T W), loses 6 digits to cancellation; centre mode 2 of the streamed-W kernel subtracts it from the

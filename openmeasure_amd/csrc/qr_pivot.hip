@@ -30,6 +30,9 @@
 namespace {
 
 constexpr int QR_THREADS = 256;
+#ifndef QR_ABLATE
+#define QR_ABLATE 0   // diagnostics (tools/ablate.sh, wrong results): 1 = sweeps keep no candidate lists, 2 = nor touch the norm vector
+#endif
 #ifndef QR_TOPT_N
 #define QR_TOPT_N 16   // 16 instead of 8: 5 sweeps instead of 6 at config 3 (55.6 -> 49.7 ms, tools/topt_ab.sh); a batch of
                        // 32 directions on top of that certified [18,16,14,10,6]: still 5 sweeps, each slower
@@ -161,6 +164,31 @@ struct TopList {
   }
 };
 
+// Who writes a row's norm at the end of a sweep block (all three kernel forms).  The 16 x 16 MFMA result of a wave's
+// 16-row block leaves lane (g = lane >> 4, c = lane & 15) with the entries (row g + 4 q, column c), q = 0..3.
+//   refresh: after the 16-lane sums every lane of group g holds the squared projections of rows g + 4 q -- lane (g, c < 4)
+//            takes row g + 4 c (its register q = c);
+//   init:    the diagonal entry of row c sits in lane (g = c & 3, c), register q = c >> 2 -- that lane takes row c.
+// Either way the 16 owners of a block read (refresh) and write 16 CONSECUTIVE doubles of the norm vector with one load and
+// one store instruction per wave.  The first form of these kernels let lane (g, 0) write its four rows with four stores of
+// four scattered 8-byte pieces each: at config 3 the 0.72 GB norm vector then cost 1.8 ms of a 9.4 ms sweep
+// (tools/ablate.sh -DQR_ABLATE=2) -- partial-line writes, four instructions per 128-byte line.
+template <bool INIT>
+struct RowOwner {
+  int off, q;        // row of the block this lane reads / writes, register holding its value
+  bool own;
+  __device__ inline RowOwner(int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    if (INIT) { off = c; q = c >> 2; own = (c & 3) == g; }
+    else { off = g + 4 * (c & 3); q = c & 3; own = c < 4; }     // lanes c >= 4 mirror an owner's address: loads only
+  }
+  __device__ inline int slot(int lane) const { return INIT ? ((lane >> 4) * 4 + ((lane & 15) >> 2)) : ((lane >> 4) * 4 + (lane & 3)); }
+  __device__ inline double pick(double v0, double v1, double v2, double v3) const {
+    return q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3;
+  }
+};
+constexpr int QR_SPW = 16;   // owner lanes (and candidate lists) per wave
+
 // Refresh sweep, MFMA form: nrm <- nrm - sum_t (u_i . q_t)^2 for up to 16 directions at once.
 // Panels of 64 rows of Ur go to LDS raw (rowtile.hpp staging, double-buffered, loads of the panel
 // after next issued behind the stores); wave w multiplies its 16-row block with Q^T (directions as
@@ -177,7 +205,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
   constexpr int NW = QR_THREADS / 64, R = 64;
   constexpr int MPAD = 16 * MTR, MP = MPAD + 2, KSTEPS = MPAD / 4;
   using RT = RowTile<MTR, R, MP, NW, 16, TU>;
-  constexpr int SPW = INIT ? 16 : 4;                       // lanes of a wave that own rows (and so a top list)
+  constexpr int SPW = QR_SPW;                              // lanes of a wave that own rows (and so a top list)
   constexpr int PANELS = 2 * R * MP, MERGE = 2 * (QR_THREADS / 64) * SPW * QR_TOPT;
   __shared__ double smem[PANELS > MERGE ? PANELS : MERGE];    // panels during the sweep, merge lists afterwards
   double *const lds0 = smem, *const lds1 = smem + R * MP;
@@ -194,6 +222,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
   }
   TopList top;
   top.init();
+  const RowOwner<INIT> who(lane);
   RT tile;
   const int64_t npanels = (n_rows + R - 1) / R;
   int64_t c = blockIdx.x;
@@ -205,19 +234,22 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
     tile.template load<VEC>(Ur, ldu, r, nrow0, n_rows, wave, lane);
     int buf = 0;
     const int afrag = (lane & 15) * MP + (lane >> 4);
+    // the old norm of this lane's row, two panels ahead like the rows themselves: a load issued in the iteration that
+    // consumes it leaves one HBM latency exposed per panel (a panel's 16 dependent MFMAs are shorter than that)
+    auto old_of = [&](int64_t row0p) {
+      const int64_t rr = row0p + wave * 16 + who.off;
+      return (INIT || QR_ABLATE >= 2) ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];
+    };
+    double old = old_of(c * R), old_n = old_of(nrow0);
     while (c < npanels) {
       const double *cur = buf ? lds1 : lds0;
       double *nxt = buf ? lds0 : lds1;
       const int64_t c2 = cn + gridDim.x;
       const int64_t n2row0 = (c2 < npanels) ? c2 * R : n_rows;
       __syncthreads();
-      const int64_t brow = c * R + wave * 16 + (lane >> 4);       // this lane's first row of the block
-      double old[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t rr = brow + 4 * i;
-        old[i] = INIT ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];  // requested before the MFMAs
-      }
+      const int64_t orow = c * R + wave * 16 + who.off;          // the row this lane reads / writes (RowOwner)
+      const bool mine = who.own && orow < n_rows;
+      const double old_n2 = old_of(n2row0);
       const double *p = cur + wave * 16 * MP + afrag;
       f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -232,31 +264,21 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
           }
         }
       }
+      double v;
       if (INIT) {
-        // D[i][j] = u_i . u_j of the block: lane (g = lane >> 4, c = lane & 15) holds D[g + 4 q][c]; the diagonal
-        // entry of row c sits in the lane with g == (c & 3), register q = c >> 2
-        const double dv[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t rr = brow + 4 * i;
-          const bool mine = ((lane & 15) == (lane >> 4) + 4 * i) && (rr < n_rows);
-          if (mine) nrm[rr] = dv[i];
-          top.insert(dv[i], row0 + rr, mine);
-        }
+        v = who.pick(acc.x, acc.y, acc.z, acc.w);            // D[i][j] = u_i . u_j of the block: its diagonal
       } else {
-        const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
-                              group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t rr = brow + 4 * i;
-          const bool mine = ((lane & 15) == 0) && (rr < n_rows);
-          double v = old[i] - d2[i];
-          v = v < 0.0 ? 0.0 : v;
-          v = old[i] < 0.0 ? -1.0 : v;
-          if (mine) nrm[rr] = v;
-          top.insert(v, row0 + rr, mine);
-        }
+        const double d2 = who.pick(group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
+                                   group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w));
+        v = old - d2;
+        v = v < 0.0 ? 0.0 : v;
+        v = old < 0.0 ? -1.0 : v;
       }
+      if (QR_ABLATE >= 2) asm volatile("" ::"v"(v));
+      if (QR_ABLATE < 2 && mine) nrm[orow] = v;
+      if (QR_ABLATE < 1) top.insert(v, row0 + orow, mine);
+      old = old_n;
+      old_n = old_n2;
       buf ^= 1;
       c = cn;
       cn = c2;
@@ -264,11 +286,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_mfma_kernel(
     }
   }
   __syncthreads();   // the panels are dead from here on: their LDS is reused for the merge
-  // owners: refresh -- lanes 0/16/32/48 (rows a, a+4, a+8, a+12 of the block); init -- the lane holding the diagonal
-  // entry of its row, (lane & 15) = (lane >> 4) + 4 i
-  const bool owner = INIT ? (((lane & 15) & 3) == (lane >> 4)) : ((lane & 15) == 0);
-  const int slot = INIT ? ((lane >> 4) * 4 + ((lane & 15) >> 2)) : (lane >> 4);
-  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, who.own, who.slot(lane));
 }
 
 // Refresh / init sweep, register-direct form (r a multiple of 16, rows 16-byte aligned): the same arithmetic, the same
@@ -285,7 +303,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_direct_kernel(
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
     const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
   constexpr int R = 64;
-  constexpr int SPW = INIT ? 16 : 4;
+  constexpr int SPW = QR_SPW;
   __shared__ double smem[2 * (QR_THREADS / 64) * SPW * QR_TOPT];
   double *const sval = smem;
   long long *const sidx = reinterpret_cast<long long *>(smem + (QR_THREADS / 64) * SPW * QR_TOPT);
@@ -302,6 +320,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_direct_kernel(
       bfrag[4 * g + t] = (!INIT && li < nq) ? Q[(int64_t)li * r + 16 * g + 4 * kk + t] : 0.0;
   TopList top;
   top.init();
+  const RowOwner<INIT> who(lane);
   const int64_t npanels = (n_rows + R - 1) / R;
   auto load_block = [&](int64_t c, P4 (&dst)[NG]) {
     int64_t row = c * R + wave * 16 + li;
@@ -310,19 +329,20 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_direct_kernel(
 #pragma unroll
     for (int g = 0; g < NG; ++g) dst[g] = *reinterpret_cast<const P4 *>(rp + 16 * g);
   };
+  auto old_of = [&](int64_t cc) {                          // the old norm of this lane's row of block cc
+    const int64_t rr = cc * R + wave * 16 + who.off;
+    return INIT ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];
+  };
   int64_t c = blockIdx.x;
   P4 cur[NG], nxt[NG];
-  if (c < npanels) load_block(c, cur);
+  double old = 0.0;
+  if (c < npanels) { load_block(c, cur); old = old_of(c); }
   while (c < npanels) {
     const int64_t cn = c + gridDim.x;
     load_block(cn < npanels ? cn : c, nxt);
-    const int64_t brow = c * R + wave * 16 + kk;           // this lane's first output row of the block
-    double old[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t rr = brow + 4 * i;
-      old[i] = INIT ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];
-    }
+    const double old_n = old_of(cn < npanels ? cn : c);    // one block ahead, like the rows
+    const int64_t orow = c * R + wave * 16 + who.off;      // the row this lane reads / writes (RowOwner)
+    const bool mine = who.own && orow < n_rows;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -331,36 +351,24 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_direct_kernel(
       for (int t = 0; t < 4; ++t)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], INIT ? a4[t] : bfrag[4 * g + t], acc, 0, 0, 0);
     }
+    double v;
     if (INIT) {
-      const double dv[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t rr = brow + 4 * i;
-        const bool mine = (li == kk + 4 * i) && (rr < n_rows);
-        if (mine) nrm[rr] = dv[i];
-        top.insert(dv[i], row0 + rr, mine);
-      }
+      v = who.pick(acc.x, acc.y, acc.z, acc.w);
     } else {
-      const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
-                            group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t rr = brow + 4 * i;
-        const bool mine = (li == 0) && (rr < n_rows);
-        double v = old[i] - d2[i];
-        v = v < 0.0 ? 0.0 : v;
-        v = old[i] < 0.0 ? -1.0 : v;
-        if (mine) nrm[rr] = v;
-        top.insert(v, row0 + rr, mine);
-      }
+      const double d2 = who.pick(group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
+                                 group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w));
+      v = old - d2;
+      v = v < 0.0 ? 0.0 : v;
+      v = old < 0.0 ? -1.0 : v;
     }
+    if (mine) nrm[orow] = v;
+    top.insert(v, row0 + orow, mine);
 #pragma unroll
     for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
+    old = old_n;
     c = cn;
   }
-  const bool owner = INIT ? ((li & 3) == kk) : (li == 0);
-  const int slot = INIT ? (kk * 4 + (li >> 2)) : kk;
-  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, who.own, who.slot(lane));
 }
 
 // Refresh / init sweep for a basis wider than 128 columns (r <= SPR_MAX_R_WIDE; the reference pivots Ur^T for any r <= m,
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_wide_kernel(
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
     const double *__restrict__ Q, int nq, double *__restrict__ nrm, double *__restrict__ tops) {
   constexpr int R = 64, SG = 8;                             // rows per workgroup step; groups per register batch
-  constexpr int SPW = INIT ? 16 : 4;
+  constexpr int SPW = QR_SPW;
   __shared__ double smem[2 * (QR_THREADS / 64) * SPW * QR_TOPT];
   __shared__ double Ql[INIT ? 16 : NGMAX * 256];
   double *const sval = smem;
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_wide_kernel(
   }
   TopList top;
   top.init();
+  const RowOwner<INIT> who(lane);
   const int64_t npanels = (n_rows + R - 1) / R;
   auto load_batch = [&](const TU *rp, int g0, P4 (&dst)[SG]) {
 #pragma unroll
@@ -414,13 +423,9 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_wide_kernel(
     int64_t row = c * R + wave * 16 + li;
     row = row < n_rows ? row : n_rows - 1;                  // rows past the end re-read the last row; never stored
     const TU *rp = Ur + row * ldu;
-    const int64_t brow = c * R + wave * 16 + kk;            // this lane's first output row of the block
-    double old[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t rr = brow + 4 * i;
-      old[i] = INIT ? 0.0 : nrm[rr < n_rows ? rr : n_rows - 1];
-    }
+    const int64_t orow = c * R + wave * 16 + who.off;       // the row this lane reads / writes (RowOwner)
+    const bool mine = who.own && orow < n_rows;
+    const double old = INIT ? 0.0 : nrm[orow < n_rows ? orow : n_rows - 1];
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     P4 cur[SG], nxt[SG];
     load_batch(rp, 0, cur);
@@ -439,36 +444,22 @@ __global__ __launch_bounds__(QR_THREADS) void qr_refresh_wide_kernel(
 #pragma unroll
       for (int u = 0; u < SG; ++u) cur[u] = nxt[u];
     }
+    double v;
     if (INIT) {
-      const double dv[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t rr = brow + 4 * i;
-        const bool mine = (li == kk + 4 * i) && (rr < n_rows);
-        if (mine) nrm[rr] = dv[i];
-        top.insert(dv[i], row0 + rr, mine);
-      }
+      v = who.pick(acc.x, acc.y, acc.z, acc.w);
     } else {
-      const double d2[4] = {group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
-                            group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w)};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t rr = brow + 4 * i;
-        const bool mine = (li == 0) && (rr < n_rows);
-        double v = old[i] - d2[i];
-        v = v < 0.0 ? 0.0 : v;
-        v = old[i] < 0.0 ? -1.0 : v;
-        if (mine) nrm[rr] = v;
-        top.insert(v, row0 + rr, mine);
-      }
+      const double d2 = who.pick(group_sum_t<16>(acc.x * acc.x), group_sum_t<16>(acc.y * acc.y),
+                                 group_sum_t<16>(acc.z * acc.z), group_sum_t<16>(acc.w * acc.w));
+      v = old - d2;
+      v = v < 0.0 ? 0.0 : v;
+      v = old < 0.0 ? -1.0 : v;
     }
+    if (mine) nrm[orow] = v;
+    top.insert(v, row0 + orow, mine);
   }
-  const bool owner = INIT ? ((li & 3) == kk) : (li == 0);
-  const int slot = INIT ? (kk * 4 + (li >> 2)) : kk;
-  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, owner, slot);
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, who.own, who.slot(lane));
 }
 
-// grid = sweep blocks: copy each block's top rows into the compact candidate arrays
 // First "sweep" of a placement whose squared row norms already exist (written by the projection that stored the basis,
 // spr_project_norms_* / spr_project_stream_norms_*): 8 bytes per row are read instead of the whole basis.  nrm0 is copied
 // to the working vector nrm (the steps down-date it) and every workgroup leaves the QR_TOPT largest rows of ITS panels --
@@ -509,6 +500,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_tops_from_norms_kernel(const do
   top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, true, lane);
 }
 
+// grid = sweep blocks: copy each block's top rows into the compact candidate arrays
 template <typename TU>
 __global__ __launch_bounds__(QR_THREADS) void qr_gather_kernel(
     const double *__restrict__ tops, const TU *__restrict__ Ur, int r, int64_t ldu, int64_t row0,

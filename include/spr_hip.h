@@ -296,11 +296,31 @@ int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const double *d_rec
                     int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
                     const double *d_xyz, int32_t xyz_dim, int64_t n_points, double d_min,
                     void *d_workspace, size_t workspace_bytes, void *stream);
-/* single GPU: n_steps consecutive steps in one call (d_recs = d_rec, n_rec = 1, first = the call's first step) */
-int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_t n_steps, const double *d_tau,
-                     double *d_Q, int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
+/* single GPU: n_steps consecutive steps in one call (d_recs = d_rec, n_rec = 1, first = first_exact for the call's
+ * first step: 1 after spr_qr_init_* / spr_qr_refresh_* / a full epoch sweep, 0 after a pool sweep) */
+int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_t n_steps, int32_t first_exact,
+                     const double *d_tau, double *d_Q, int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
                      const double *d_xyz, int32_t xyz_dim, int64_t n_points, double d_min,
                      void *d_workspace, size_t workspace_bytes, void *stream);
+/* ---- K6, epoch sweeps: refreshes that only visit the rows that can still be picked (csrc/qr_pivot.hip) -----------
+ * Same pivots as the refresh-per-batch scheme above (:739), fewer passes over Ur.  d_nrm_e holds norms that are exact
+ * for the directions [0, j_e) (a copy of the initial norms, later rewritten by full sweeps); the rows with d_nrm_e >
+ * theta form the POOL (spr_qr_pool_build: sorted local row list).  A pool sweep recomputes d_nrm = d_nrm_e - sum over the
+ * epoch's directions [j_e, j) of (u . q)^2 for the pool's rows only and certifies the following steps against
+ * max(tau of the pool, tau_floor = theta); a full sweep (d_pool = NULL) does it for every row, rewrites d_nrm_e and
+ * starts the next epoch at j.  j_mark: the picks d_piv[j_mark, j) have not been taken out of the race yet.
+ * Range: r a multiple of 16 up to SPR_MAX_R, 16-byte aligned rows, fewer than 2^31 local rows
+ * (spr_qr_epoch_supported); at most spr_qr_epoch_max_directions(r) directions per sweep. */
+int32_t spr_qr_epoch_supported(int32_t r, int64_t ldu, const void *d_Ur, int32_t u_is_f32, int64_t n_rows);
+int32_t spr_qr_epoch_max_directions(int32_t r);
+size_t spr_qr_pool_workspace(void);
+int spr_qr_pool_build(const double *d_nrm_e, int64_t n_rows, double theta, int32_t *d_pool, int64_t cap,
+                      int32_t *d_pool_n, void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_epoch_sweep_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                           const double *d_Q, const int64_t *d_piv, int32_t j_e, int32_t j, int32_t j_mark,
+                           double *d_nrm_e, double *d_nrm, const int32_t *d_pool, const int32_t *d_pool_n,
+                           int64_t pool_n_host, double tau_floor, double *d_rec, double *d_tau,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_qr_exclude_f64(double *d_nrm, int64_t n_rows, int64_t row0, int64_t n_points,
                        const uint8_t *d_mask, const double *d_xyz, int32_t xyz_dim,
                        const int64_t *d_piv, int32_t nq, double d_min, void *stream);
@@ -470,6 +490,11 @@ int spr_qr_init_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu,
 int spr_qr_init_norms_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
                           const double *d_nrm0, double *d_nrm, double *d_rec, double *d_tau,
                           void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_qr_epoch_sweep_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                           const double *d_Q, const int64_t *d_piv, int32_t j_e, int32_t j, int32_t j_mark,
+                           double *d_nrm_e, double *d_nrm, const int32_t *d_pool, const int32_t *d_pool_n,
+                           int64_t pool_n_host, double tau_floor, double *d_rec, double *d_tau,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_qr_refresh_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
                        const double *d_Q, const int64_t *d_piv, int32_t j0, int32_t nq,
                        double *d_nrm, double *d_rec, double *d_tau,

@@ -68,7 +68,12 @@ PROTOTYPES = {
     'spr_qr_init_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     'spr_qr_init_norms_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     'spr_qr_step_f64': (C.c_int, [_i64, _i32, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _i64, _dbl, _p, _sz, _p]),
-    'spr_qr_steps_f64': (C.c_int, [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _dbl, _p, _sz, _p]),
+    'spr_qr_steps_f64': (C.c_int, [_i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _dbl, _p, _sz, _p]),
+    'spr_qr_epoch_supported': (_i32, [_i32, _i64, _p, _i32, _i64]),
+    'spr_qr_epoch_max_directions': (_i32, [_i32]),
+    'spr_qr_pool_workspace': (_sz, []),
+    'spr_qr_pool_build': (C.c_int, [_p, _i64, _dbl, _p, _i64, _p, _p, _sz, _p]),
+    'spr_qr_epoch_sweep_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _dbl, _p, _p, _p, _sz, _p]),
     'spr_qr_exclude_f64': (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _i32, _p, _i32, _dbl, _p]),
     'spr_qr_refresh_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     'spr_measure_csr_f64': (C.c_int, [_p, _p, _p, _i32, _p, _i64, _i32, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p]),
@@ -102,6 +107,7 @@ for _f64, _x32 in (('spr_stats_gram_f64', 'spr_stats_gram_x32'), ('spr_rowstats_
                    ('spr_project_stream_norms_f64', 'spr_project_stream_norms_x32'),
                    ('spr_project_stream_norms_f64', 'spr_project_stream_norms_x32_f64out'),
                    ('spr_qr_init_norms_f64', 'spr_qr_init_norms_u32'),
+                   ('spr_qr_epoch_sweep_f64', 'spr_qr_epoch_sweep_u32'),
                    ('spr_scale_rows_f64', 'spr_scale_rows_x32'), ('spr_feature_minmax_f64', 'spr_feature_minmax_x32'),
                    ('spr_colsums_f64', 'spr_colsums_x32'), ('spr_feature_digit_hist_f64', 'spr_feature_digit_hist_x32'),
                    ('spr_synth_f64', 'spr_synth_f32'), ('spr_reconstruct_f64', 'spr_reconstruct_u32'),

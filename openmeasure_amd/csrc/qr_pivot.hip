@@ -523,7 +523,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_gather_kernel(
 __global__ __launch_bounds__(1024) void qr_cand_best_kernel(
     const double *__restrict__ tops, int n_blocks, const int64_t *__restrict__ cand_idx,
     const double *__restrict__ cand_res, const double *__restrict__ cand_U, int n_cand, int r, int ldc,
-    double *__restrict__ tau, double *__restrict__ rec) {
+    double *__restrict__ tau, double *__restrict__ rec, double tau_floor) {
   __shared__ double sv1[16], sv2[16], stau[16];
   __shared__ long long si1[16];
   __shared__ int spos[16];
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(1024) void qr_cand_best_kernel(
     }
     rec[0] = g.v1; rec[1] = (double)g.i1; rec[2] = g.v2;
     spos[0] = gp;
-    if (tau) *tau = gt;
+    if (tau) *tau = gt > tau_floor ? gt : tau_floor;   // tau_floor: the bound of the rows a pool sweep did not visit
   }
   __syncthreads();
   const int gp = spos[0];
@@ -843,16 +843,180 @@ int check_ur(const char *who, const void *Ur, int64_t n_rows, int32_t r, int64_t
   return SPR_OK;
 }
 
+// ---- Epoch sweeps: refreshes that visit only the rows that can still matter --------------------------------------
+// The certified batches above end when the winner's residual reaches tau, the largest norm a non-candidate may have;
+// with 16 candidates per sweep block that is after ~16 steps (tools/cert_probe.py: config 3, tau = 0.75 of the first
+// winner, winners shrinking by 0.77 per 16 steps), and every refresh re-reads the whole basis.  But a row whose norm is
+// far below the winners cannot be picked for many steps: its STALE norm is still an upper bound (norms only decrease).
+// An epoch starts with norms nrm_e that are exact for the directions [0, j_e) (the initial norms; later a full epoch
+// sweep).  The rows with nrm_e > theta form the POOL (a sorted index list); every refresh inside the epoch visits only
+// the pool -- residual = nrm_e - sum over ALL directions of the epoch (u . q)^2, from scratch, so no per-row record of
+// what has been applied is needed --, and the steps are certified against max(tau of the pool, theta).  When the
+// winners come down to theta, ONE full sweep applies the epoch's directions to every row (rewriting nrm_e) and a new
+// epoch starts with a lower theta.  The directions of an epoch (up to NT tiles of 16) sit in LDS in fragment order;
+// rows go HBM -> registers in the MFMA A layout exactly as in qr_refresh_direct_kernel.
+template <int NG, int NT, typename TU, bool POOL>
+__global__ __launch_bounds__(QR_THREADS) void qr_epoch_sweep_kernel(
+    const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0, const double *__restrict__ Q, int nq,
+    double *__restrict__ nrm_e, double *__restrict__ nrm, const int32_t *__restrict__ pool,
+    const int32_t *__restrict__ pool_n_ptr, double *__restrict__ tops) {
+  constexpr int R = 64, SPW = QR_SPW;
+  __shared__ double smem[2 * (QR_THREADS / 64) * SPW * QR_TOPT];
+  __shared__ double Ql[NT * NG * 256];     // Ql[((tile NG + g) 4 + t) 64 + kk 16 + li] = Q[16 tile + li][16 g + 4 kk + t]
+  double *const sval = smem;
+  long long *const sidx = reinterpret_cast<long long *>(smem + (QR_THREADS / 64) * SPW * QR_TOPT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kk = lane >> 4;
+  using P4 = typename std::conditional<std::is_same<TU, float>::value, float4, double4>::type;
+  const int nt = (nq + 15) / 16;
+  for (int e = threadIdx.x; e < nt * NG * 256; e += QR_THREADS) {
+    const int j = e & 15, k4 = (e >> 4) & 3, t = (e >> 6) & 3, g = (e >> 8) % NG, tile = (e >> 8) / NG;
+    const int d = 16 * tile + j;
+    Ql[e] = (d < nq) ? Q[(int64_t)d * r + 16 * g + 4 * k4 + t] : 0.0;
+  }
+  __syncthreads();
+  TopList top;
+  top.init();
+  const RowOwner<false> who(lane);
+  const int64_t n_units = POOL ? (int64_t)*pool_n_ptr : n_rows;      // rows to visit
+  const int64_t npanels = (n_units + R - 1) / R;
+  // row of this lane's slot in panel c (its A operand) and the row this lane owns the norm of; -1: past the end
+  auto slot_row = [&](int64_t c) -> int64_t {
+    const int64_t u = c * R + wave * 16 + li;
+    if (u >= n_units) return -1;
+    return POOL ? (int64_t)pool[u] : u;
+  };
+  auto load_block = [&](int64_t row, P4 (&dst)[NG]) {
+    const TU *rp = Ur + (row >= 0 ? row : 0) * ldu + 4 * kk;   // past the end: a harmless re-read of row 0, never stored
+#pragma unroll
+    for (int g = 0; g < NG; ++g) dst[g] = *reinterpret_cast<const P4 *>(rp + 16 * g);
+  };
+  auto own_row = [&](int64_t row) -> int64_t {                 // lanes 0..15 hold the rows of slots 0..15
+    const int lo = __shfl((int)(row & 0xffffffff), who.off, 64), hi = __shfl((int)(row >> 32), who.off, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+  };
+  // NBUF register sets per wave, used in rotation (no copies): while set u is multiplied, the rows NBUF - 1 panels ahead
+  // are requested into the set that was multiplied last.  Three sets (two panels ahead) where a set is <= 32 VGPRs: with two
+  // waves per SIMD one panel ahead leaves 16 MB in flight on the chip -- 4.3 TB/s for a full sweep at config 3, 10.6 ms.
+  constexpr int NBUF = (NG * sizeof(P4) / 4 <= 32 && NG <= 6) ? 3 : 2;
+  P4 buf[NBUF][NG];
+  double oldv[NBUF];
+  int64_t orv[NBUF];
+  auto fetch = [&](int64_t cc, P4 (&dst)[NG], double &old, int64_t &orow) {
+    const int64_t row = cc < npanels ? slot_row(cc) : -1;
+    load_block(row, dst);
+    orow = own_row(row);
+    old = nrm_e[orow >= 0 ? orow : 0];
+  };
+  auto process = [&](const P4 (&cur)[NG], double old, int64_t orow) {
+    const bool mine = who.own && orow >= 0;
+    double q2[4] = {0.0, 0.0, 0.0, 0.0};                       // this lane's direction column, summed over the tiles
+    for (int tile = 0; tile < nt; ++tile) {
+      const double *ql = Ql + tile * NG * 256 + kk * 16 + li;
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const double a4[4] = {(double)cur[g].x, (double)cur[g].y, (double)cur[g].z, (double)cur[g].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], ql[(g * 4 + t) * 64], acc, 0, 0, 0);
+      }
+      q2[0] = fma(acc.x, acc.x, q2[0]); q2[1] = fma(acc.y, acc.y, q2[1]);
+      q2[2] = fma(acc.z, acc.z, q2[2]); q2[3] = fma(acc.w, acc.w, q2[3]);
+    }
+    const double d2 = who.pick(group_sum_t<16>(q2[0]), group_sum_t<16>(q2[1]), group_sum_t<16>(q2[2]), group_sum_t<16>(q2[3]));
+    double v = old - d2;
+    v = v < 0.0 ? 0.0 : v;
+    v = old < 0.0 ? -1.0 : v;
+    if (mine) {
+      nrm[orow] = v;
+      if (!POOL) nrm_e[orow] = v;                              // full sweep: the next epoch starts from these
+    }
+    top.insert(v, row0 + orow, mine);
+  };
+  int64_t c = blockIdx.x;
+  const int64_t gs = gridDim.x;
+#pragma unroll
+  for (int u = 0; u < NBUF - 1; ++u) fetch(c + u * gs, buf[u], oldv[u], orv[u]);
+  while (c < npanels) {
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) {
+      if (c < npanels) {                                       // wave-uniform
+        constexpr int NB1 = NBUF - 1;
+        fetch(c + NB1 * gs, buf[(u + NB1) % NBUF], oldv[(u + NB1) % NBUF], orv[(u + NB1) % NBUF]);
+        process(buf[u], oldv[u], orv[u]);
+        c += gs;
+      }
+    }
+  }
+  top.template block_merge<SPW>(sval, sidx, tops + (int64_t)blockIdx.x * QR_TOPT * 2, who.own, who.slot(lane));
+}
+
+// ---- pool = sorted list of the rows with nrm_e > theta: count per chunk, scan, fill (deterministic order) ------------
+constexpr int PB_THREADS = 256;
+constexpr int PB_MAX_BLOCKS = 2048;
+
+__global__ __launch_bounds__(PB_THREADS) void qr_pool_count_kernel(const double *__restrict__ nrm_e, int64_t n_rows,
+                                                                   int64_t chunk, double theta, int32_t *__restrict__ counts) {
+  __shared__ int red[PB_THREADS / 64];
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n_rows ? lo + chunk : n_rows;
+  int cnt = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += PB_THREADS) cnt += nrm_e[i] > theta;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < PB_THREADS / 64; ++w) t += red[w];
+    counts[blockIdx.x] = t;
+  }
+}
+
+// one workgroup: exclusive scan of the chunk counts (in place); pool_n = total, or -1 when the list would not fit
+__global__ void qr_pool_scan_kernel(int32_t *__restrict__ counts, int n_blocks, int64_t cap, int32_t *__restrict__ pool_n) {
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int b = 0; b < n_blocks; ++b) { const int c = counts[b]; counts[b] = (int32_t)(run < INT32_MAX ? run : INT32_MAX); run += c; }
+    *pool_n = run <= cap ? (int32_t)run : -1;
+  }
+}
+
+__global__ __launch_bounds__(PB_THREADS) void qr_pool_fill_kernel(const double *__restrict__ nrm_e, int64_t n_rows,
+                                                                  int64_t chunk, double theta,
+                                                                  const int32_t *__restrict__ offsets,
+                                                                  const int32_t *__restrict__ pool_n,
+                                                                  int32_t *__restrict__ pool) {
+  __shared__ int wcnt[PB_THREADS / 64];
+  if (*pool_n < 0) return;                                       // would not fit: the caller falls back to full sweeps
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n_rows ? lo + chunk : n_rows;
+  int64_t base = offsets[blockIdx.x];
+  for (int64_t i0 = lo; i0 < hi; i0 += PB_THREADS) {             // workgroup-uniform trip count
+    const int64_t i = i0 + threadIdx.x;
+    const bool in = i < hi && nrm_e[i] > theta;
+    const unsigned long long m = __ballot(in);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < PB_THREADS / 64; ++w) { if (w < wave) woff += wcnt[w]; tot += wcnt[w]; }
+    if (in) pool[base + woff + before] = (int32_t)i;
+    base += tot;
+    __syncthreads();
+  }
+}
+
 // candidates from the last sweep's block tops + this rank's record and tau
 template <typename TU>
 int build_candidates(const QrWs &w, int grid, const TU *Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0,
-                     double *rec, double *tau_out, hipStream_t st) {
+                     double *rec, double *tau_out, hipStream_t st, double tau_floor = -2.0) {
   const int ldc = r + (r & 1);
   hipLaunchKernelGGL(qr_gather_kernel<TU>, dim3(grid), dim3(QR_THREADS), 0, st, w.tops, Ur, r, ldu, row0, n_rows, ldc,
                      w.cand_idx, w.cand_res, w.cand_U);
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, w.tops, grid, w.cand_idx, w.cand_res,
-                     w.cand_U, grid * QR_TOPT, r, ldc, tau_out, rec);
+                     w.cand_U, grid * QR_TOPT, r, ldc, tau_out, rec, tau_floor);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
@@ -989,7 +1153,7 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
                        w.cand_idx, d_Q + (int64_t)step * r, d_piv + step, w.cand_res, d_xyz, (int)xyz_dim, n_points, d_min);
     SPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, (const double *)nullptr, 0, w.cand_idx,
-                       w.cand_res, w.cand_U, n_cand, (int)r, ldc, (double *)nullptr, d_rec);
+                       w.cand_res, w.cand_U, n_cand, (int)r, ldc, (double *)nullptr, d_rec, -2.0);
     SPR_LAUNCH_CHECK();
     return SPR_OK;
   }
@@ -1006,22 +1170,23 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
 #undef CD
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(qr_cand_best_kernel, dim3(1), dim3(1024), 0, st, (const double *)nullptr, 0, w.cand_idx,
-                     w.cand_res, w.cand_U, n_cand, (int)r, ldc, (double *)nullptr, d_rec);
+                     w.cand_res, w.cand_U, n_cand, (int)r, ldc, (double *)nullptr, d_rec, -2.0);
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
 
 // Single-GPU convenience: n_steps candidate-set steps (step0, step0+1, ...) in one call, the rank's own record and tau
 // feeding every step -- the same launches as n_steps calls of spr_qr_step_f64 with d_recs = d_rec, n_rec = 1, first =
-// (t == 0), without the per-call host overhead that dominates small placements.
-extern "C" int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_t n_steps, const double *d_tau,
-                                double *d_Q, int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
+// (t == 0 && first_exact), without the per-call host overhead that dominates small placements.  first_exact = 0 after a
+// POOL sweep: its candidates are only the best rows of the pool, so the first step is certified against tau like the rest.
+extern "C" int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_t n_steps, int32_t first_exact,
+                                const double *d_tau, double *d_Q, int64_t *d_piv, double *d_gap, double *d_ok, double *d_rec,
                                 const double *d_xyz, int32_t xyz_dim, int64_t n_points, double d_min,
                                 void *d_workspace, size_t workspace_bytes, void *stream) {
   SPR_REQUIRE(n_steps >= 1 && step0 >= 0 && step0 + n_steps <= r, SPR_E_INVALID,
               "spr_qr_steps_f64: steps [%d, %d) outside [0, %d)", step0, step0 + n_steps, r);
   for (int t = 0; t < n_steps; ++t) {
-    const int rc = spr_qr_step_f64(n_rows, r, step0 + t, d_rec, 1, d_tau, 1, t == 0, d_Q, d_piv, d_gap, d_ok, d_rec,
+    const int rc = spr_qr_step_f64(n_rows, r, step0 + t, d_rec, 1, d_tau, 1, t == 0 && first_exact, d_Q, d_piv, d_gap, d_ok, d_rec,
                                    d_xyz, xyz_dim, n_points, d_min, d_workspace, workspace_bytes, stream);
     if (rc != SPR_OK) return rc;
   }
@@ -1078,4 +1243,112 @@ extern "C" int spr_qr_refresh_u32(const float *d_Ur, int64_t n_rows, int32_t r, 
                                   void *stream) {
   return qr_refresh_entry("spr_qr_refresh_u32", d_Ur, n_rows, r, ldu, row0, d_Q, d_piv, j0, nq, d_nrm, d_rec, d_tau,
                           d_workspace, workspace_bytes, stream);
+}
+
+// ---- epoch sweeps (see qr_epoch_sweep_kernel) ---------------------------------------------------------------------
+extern "C" int32_t spr_qr_epoch_supported(int32_t r, int64_t ldu, const void *d_Ur, int32_t u_is_f32, int64_t n_rows) {
+  const size_t es = u_is_f32 ? sizeof(float) : sizeof(double);
+  return r >= 16 && r <= SPR_MAX_R && r % 16 == 0 && (ldu * es) % 16 == 0 && (reinterpret_cast<uintptr_t>(d_Ur) & 15) == 0 &&
+         n_rows > 0 && n_rows < INT32_MAX;
+}
+
+extern "C" int32_t spr_qr_epoch_max_directions(int32_t r) {          // directions one epoch sweep can apply
+  const int ng = r / 16;
+  return 16 * (ng < 4 ? ng : ng <= 6 ? 4 : 3);
+}
+
+extern "C" size_t spr_qr_pool_workspace(void) { return sizeof(int32_t) * (PB_MAX_BLOCKS + 4); }
+
+// d_pool[0 .. *d_pool_n) <- the local rows with d_nrm_e > theta, ascending; *d_pool_n = -1 when more than cap qualify
+extern "C" int spr_qr_pool_build(const double *d_nrm_e, int64_t n_rows, double theta, int32_t *d_pool, int64_t cap,
+                                 int32_t *d_pool_n, void *d_workspace, size_t workspace_bytes, void *stream) {
+  SPR_REQUIRE(d_nrm_e && d_pool && d_pool_n && d_workspace, SPR_E_INVALID, "spr_qr_pool_build: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && n_rows < INT32_MAX && cap > 0, SPR_E_INVALID, "spr_qr_pool_build: bad shape");
+  SPR_REQUIRE(workspace_bytes >= spr_qr_pool_workspace(), SPR_E_WORKSPACE, "spr_qr_pool_build: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t chunk = (n_rows + PB_MAX_BLOCKS - 1) / PB_MAX_BLOCKS;
+  chunk = (chunk + PB_THREADS - 1) / PB_THREADS * PB_THREADS;
+  const int blocks = (int)((n_rows + chunk - 1) / chunk);
+  int32_t *counts = static_cast<int32_t *>(d_workspace);
+  hipLaunchKernelGGL(qr_pool_count_kernel, dim3(blocks), dim3(PB_THREADS), 0, st, d_nrm_e, n_rows, chunk, theta, counts);
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qr_pool_scan_kernel, dim3(1), dim3(64), 0, st, counts, blocks, cap, d_pool_n);
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qr_pool_fill_kernel, dim3(blocks), dim3(PB_THREADS), 0, st, d_nrm_e, n_rows, chunk, theta, counts,
+                     d_pool_n, d_pool);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+template <typename TU>
+static int qr_epoch_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                          const double *d_Q, const int64_t *d_piv, int32_t j_e, int32_t j, int32_t j_mark,
+                          double *d_nrm_e, double *d_nrm, const int32_t *d_pool, const int32_t *d_pool_n,
+                          int64_t pool_n_host, double tau_floor, double *d_rec, double *d_tau, void *d_workspace,
+                          size_t workspace_bytes, void *stream) {
+  int rc = check_ur(who, d_Ur, n_rows, r, ldu);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_Q && d_piv && d_nrm_e && d_nrm && d_rec && d_tau && d_workspace, SPR_E_INVALID, "%s: NULL pointer", who);
+  SPR_REQUIRE(spr_qr_epoch_supported(r, ldu, d_Ur, std::is_same<TU, float>::value, n_rows), SPR_E_UNSUPPORTED,
+              "%s: r=%d / alignment outside the epoch sweep's range (r a multiple of 16 up to %d, 16-byte rows)", who, r, SPR_MAX_R);
+  SPR_REQUIRE(j_e >= 0 && j > j_e && j <= r && j - j_e <= spr_qr_epoch_max_directions(r) && j_mark >= 0 && j_mark <= j,
+              SPR_E_INVALID, "%s: bad direction range [%d, %d) (at most %d per sweep), marks from %d", who, j_e, j,
+              spr_qr_epoch_max_directions(r), j_mark);
+  SPR_REQUIRE(!d_pool || (d_pool_n && pool_n_host >= 1 && pool_n_host <= n_rows), SPR_E_INVALID, "%s: bad pool", who);
+  SPR_REQUIRE(workspace_bytes >= QrWs::bytes(r), SPR_E_WORKSPACE, "%s: workspace too small", who);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  QrWs w(d_workspace, r);
+  // the picks since the last sweep leave the race for good, in the epoch norms and in the bounds
+  for (int m0 = j_mark; m0 < j; m0 += 64) {
+    const int nm = j - m0 < 64 ? j - m0 : 64;
+    hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + m0, nm, row0, n_rows, d_nrm_e);
+    hipLaunchKernelGGL(qr_mark_kernel, dim3(1), dim3(64), 0, st, d_piv + m0, nm, row0, n_rows, d_nrm);
+  }
+  SPR_LAUNCH_CHECK();
+  // always the grid of a full sweep: the step kernels walk sweep_grid(n_rows) x QR_TOPT candidate slots, so the workgroups
+  // a small pool leaves without rows must still write their (empty) lists over the previous sweep's
+  const int grid = sweep_grid(n_rows);
+  (void)pool_n_host;
+  const double *Qe = d_Q + (int64_t)j_e * r;
+  const int nq = j - j_e;
+#define ES(NGV, NTV)                                                                                                     \
+  do {                                                                                                                   \
+    if (d_pool)                                                                                                          \
+      hipLaunchKernelGGL((qr_epoch_sweep_kernel<NGV, NTV, TU, true>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows,  \
+                         (int)r, ldu, row0, Qe, nq, d_nrm_e, d_nrm, d_pool, d_pool_n, w.tops);                           \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((qr_epoch_sweep_kernel<NGV, NTV, TU, false>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows, \
+                         (int)r, ldu, row0, Qe, nq, d_nrm_e, d_nrm, d_pool, d_pool_n, w.tops);                           \
+  } while (0)
+  switch (r / 16) {
+    case 1: ES(1, 1); break;
+    case 2: ES(2, 2); break;
+    case 3: ES(3, 3); break;
+    case 4: ES(4, 4); break;
+    case 5: ES(5, 4); break;
+    case 6: ES(6, 4); break;
+    case 7: ES(7, 3); break;      // three tiles: 2 x (48 KB image + lists) fit a CU's LDS -- two workgroups per CU
+    default: ES(8, 3); break;
+  }
+#undef ES
+  SPR_LAUNCH_CHECK();
+  return build_candidates<TU>(w, grid, d_Ur, n_rows, r, ldu, row0, d_rec, d_tau, st, tau_floor);
+}
+
+extern "C" int spr_qr_epoch_sweep_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                      const double *d_Q, const int64_t *d_piv, int32_t j_e, int32_t j, int32_t j_mark,
+                                      double *d_nrm_e, double *d_nrm, const int32_t *d_pool, const int32_t *d_pool_n,
+                                      int64_t pool_n_host, double tau_floor, double *d_rec, double *d_tau,
+                                      void *d_workspace, size_t workspace_bytes, void *stream) {
+  return qr_epoch_entry("spr_qr_epoch_sweep_f64", d_Ur, n_rows, r, ldu, row0, d_Q, d_piv, j_e, j, j_mark, d_nrm_e, d_nrm,
+                        d_pool, d_pool_n, pool_n_host, tau_floor, d_rec, d_tau, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int spr_qr_epoch_sweep_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
+                                      const double *d_Q, const int64_t *d_piv, int32_t j_e, int32_t j, int32_t j_mark,
+                                      double *d_nrm_e, double *d_nrm, const int32_t *d_pool, const int32_t *d_pool_n,
+                                      int64_t pool_n_host, double tau_floor, double *d_rec, double *d_tau,
+                                      void *d_workspace, size_t workspace_bytes, void *stream) {
+  return qr_epoch_entry("spr_qr_epoch_sweep_u32", d_Ur, n_rows, r, ldu, row0, d_Q, d_piv, j_e, j, j_mark, d_nrm_e, d_nrm,
+                        d_pool, d_pool_n, pool_n_host, tau_floor, d_rec, d_tau, d_workspace, workspace_bytes, stream);
 }

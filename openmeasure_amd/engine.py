@@ -501,12 +501,57 @@ class HipEngine:
                                             xyz.shape[1] if xyz is not None else 0, n_points, float(d_min),
                                             _ptr(st['ws']), st['ws'].numel(), self._stream()), 'spr_qr_step_f64')
 
-    def qr_steps(self, st, step0, n_steps, xyz=None, n_points=0, d_min=0.0):
-        """Single GPU: n_steps consecutive candidate-set steps in one library call (spr_qr_steps_f64)."""
-        _lib.check(self.lib.spr_qr_steps_f64(st['n'], st['r'], step0, n_steps, _ptr(st['tau']), _ptr(st['Q']),
-                                             _ptr(st['piv']), _ptr(st['gap']), _ptr(st['ok']), _ptr(st['rec']), _ptr(xyz),
-                                             xyz.shape[1] if xyz is not None else 0, n_points, float(d_min),
-                                             _ptr(st['ws']), st['ws'].numel(), self._stream()), 'spr_qr_steps_f64')
+    def qr_steps(self, st, step0, n_steps, xyz=None, n_points=0, d_min=0.0, first_exact=True):
+        """Single GPU: n_steps consecutive candidate-set steps in one library call (spr_qr_steps_f64).
+        first_exact=False after a pool sweep: the call's first step is certified against tau like the others."""
+        _lib.check(self.lib.spr_qr_steps_f64(st['n'], st['r'], step0, n_steps, int(bool(first_exact)), _ptr(st['tau']),
+                                             _ptr(st['Q']), _ptr(st['piv']), _ptr(st['gap']), _ptr(st['ok']),
+                                             _ptr(st['rec']), _ptr(xyz), xyz.shape[1] if xyz is not None else 0, n_points,
+                                             float(d_min), _ptr(st['ws']), st['ws'].numel(), self._stream()),
+                   'spr_qr_steps_f64')
+
+    # ---- K6, epoch sweeps (spr_qr_epoch_sweep_*, spr_qr_pool_build) -------------------------------------------------
+    def qr_epoch_ok(self, st):
+        """Can this basis take epoch sweeps (r a multiple of 16 up to 128, 16-byte rows, < 2^31 local rows)?"""
+        Ur = st['Ur']
+        return bool(self.lib.spr_qr_epoch_supported(st['r'], st['ldu'], Ur.data_ptr(), int(Ur.dtype == self.torch.float32),
+                                                    st['n']))
+
+    def qr_epoch_max_directions(self, st):
+        """Directions one epoch sweep can apply (the direction tiles its LDS image holds)."""
+        return int(self.lib.spr_qr_epoch_max_directions(st['r']))
+
+    def qr_epoch_begin(self, st):
+        """Epoch 0 starts from the exact initial norms."""
+        st['nrm_e'] = st['nrm'].clone()
+        st['pool_n'] = 0
+
+    def qr_pool_build(self, st, theta):
+        """Pool of the epoch: the local rows with nrm_e > theta, ascending.  -> their number (one host sync), -1 when the
+        list would not fit (more than a quarter of the rows: no pool then)."""
+        t = self.torch
+        cap = max(st['n'] // 4, 1 << 16)
+        if 'pool' not in st:
+            st['pool'] = self.empty((cap,), dtype=t.int32)
+            st['pool_cnt'] = self.zeros((1,), dtype=t.int32)
+        ws = self._workspace('qrpool', self.lib.spr_qr_pool_workspace())
+        _lib.check(self.lib.spr_qr_pool_build(_ptr(st['nrm_e']), st['n'], float(theta), _ptr(st['pool']), cap,
+                                              _ptr(st['pool_cnt']), _ptr(ws), ws.numel(), self._stream()),
+                   'spr_qr_pool_build')
+        st['pool_n'] = int(self.to_host(st['pool_cnt'])[0])
+        return st['pool_n']
+
+    def qr_epoch_sweep(self, st, j_e, j, j_mark, pool=False, tau_floor=-2.0):
+        """Residual norms from the epoch norms and the directions Q[j_e:j]: for the pool's rows (pool=True; steps are then
+        certified against max(tau, tau_floor)) or for every row (pool=False: also rewrites the epoch norms, the next epoch
+        starts at j); candidates / record / tau redrawn either way.  piv[j_mark:j] leave the race."""
+        pl = st['pool'] if pool else None
+        _lib.check(self._u('spr_qr_epoch_sweep', st['Ur'])(_ptr(st['Ur']), st['n'], st['r'], st['ldu'], st['row0'],
+                                                          _ptr(st['Q']), _ptr(st['piv']), j_e, j, j_mark, _ptr(st['nrm_e']),
+                                                          _ptr(st['nrm']), _ptr(pl), _ptr(st['pool_cnt']) if pool else None,
+                                                          st['pool_n'] if pool else 0, float(tau_floor), _ptr(st['rec']),
+                                                          _ptr(st['tau']), _ptr(st['ws']), st['ws'].numel(),
+                                                          self._stream()), 'spr_qr_epoch_sweep_f64')
 
     def qr_exclude(self, st, mask=None, xyz=None, n_points=1, j0=0, nq=0, d_min=0.0):
         """Rows outside `mask` (uint8 per local row) and rows closer than d_min to the picks piv[j0:j0+nq] leave

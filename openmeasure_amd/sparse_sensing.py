@@ -335,11 +335,87 @@ def _eigh_small(G):
     return w, v
 
 
-def pivot_loop(eng, st, s, all_gather=None, start=0, near=None):
+_POOL_FRACTION = 1.0 / 16       # share of the rows a pool sweep visits
+_POOL_USEFUL = 0.85             # a pool pays only if its threshold lies this far below the best row
+_POOL_MARGIN = 1.15             # leave the pool when the winners have come this close to its threshold
+
+
+def _pivot_loop_pooled(eng, st, s, stats):
+    """pivot_loop with epoch sweeps (csrc/qr_pivot.hip, qr_epoch_sweep_kernel): between two passes over the whole basis
+    the refreshes visit only the POOL -- the rows whose norm at the start of the epoch lies above a threshold theta, about
+    1/16 of them --, and the steps are certified against max(tau of the pool, theta): rows outside the pool keep their
+    stale norms, which are upper bounds.  When the winners have come down to theta one full sweep starts the next epoch.
+    Same pivots as a refresh per batch; at BASELINE config 3 two passes over Ur instead of four."""
+    torch = eng.torch
+    n, batch = st['n'], eng.qr_batch
+    dmax = eng.qr_epoch_max_directions(st)
+    eng.qr_epoch_begin(st)
+    stride = max(1, n // 65536)
+    full, pooled = 1, 0
+
+    def new_epoch():
+        """threshold of the next pool from a sample of the epoch norms; -> theta or None (no pool)"""
+        chk = eng.to_host(torch.cat([st['rec'][:1], st['nrm_e'][::stride]]))
+        best, samp = chk[0], chk[1:]
+        k = int(len(samp) * (1.0 - _POOL_FRACTION))
+        theta = float(np.partition(samp, k)[k]) if 0 <= k < len(samp) else -1.0
+        if not (0.0 < theta < _POOL_USEFUL * best):
+            return None
+        return theta if eng.qr_pool_build(st, theta) > 0 else None
+
+    theta = new_epoch()
+    j = j_e = j_mark = 0
+    first_exact = True
+    while j < s:
+        nb = min(batch, s - j)
+        eng.qr_steps(st, j, nb, first_exact=first_exact)
+        chk = eng.to_host(torch.cat([st['ok'][j:j + nb], st['rec'][:1], st['tau']]))   # one sync per batch
+        ok, best_next, tau = chk[:nb], chk[nb], chk[nb + 1]
+        k = nb if ok.all() else int(np.argmin(ok))               # certified prefix
+        if k < 1 and first_exact:
+            raise RuntimeError('optimal_placement: first step after a sweep was not certified')
+        j += k
+        if j >= s:
+            break
+        # where the next winners are: the best remaining candidate after a fully certified batch, at most tau otherwise
+        level = best_next if k == nb else tau
+        use_pool = (theta is not None and k > 0 and level > _POOL_MARGIN * theta and j - j_e + batch <= dmax)
+        if stats is not None:
+            stats.setdefault('log', []).append(('batch', j - k, k, nb, float(level), float(tau), theta, st.get('pool_n', 0)))
+        if use_pool:
+            eng.qr_epoch_sweep(st, j_e, j, j_mark, pool=True, tau_floor=theta)
+            pooled += 1
+            first_exact = False
+            if stats is not None:
+                stats['log'].append(('pool sweep', j_e, j))
+        else:
+            while j - j_e > dmax:                                # more directions than one sweep applies (rare)
+                eng.qr_epoch_sweep(st, j_e, j_e + dmax, j_mark)
+                j_e += dmax
+                j_mark = max(j_mark, j_e)
+                full += 1
+            eng.qr_epoch_sweep(st, j_e, j, j_mark)
+            full += 1
+            if stats is not None:
+                stats['log'].append(('full sweep', j_e, j))
+            j_e = j
+            first_exact = True
+            theta = new_epoch() if s - j > batch // 2 else None
+        j_mark = j
+    if stats is not None:
+        stats['pool_sweeps'] = pooled
+    return full
+
+
+def pivot_loop(eng, st, s, all_gather=None, start=0, near=None, pools=False, stats=None):
     """Host driver of the candidate-set pivoting (include/spr_hip.h, K6): batches of certified
     steps on the candidate set, one full sweep per batch.  Returns the number of sweeps over Ur.
     start: first step index (GEM keeps its centring direction in slot 0); near = (xyz, n_points, d_min):
-    GEM's distance exclusion around every pick."""
+    GEM's distance exclusion around every pick.  pools: refresh only the rows that can still be picked between two
+    full sweeps (one rank, plain QR pivoting, bases the epoch-sweep kernel takes; see _pivot_loop_pooled)."""
+    if (pools and all_gather is None and near is None and start == 0 and s > eng.qr_batch
+            and hasattr(eng, 'qr_epoch_ok') and eng.qr_epoch_ok(st)):
+        return _pivot_loop_pooled(eng, st, s, stats)
     kw = dict(xyz=near[0], n_points=near[1], d_min=near[2]) if near is not None else {}
     j, sweeps = start, 1
     while j < s:
@@ -1162,6 +1238,10 @@ class SPR(ROM):
 
     placement_norms = None      # "auto": see ROM.placement_norms
 
+    #: optimal_placement('qr') on one rank: between two passes over the whole basis, refresh only the rows whose norm can
+    #: still win a step (pivot_loop / _pivot_loop_pooled).  Same sensors; False: one full sweep per batch of steps.
+    placement_pools = True
+
     def __init__(self, X, n_features, xyz, shard=None, engine=None):
         super().__init__(X, n_features, xyz, shard=shard, engine=engine)
 
@@ -1191,8 +1271,11 @@ class SPR(ROM):
             st = eng.qr_begin(Ur_d, self._row0, s, norms=nrm0)
         else:
             st = eng.qr_begin(Ur_d, self._row0, s)
-        sweeps = pivot_loop(eng, st, s, self._all_gather if self._dist() else None)
+        stats = {}
+        sweeps = pivot_loop(eng, st, s, self._all_gather if self._dist() else None, pools=self.placement_pools,
+                            stats=stats)
         self.pivot_sweeps_ = sweeps - int(self.placement_from_norms_)   # passes over the basis (the start read none)
+        self.pivot_pool_sweeps_ = stats.get('pool_sweeps', 0)           # refreshes that visited the pool only
         piv = eng.to_host(st['piv']).astype(np.int64)
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])

@@ -22,7 +22,8 @@ lib = _lib.load()
 assert lib.spr_abi_version() == 1
 n = 0
 for name, (res, args) in sorted(_lib.PROTOTYPES.items()):
-    if res is not C.c_int or not args or name in ('spr_abi_version', 'spr_device_cus', 'spr_project_norms_supported'):   # the last one is a yes/no query
+    if res is not C.c_int or not args or name in ('spr_abi_version', 'spr_device_cus', 'spr_project_norms_supported', 'spr_qr_epoch_supported',
+                                                 'spr_qr_epoch_max_directions'):   # yes/no and size queries
         continue
     fn = getattr(lib, name)
     # all-zero arguments: NULL pointers and empty shapes must be rejected by the validation layer, with a message

@@ -536,6 +536,116 @@ def test_pivots_candidate_set_vs_oracle(eng, n, r, seed):
     assert 1 <= sweeps <= r
 
 
+@pytest.mark.parametrize('n,r,seed', [(200000, 32, 1), (50000, 64, 2), (700000, 16, 4), (30000, 128, 6), (120000, 48, 7)])
+def test_pivots_pooled_vs_oracle(eng, n, r, seed):
+    """the same near-uniform bases through the epoch-sweep driver (pools=True): thresholds that rarely pay, many failed
+    certifications, every refresh an epoch sweep -- dgeqp3's order exactly"""
+    from openmeasure_amd.sparse_sensing import pivot_loop
+    rng = np.random.default_rng(seed)
+    U, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    ref, _ = orc.qr_pivots(U)
+    Ud = eng.to_device(U)
+    st = eng.qr_begin(Ud, 0, r)
+    stats = {}
+    sweeps = pivot_loop(eng, st, r, pools=True, stats=stats)
+    np.testing.assert_array_equal(eng.to_host(st['piv']), ref)
+    assert 1 <= sweeps <= r and ('pool_sweeps' in stats) == (r > eng.qr_batch)   # one batch: nothing to refresh
+
+
+def test_pool_build_is_the_sorted_set_of_rows_above_the_threshold(eng):
+    import torch
+    rng = np.random.default_rng(3)
+    for n, theta in ((1, 0.5), (255, 0.9), (70001, 0.97), (1_000_003, 0.5), (1_000_003, 0.999), (300000, 2.0)):
+        v = rng.random(n)
+        v[rng.integers(0, n, size=max(1, n // 50))] = -1.0             # rows already picked
+        st = dict(nrm_e=eng.to_device(v), n=n)
+        got = eng.qr_pool_build(st, theta)
+        want = np.flatnonzero(v > theta)
+        cap = st['pool'].shape[0]
+        if len(want) > cap:
+            assert got == -1
+            continue
+        assert got == len(want)
+        np.testing.assert_array_equal(eng.to_host(st['pool'][:got].to(torch.int64)), want)
+
+
+@pytest.mark.parametrize('n,r,f32', [(70000, 64, False), (50001, 128, True), (33333, 16, False), (40000, 48, False)])
+def test_epoch_sweep_vs_numpy(eng, n, r, f32):
+    """spr_qr_epoch_sweep_*: residual = epoch norm - sum over the epoch's directions of (u . q)^2, for the pool's rows only
+    (others untouched, tau floored) or for every row (epoch norms rewritten); picks leave the race; 1 .. 64 directions."""
+    import torch
+    rng = np.random.default_rng(r)
+    U = rng.standard_normal((n, r)) / np.sqrt(r)
+    if f32:
+        U = U.astype(np.float32).astype(np.float64)
+    Ud = eng.to_device(U.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(U)
+    Qh, _ = np.linalg.qr(rng.standard_normal((r, r)))
+    dmax = int(eng.lib.spr_qr_epoch_max_directions(r))
+    for j_e, j in ((0, 5), (3, min(r, 3 + min(16, dmax))), (0, min(dmax, r)), (7, 7 + min(dmax, r - 7))):
+        st = eng.qr_begin(Ud, 11, r)
+        eng.qr_epoch_begin(st)
+        st['Q'].copy_(eng.to_device(Qh.T.copy()))                          # directions = rows of Q
+        picks = rng.choice(n, size=j, replace=False).astype(np.int64) + 11
+        st['piv'][:j].copy_(eng.to_device(picks, dtype=torch.int64))
+        nrm_e = eng.to_host(st['nrm_e']).copy()
+        np.testing.assert_allclose(nrm_e, (U ** 2).sum(axis=1), rtol=1e-13)
+        theta = float(np.quantile(nrm_e, 0.9))
+        pn = eng.qr_pool_build(st, theta)
+        assert pn == int((nrm_e > theta).sum())
+        before = eng.to_host(st['nrm']).copy()
+        d2 = ((U @ Qh[:, j_e:j]) ** 2).sum(axis=1)
+        want = np.maximum(nrm_e - d2, 0.0)
+        # pool sweep: pool rows recomputed, the others untouched (apart from the picks), tau >= theta
+        eng.qr_epoch_sweep(st, j_e, j, 0, pool=True, tau_floor=theta)
+        got = eng.to_host(st['nrm'])
+        inpool = nrm_e > theta
+        loc = picks - 11
+        exp = np.where(inpool, want, before)
+        exp[loc] = -1.0
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-13 * nrm_e.max())
+        assert float(eng.to_host(st['tau'])[0]) >= theta
+        np.testing.assert_array_equal(eng.to_host(st['nrm_e'])[~np.isin(np.arange(n), loc)], nrm_e[~np.isin(np.arange(n), loc)])
+        # full sweep: every row, epoch norms rewritten
+        eng.qr_epoch_sweep(st, j_e, j, j)
+        exp = want.copy()
+        exp[loc] = -1.0
+        np.testing.assert_allclose(eng.to_host(st['nrm']), exp, rtol=0, atol=1e-13 * nrm_e.max())
+        np.testing.assert_array_equal(eng.to_host(st['nrm_e']), eng.to_host(st['nrm']))
+        best = eng.to_host(st['rec'])
+        assert abs(best[0] - np.max(exp)) <= 1e-13 * nrm_e.max()
+        if np.max(exp) > 1e-6 * nrm_e.max():                                  # all r directions applied: rounding noise only
+            assert int(best[1]) - 11 == int(np.argmax(exp))
+
+
+@pytest.mark.parametrize('n_points,F,m,r,f32_basis', [(60000, 4, 256, 64, False), (50000, 4, 64, 32, False),
+                                                    (20000, 16, 512, 128, True), (30000, 3, 128, 48, False)])
+def test_placement_pools_same_sensors(eng, n_points, F, m, r, f32_basis):
+    """SPR.placement_pools: the epoch-sweep driver picks the sensors of the refresh-per-batch driver (and of the oracle),
+    with fewer passes over the basis."""
+    import torch
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    rho = 10 ** (-3 / (r - 1))
+    X = synth_host(n_points, F, m, min(m, 2 * r), rho, 1e-3, 9 + m)
+    Xin = DeviceMatrix(eng.to_device(X.astype(np.float32), dtype=torch.float32), basis='f32') if f32_basis else X
+    spr = SPR(Xin, F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    spr.placement_pools = False
+    spr.optimal_placement()
+    plain, plain_sweeps, gaps = spr.sensors_.copy(), spr.pivot_sweeps_, spr.pivot_gap_.copy()
+    assert spr.pivot_pool_sweeps_ == 0
+    spr.placement_pools = True
+    spr.optimal_placement()
+    np.testing.assert_array_equal(spr.sensors_, plain)
+    # the gap of a step is measured against the runner-up AMONG THE CANDIDATES: the same wherever that row is a candidate of
+    # both drivers (most steps), never a tie
+    assert (spr.pivot_gap_ > 0).all() and np.mean(np.isclose(spr.pivot_gap_, gaps, rtol=1e-6)) > 0.5
+    assert spr.pivot_sweeps_ <= plain_sweeps
+    if r >= 64:      # enough batches for a pool to pay (two or three: the threshold is reached before the first refresh)
+        assert spr.pivot_pool_sweeps_ >= 1 and spr.pivot_sweeps_ < plain_sweeps, (spr.pivot_sweeps_, spr.pivot_pool_sweeps_, plain_sweeps)
+    if not f32_basis:
+        np.testing.assert_array_equal(plain, orc.qr_pivots(orc.fit(X, F, 'number', r)['Ur'])[0])
+
+
 def test_weighted_predict_batch_vs_oracle(eng):
     rng = np.random.default_rng(8)
     s, r, F, n_p = 40, 12, 3, 4

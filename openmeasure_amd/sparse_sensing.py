@@ -340,12 +340,16 @@ _POOL_USEFUL = 0.85             # a pool pays only if its threshold lies this fa
 _POOL_MARGIN = 1.15             # leave the pool when the winners have come this close to its threshold
 
 
-def _pivot_loop_pooled(eng, st, s, stats):
+def _pivot_loop_pooled(eng, st, s, stats, all_gather=None):
     """pivot_loop with epoch sweeps (csrc/qr_pivot.hip, qr_epoch_sweep_kernel): between two passes over the whole basis
     the refreshes visit only the POOL -- the rows whose norm at the start of the epoch lies above a threshold theta, about
     1/16 of them --, and the steps are certified against max(tau of the pool, theta): rows outside the pool keep their
     stale norms, which are upper bounds.  When the winners have come down to theta one full sweep starts the next epoch.
-    Same pivots as a refresh per batch; at BASELINE config 3 two passes over Ur instead of four."""
+    Same pivots as a refresh per batch; at BASELINE config 3 two passes over Ur instead of four.
+    Sharded runs: every rank keeps its own pool and decides on its own between a pool sweep and a full one -- the tau the
+    ranks all-gather is each rank's own bound on its non-candidates, whatever refresh produced it.  Only the exactness of
+    the first step after a refresh (which holds when EVERY rank has just swept all its rows) needs common knowledge: it
+    is claimed after the initial norms and after a batch that certified nothing (all ranks then take a full sweep)."""
     torch = eng.torch
     n, batch = st['n'], eng.qr_batch
     dmax = eng.qr_epoch_max_directions(st)
@@ -366,14 +370,22 @@ def _pivot_loop_pooled(eng, st, s, stats):
     theta = new_epoch()
     j = j_e = j_mark = 0
     first_exact = True
+    sharded = all_gather is not None
     while j < s:
         nb = min(batch, s - j)
-        eng.qr_steps(st, j, nb, first_exact=first_exact)
+        if not sharded:
+            eng.qr_steps(st, j, nb, first_exact=first_exact)
+        else:
+            taus = all_gather(st['tau'])
+            for t in range(nb):                                  # steps on the candidate set, no host sync
+                eng.qr_step(st, j + t, all_gather(st['rec']), taus, first=(t == 0 and first_exact))
         chk = eng.to_host(torch.cat([st['ok'][j:j + nb], st['rec'][:1], st['tau']]))   # one sync per batch
         ok, best_next, tau = chk[:nb], chk[nb], chk[nb + 1]
         k = nb if ok.all() else int(np.argmin(ok))               # certified prefix
         if k < 1 and first_exact:
             raise RuntimeError('optimal_placement: first step after a sweep was not certified')
+        # (k == 0 without first_exact: a tie between the best row and tau after a pool sweep -- or, sharded, after full
+        #  sweeps nobody could vouch for; the full sweep below is then followed by a step that is exact by construction)
         j += k
         if j >= s:
             break
@@ -399,7 +411,7 @@ def _pivot_loop_pooled(eng, st, s, stats):
             if stats is not None:
                 stats['log'].append(('full sweep', j_e, j))
             j_e = j
-            first_exact = True
+            first_exact = (not sharded) or k == 0               # sharded: only k == 0 tells that every rank swept all rows
             theta = new_epoch() if s - j > batch // 2 else None
         j_mark = j
     if stats is not None:
@@ -412,10 +424,10 @@ def pivot_loop(eng, st, s, all_gather=None, start=0, near=None, pools=False, sta
     steps on the candidate set, one full sweep per batch.  Returns the number of sweeps over Ur.
     start: first step index (GEM keeps its centring direction in slot 0); near = (xyz, n_points, d_min):
     GEM's distance exclusion around every pick.  pools: refresh only the rows that can still be picked between two
-    full sweeps (one rank, plain QR pivoting, bases the epoch-sweep kernel takes; see _pivot_loop_pooled)."""
-    if (pools and all_gather is None and near is None and start == 0 and s > eng.qr_batch
+    full sweeps (plain QR pivoting, bases the epoch-sweep kernel takes; see _pivot_loop_pooled)."""
+    if (pools and near is None and start == 0 and s > eng.qr_batch
             and hasattr(eng, 'qr_epoch_ok') and eng.qr_epoch_ok(st)):
-        return _pivot_loop_pooled(eng, st, s, stats)
+        return _pivot_loop_pooled(eng, st, s, stats, all_gather)
     kw = dict(xyz=near[0], n_points=near[1], d_min=near[2]) if near is not None else {}
     j, sweeps = start, 1
     while j < s:

@@ -95,7 +95,7 @@ def _synth_worker(rank, world, port, cells, F, m, s_, out_dir):
         x = spr.reconstruct(spr.Ar[:1], to_host=False, wait=False).wait()
         if rank == 0:
             np.savez(os.path.join(out_dir, 'dist.npz'), piv=spr.sensors_, S=spr.S_, field=eng.to_host(x)[0], a=spr.Ar[0],
-                     sign=np.sign(spr.Ar[0]))
+                     sign=np.sign(spr.Ar[0]), pool_sweeps=spr.pivot_pool_sweeps_, sweeps=spr.pivot_sweeps_)
     finally:
         dist.destroy_process_group()
 
@@ -119,6 +119,9 @@ def test_config4_shaped_shards_four_ranks_one_gpu(tmp_path):
     one.fit(select_modes='number', n_modes=s_)
     one.optimal_placement()
     np.testing.assert_array_equal(d['piv'], one.sensors_)
+    # every rank kept its own pool of rows between full sweeps (epoch sweeps, SPR.placement_pools) and still certified
+    # the single-rank order
+    assert int(d['pool_sweeps']) >= 1, (int(d['pool_sweeps']), int(d['sweeps']))
     np.testing.assert_allclose(d['S'][:s_], one.S_[:s_], rtol=1e-11)
     ref = eng.to_host(one.reconstruct(one.Ar[:1] * 1.0, to_host=False))[0]
     # the same coefficient vector in each run's own sign convention reconstructs the same field

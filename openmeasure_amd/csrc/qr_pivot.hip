@@ -30,6 +30,9 @@
 namespace {
 
 constexpr int QR_THREADS = 256;
+#ifndef QR_EPOCH_DEEP
+#define QR_EPOCH_DEEP 0   // 1: epoch sweeps keep a third register set (two panels ahead) where it fits; 0: two sets, more waves
+#endif
 #ifndef QR_ABLATE
 #define QR_ABLATE 0   // diagnostics (tools/ablate.sh, wrong results): 1 = sweeps keep no candidate lists, 2 = nor touch the norm vector
 #endif
@@ -83,15 +86,19 @@ __device__ inline f64x2 load_row_piece(const TU *__restrict__ rp, int k0, int r,
 }
 
 // Per-lane sorted list of the QR_TOPT largest (value, global row) pairs seen, and its block-level merge.
-struct TopList {
+// TI: index type of the per-lane entries -- the global row as long long, or (epoch sweeps: fewer than 2^31 local rows) the
+// LOCAL row as int with the shard's first row added when the lists are staged: 16 VGPRs less, a third wave per SIMD.
+template <typename TI>
+struct TopListT {
   double tv[QR_TOPT];
-  long long ti[QR_TOPT];
+  TI ti[QR_TOPT];
+  long long base = 0;            // added to every index at the block merge
   __device__ inline void init() {
 #pragma unroll
     for (int k = 0; k < QR_TOPT; ++k) { tv[k] = -2.0; ti[k] = -1; }
   }
   // rows reach a lane in increasing index order, so "strictly greater" keeps the lowest index among equals
-  __device__ inline void insert(double v, long long gi, bool mine) {
+  __device__ inline void insert(double v, TI gi, bool mine) {
     const bool ins = mine && (v > tv[QR_TOPT - 1]);
     if (__any(ins)) {
 #pragma unroll
@@ -99,7 +106,7 @@ struct TopList {
         const bool here = ins && (v > tv[k]);
         const bool above = (k > 0) ? (v > tv[k > 0 ? k - 1 : 0]) : false;
         const double nv = above ? tv[k > 0 ? k - 1 : 0] : v;
-        const long long ni = above ? ti[k > 0 ? k - 1 : 0] : gi;
+        const TI ni = above ? ti[k > 0 ? k - 1 : 0] : gi;
         tv[k] = here ? nv : tv[k];
         ti[k] = here ? ni : ti[k];
       }
@@ -134,7 +141,7 @@ struct TopList {
 #pragma unroll
       for (int k = 0; k < QR_TOPT; ++k) {
         sval[(wave * SPW + slot) * QR_TOPT + k] = tv[k];
-        sidx[(wave * SPW + slot) * QR_TOPT + k] = ti[k];
+        sidx[(wave * SPW + slot) * QR_TOPT + k] = ti[k] >= 0 ? (long long)ti[k] + base : -1;
       }
     }
     __syncthreads();
@@ -163,6 +170,7 @@ struct TopList {
     }
   }
 };
+using TopList = TopListT<long long>;
 
 // Who writes a row's norm at the end of a sweep block (all three kernel forms).  The 16 x 16 MFMA result of a wave's
 // 16-row block leaves lane (g = lane >> 4, c = lane & 15) with the entries (row g + 4 q, column c), q = 0..3.
@@ -856,7 +864,7 @@ int check_ur(const char *who, const void *Ur, int64_t n_rows, int32_t r, int64_t
 // epoch starts with a lower theta.  The directions of an epoch (up to NT tiles of 16) sit in LDS in fragment order;
 // rows go HBM -> registers in the MFMA A layout exactly as in qr_refresh_direct_kernel.
 template <int NG, int NT, typename TU, bool POOL>
-__global__ __launch_bounds__(QR_THREADS) void qr_epoch_sweep_kernel(
+__global__ __launch_bounds__(QR_THREADS, (NG <= 4 ? 3 : 2)) void qr_epoch_sweep_kernel(
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0, const double *__restrict__ Q, int nq,
     double *__restrict__ nrm_e, double *__restrict__ nrm, const int32_t *__restrict__ pool,
     const int32_t *__restrict__ pool_n_ptr, double *__restrict__ tops) {
@@ -876,8 +884,9 @@ __global__ __launch_bounds__(QR_THREADS) void qr_epoch_sweep_kernel(
     Ql[e] = (d < nq) ? Q[(int64_t)d * r + 16 * g + 4 * k4 + t] : 0.0;
   }
   __syncthreads();
-  TopList top;
+  TopListT<int> top;               // local rows (< 2^31: spr_qr_epoch_supported); row0 is added at the merge
   top.init();
+  top.base = row0;
   const RowOwner<false> who(lane);
   const int64_t n_units = POOL ? (int64_t)*pool_n_ptr : n_rows;      // rows to visit
   const int64_t npanels = (n_units + R - 1) / R;
@@ -899,7 +908,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_epoch_sweep_kernel(
   // NBUF register sets per wave, used in rotation (no copies): while set u is multiplied, the rows NBUF - 1 panels ahead
   // are requested into the set that was multiplied last.  Three sets (two panels ahead) where a set is <= 32 VGPRs: with two
   // waves per SIMD one panel ahead leaves 16 MB in flight on the chip -- 4.3 TB/s for a full sweep at config 3, 10.6 ms.
-  constexpr int NBUF = (NG * sizeof(P4) / 4 <= 32 && NG <= 6) ? 3 : 2;
+  constexpr int NBUF = (QR_EPOCH_DEEP && NG * sizeof(P4) / 4 <= 32 && NG <= 6) ? 3 : 2;
   P4 buf[NBUF][NG];
   double oldv[NBUF];
   int64_t orv[NBUF];
@@ -933,7 +942,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_epoch_sweep_kernel(
       nrm[orow] = v;
       if (!POOL) nrm_e[orow] = v;                              // full sweep: the next epoch starts from these
     }
-    top.insert(v, row0 + orow, mine);
+    top.insert(v, (int)orow, mine);
   };
   int64_t c = blockIdx.x;
   const int64_t gs = gridDim.x;

@@ -291,3 +291,147 @@ class NumpyEngine:
             info[p] = (1, keep.sum(), sv.max(), sv[keep].min())
         return (torch.from_numpy(Ar), torch.from_numpy(As), torch.from_numpy(y0), torch.from_numpy(info))
 
+
+
+class CandidateEngine(NumpyEngine):
+    """The pivoting half of the engine as a CANDIDATE-SET model (still a test double): sweeps leave, per block of
+    ``block`` rows, the ``topt`` largest residual norms as candidates and tau = the largest norm a non-candidate may have;
+    steps act on the candidates only and are certified against tau; refreshes, pool sweeps and full epoch sweeps redraw
+    the candidates -- the protocol of csrc/qr_pivot.hip in NumPy, with blocks small enough that certification fails and
+    pools empty out on matrices of a few hundred rows.  Lets the host drivers (pivot_loop, _pivot_loop_pooled, sharded or
+    not) run on CPU; ``log`` records the refreshes taken."""
+
+    qr_batch = 4
+
+    def __init__(self, block=16, topt=2, max_dirs=8):
+        super().__init__()
+        self.block, self.topt, self.max_dirs = block, topt, max_dirs
+        self.log = []
+
+    # ---- candidate bookkeeping
+    def _draw(self, st, visited, floor=-2.0):
+        """candidates = per block the topt largest bounds among the visited rows; tau = the best bound left out"""
+        nrm = st['nrm'].numpy()
+        n = st['n']
+        cand, tau = [], -2.0
+        for b0 in range(0, n, self.block):
+            rows = np.arange(b0, min(b0 + self.block, n))
+            rows = rows[visited[rows]]
+            if rows.size == 0:
+                continue
+            order = rows[np.lexsort((rows, -nrm[rows]))]            # value descending, lowest index first
+            cand.extend(order[:self.topt].tolist())
+            if order.size > self.topt:
+                tau = max(tau, nrm[order[self.topt]])
+        st['cand'] = np.array(cand, dtype=np.int64)
+        st['cand_res'] = nrm[st['cand']].copy()
+        st['tau'] = torch.tensor([max(tau, floor)], dtype=torch.float64)
+        self._cand_record(st)
+
+    def _cand_record(self, st):
+        res, cand = st['cand_res'], st['cand']
+        live = res >= 0
+        U = self._w(st['Ur'])
+        if not live.any():
+            st['rec'] = torch.from_numpy(np.concatenate([[-2.0, 2.0 ** 62, -2.0], np.zeros(st['r'])]))
+            return
+        order = np.lexsort((cand, -res))
+        order = order[live[order]]
+        w = order[0]
+        second = res[order[1]] if order.size > 1 else -2.0
+        st['rec'] = torch.from_numpy(np.concatenate([[res[w], st['row0'] + cand[w], second], U[cand[w]]]))
+
+    def qr_begin(self, Ur, row0, n_steps, norms=None):
+        st = super().qr_begin(Ur, row0, n_steps)
+        st['ldu'] = Ur.shape[1]
+        if norms is not None:
+            st['nrm'] = norms.clone()
+        self._draw(st, np.ones(st['n'], dtype=bool))
+        return st
+
+    def qr_step(self, st, step, recs, taus, first, xyz=None, n_points=0, d_min=0.0):
+        c = recs.numpy()
+        order = np.lexsort((c[:, 1], -c[:, 0]))
+        w = order[0]
+        piv = int(c[w, 1])
+        st['piv'][step] = piv
+        others = [c[w, 2]] + [c[i, 0] for i in range(c.shape[0]) if i != w]
+        st['gap'][step] = (c[w, 0] - max(others)) / c[w, 0] if c[w, 0] > 0 else 0.0
+        st['ok'][step] = 1.0 if (first or c[w, 0] > float(taus.max())) else 0.0
+        v = c[w, 3:].copy()
+        Q = st['Q'].numpy()
+        for _ in range(2):
+            v -= Q[:step].T @ (Q[:step] @ v)
+        nn = np.linalg.norm(v)
+        Q[step] = v / nn if nn > 0 else 0.0
+        d = self._w(st['Ur'])[st['cand']] @ Q[step]                 # the candidates only
+        res = st['cand_res']
+        new = np.maximum(res - d * d, 0.0)
+        new[res < 0] = -1.0
+        new[st['cand'] + st['row0'] == piv] = -1.0
+        st['cand_res'] = new
+        self._cand_record(st)
+
+    def qr_steps(self, st, step0, n_steps, xyz=None, n_points=0, d_min=0.0, first_exact=True):
+        for t in range(n_steps):
+            self.qr_step(st, step0 + t, st['rec'][None], st['tau'][None], first=(t == 0 and first_exact))
+
+    def _mark(self, st, arr, j0, j1):
+        for g in st['piv'].numpy()[j0:j1]:
+            li = int(g) - st['row0']
+            if 0 <= li < st['n']:
+                arr[li] = -1.0
+
+    def _apply(self, st, base, rows, j0, j1):
+        U = self._w(st['Ur'])[rows]
+        d = U @ st['Q'].numpy()[j0:j1].T
+        new = np.maximum(base[rows] - (d * d).sum(axis=1), 0.0)
+        new[base[rows] < 0] = -1.0
+        return new
+
+    def qr_refresh(self, st, j0, nq):
+        nrm = st['nrm'].numpy()
+        self._mark(st, nrm, j0, j0 + nq)
+        rows = np.arange(st['n'])
+        nrm[:] = self._apply(st, nrm, rows, j0, j0 + nq)
+        self.log.append(('refresh', j0, j0 + nq))
+        self._draw(st, np.ones(st['n'], dtype=bool))
+
+    # ---- epoch sweeps
+    def qr_epoch_ok(self, st):
+        return True
+
+    def qr_epoch_max_directions(self, st):
+        return self.max_dirs
+
+    def qr_epoch_begin(self, st):
+        st['nrm_e'] = st['nrm'].clone()
+        st['pool_n'] = 0
+
+    def qr_pool_build(self, st, theta):
+        pool = np.flatnonzero(st['nrm_e'].numpy() > theta)
+        if pool.size > max(st['n'] // 4, 8):
+            st['pool_n'] = -1
+            return -1
+        st['pool'] = pool
+        st['pool_n'] = int(pool.size)
+        return st['pool_n']
+
+    def qr_epoch_sweep(self, st, j_e, j, j_mark, pool=False, tau_floor=-2.0):
+        assert 0 < j - j_e <= self.max_dirs, (j_e, j)
+        nrm, nrm_e = st['nrm'].numpy(), st['nrm_e'].numpy()
+        self._mark(st, nrm_e, j_mark, j)
+        self._mark(st, nrm, j_mark, j)
+        visited = np.zeros(st['n'], dtype=bool)
+        if pool:
+            rows = st['pool']
+            nrm[rows] = self._apply(st, nrm_e, rows, j_e, j)
+            visited[rows] = True
+            self.log.append(('pool', j_e, j, int(rows.size)))
+        else:
+            rows = np.arange(st['n'])
+            nrm[:] = self._apply(st, nrm_e, rows, j_e, j)
+            nrm_e[:] = nrm
+            visited[:] = True
+            self.log.append(('full', j_e, j))
+        self._draw(st, visited, tau_floor if pool else -2.0)

@@ -330,3 +330,51 @@ def test_one_collective_per_fit_and_per_reconstruct(tmp_path, world):
         assert o['rec'].tolist() == ['all_gather_into_tensor'] and o['rec1'].tolist() == ['all_gather_into_tensor']
         assert np.linalg.norm(o['X3'] - ref) <= 1e-6 * np.linalg.norm(ref)
         np.testing.assert_allclose(o['x1'][0], o['X3'][:, 0], rtol=1e-12, atol=1e-12)
+
+
+def _pool_worker(rank, world, port, out_dir, heavy):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import torch
+        from openmeasure_amd.sparse_sensing import pivot_loop
+        from tests.numpy_engine import CandidateEngine
+        rng = np.random.default_rng(11)
+        n, r = 1200, 20
+        U = rng.standard_normal((n, r))
+        U = U * np.exp(1.5 * rng.standard_normal((n, 1))) if heavy else np.linalg.qr(U)[0]
+        n_loc = n // world
+        row0 = rank * n_loc
+        eng = CandidateEngine()
+        st = eng.qr_begin(eng.to_device(U[row0:row0 + n_loc]), row0, r)
+        calls = []
+
+        def all_gather(t):
+            calls.append(tuple(t.shape))
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t.contiguous())
+            return torch.stack(out)
+        stats = {}
+        sweeps = pivot_loop(eng, st, r, all_gather=all_gather, pools=True, stats=stats)
+        np.savez(os.path.join(out_dir, f'pool{rank}.npz'), piv=st['piv'].numpy(), U=U, sweeps=sweeps,
+                 pool=stats['pool_sweeps'], kinds=np.array([e[0] for e in eng.log]), n_calls=len(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,heavy', [(2, True), (3, True), (4, False), (2, False)])
+def test_sharded_epoch_sweeps_on_the_candidate_model(tmp_path, world, heavy):
+    """_pivot_loop_pooled over gloo: every rank keeps its own pool and chooses its own refreshes (their sequences differ
+    from rank to rank), the all-gathered tau certifies the steps, and the order is dgeqp3's -- on the candidate-set model of
+    the device protocol, whose blocks are small enough that certification fails and pools run dry."""
+    from oracle import spr_oracle as orc
+    mp.spawn(_pool_worker, args=(world, _free_port(), str(tmp_path), heavy), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f'pool{r}.npz') for r in range(world)]
+    ref, _ = orc.qr_pivots(outs[0]['U'])
+    for o in outs:
+        np.testing.assert_array_equal(o['piv'], ref)
+        assert int(o['n_calls']) == int(outs[0]['n_calls'])            # the same collectives on every rank
+    if heavy:
+        assert sum(int(o['pool']) for o in outs) >= 1

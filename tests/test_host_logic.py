@@ -348,3 +348,52 @@ def test_gem_ridge_phase_with_dependent_picks():
     C = spr.optimal_placement(calc_type='gem', n_sensors=r + 3)
     assert C.shape == (r + 3, n)
     assert len(set(spr.sensors_.tolist())) == r + 3 and spr.sensors_.min() >= 0
+
+
+# ---- the placement drivers on a candidate-set model of the device protocol (tests/numpy_engine.py: CandidateEngine) ----
+def _pool_cases():
+    rng = np.random.default_rng(0)
+    out = []
+    for n, r in ((600, 12), (900, 20), (300, 8), (2000, 24), (257, 16)):
+        U = rng.standard_normal((n, r))
+        out.append((f'heavy-{n}x{r}', U * np.exp(1.5 * rng.standard_normal((n, 1)))))     # few rows far above the rest
+        out.append((f'uniform-{n}x{r}', np.linalg.qr(U)[0]))                             # pools never pay
+    U = rng.standard_normal((400, 10)) * np.exp(rng.standard_normal((400, 1)))
+    U[100:140] = U[60:100]                                                              # duplicated rows: ties
+    U[300:330] = 0.0                                                                    # zero rows (a mask)
+    out.append(('ties-and-zero-rows', U))
+    return out
+
+
+@pytest.mark.parametrize('name,U', _pool_cases(), ids=[c[0] for c in _pool_cases()])
+@pytest.mark.parametrize('pools', [False, True])
+def test_pivot_drivers_on_the_candidate_model(name, U, pools):
+    """pivot_loop / _pivot_loop_pooled against dgeqp3's order, on a NumPy model of the candidate-set protocol whose blocks
+    are small enough (16 rows, 2 candidates each, 8 directions per epoch sweep) that batches fail their certification,
+    pools empty out and full sweeps have to step in."""
+    from openmeasure_amd.sparse_sensing import pivot_loop
+    from oracle import spr_oracle as orc
+    from tests.numpy_engine import CandidateEngine
+    r = U.shape[1]
+    ref, _ = orc.qr_pivots(U)
+    eng = CandidateEngine()
+    st = eng.qr_begin(eng.to_device(U), 0, r)
+    stats = {}
+    sweeps = pivot_loop(eng, st, r, pools=pools, stats=stats)
+    piv = st['piv'].numpy()
+    if name.startswith('ties'):      # equal norms: LAPACK's and our tie rule agree on the first of equals only while norms are exact
+        assert len(set(piv.tolist())) == r
+        k = int(np.argmax(piv != ref)) if (piv != ref).any() else r
+        assert k >= 1
+    else:
+        np.testing.assert_array_equal(piv, ref)
+    kinds = [e[0] for e in eng.log]
+    if pools:
+        assert 'refresh' not in kinds and sweeps == 1 + kinds.count('full') and stats['pool_sweeps'] == kinds.count('pool')
+        if name.startswith('heavy'):
+            eng2 = CandidateEngine()
+            st2 = eng2.qr_begin(eng2.to_device(U), 0, r)
+            plain = pivot_loop(eng2, st2, r)
+            assert kinds.count('pool') >= 1 and sweeps <= plain and (sweeps < plain or r <= 2 * eng.qr_batch)
+    else:
+        assert set(kinds) <= {'refresh'} and sweeps == 1 + len(kinds)

@@ -59,6 +59,11 @@ template <> struct GramCfg<12> { static constexpr int NW = 12, R = 24, KS = 2; s
 #endif
 template <> struct GramCfg<16> { static constexpr int NW = 8,  R = 32, KS = 1; static constexpr bool DBUF = GRAM_DBUF16; static constexpr int LPRMAX = 16; };
 
+// Slabs a workgroup writes: its KS k-slices hold partial sums of the SAME tiles; for the narrow shapes (KS >= 4, where the
+// slabs are a visible share of the HBM traffic of an HBM-bound pass: 84 MB written and read again next to the 2 GB of
+// config 2) they are added up inside the workgroup, through the dead panel buffers, before one slab goes out.
+template <int MT> struct GramOut { static constexpr int KSO = (GramCfg<MT>::KS >= 4) ? 1 : GramCfg<MT>::KS; };
+
 // linear index over the upper triangle (row-major) <-> tile row / column
 constexpr int tri_index(int mt, int ti, int tj) { return ti * mt - ti * (ti - 1) / 2 + (tj - ti); }
 
@@ -177,17 +182,54 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
     nrow0 = n2row0;
   }
 
-  // tiles -> slab[(block*KS + ks)][tile][reg][lane]
-  double *sp = slab + ((int64_t)blockIdx.x * KS + ks) * T * 256 + lane;
+  constexpr int KSO = GramOut<MT>::KSO;
+  if constexpr (KSO != KS) {
+    // k-slice s adds its tiles onto slice s - 1, s = KS - 1 .. 1, through LDS (T x 2 KB: fits the two panel buffers, which
+    // are contiguous); fixed order, every wave of the workgroup passes the same 2 (KS - 1) barriers
+    static_assert((size_t)T * 256 <= (size_t)2 * R * MP, "tile staging must fit the panel buffers");
+    double *red = lds0 + lane;
+    for (int s = KS - 1; s >= 1; --s) {
+      __syncthreads();                                     // panels (first round) / the previous round's reads are done
+      if (ks == s) {
 #pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    double *tp = sp + (int64_t)tri_index(MT, RA, RA + j) * 256;
-    tp[0] = accA[j].x; tp[64] = accA[j].y; tp[128] = accA[j].z; tp[192] = accA[j].w;
+        for (int j = 0; j < NA; ++j) {
+          double *tp = red + tri_index(MT, RA, RA + j) * 256;
+          tp[0] = accA[j].x; tp[64] = accA[j].y; tp[128] = accA[j].z; tp[192] = accA[j].w;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          double *tp = red + tri_index(MT, RB, RB + j) * 256;
+          tp[0] = accB[j].x; tp[64] = accB[j].y; tp[128] = accB[j].z; tp[192] = accB[j].w;
+        }
+      }
+      __syncthreads();
+      if (ks == s - 1) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const double *tp = red + tri_index(MT, RA, RA + j) * 256;
+          accA[j].x += tp[0]; accA[j].y += tp[64]; accA[j].z += tp[128]; accA[j].w += tp[192];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const double *tp = red + tri_index(MT, RB, RB + j) * 256;
+          accB[j].x += tp[0]; accB[j].y += tp[64]; accB[j].z += tp[128]; accB[j].w += tp[192];
+        }
+      }
+    }
   }
+  // tiles -> slab[(block*KSO + slice)][tile][reg][lane]
+  if (KSO == KS || ks == 0) {
+    double *sp = slab + ((int64_t)blockIdx.x * KSO + (KSO == KS ? ks : 0)) * T * 256 + lane;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double *tp = sp + (int64_t)tri_index(MT, RB, RB + j) * 256;
-    tp[0] = accB[j].x; tp[64] = accB[j].y; tp[128] = accB[j].z; tp[192] = accB[j].w;
+    for (int j = 0; j < NA; ++j) {
+      double *tp = sp + (int64_t)tri_index(MT, RA, RA + j) * 256;
+      tp[0] = accA[j].x; tp[64] = accA[j].y; tp[128] = accA[j].z; tp[192] = accA[j].w;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double *tp = sp + (int64_t)tri_index(MT, RB, RB + j) * 256;
+      tp[0] = accB[j].x; tp[64] = accB[j].y; tp[128] = accB[j].z; tp[192] = accB[j].w;
+    }
   }
   // Welford partials: one slot per lane group
   if ((lane % RT::LPR) == 0) {
@@ -416,7 +458,7 @@ __global__ __launch_bounds__(1024) void gram_finalize_kernel(
     const double *__restrict__ slab, const double *__restrict__ stat_part, int m, SegPlan plan,
     int slots_per_wg, double *__restrict__ gram, double *__restrict__ fstats, int ldg, int origin) {
   constexpr int T = GramShape<MT>::T;
-  constexpr int KS = GramCfg<MT>::KS;
+  constexpr int KS = GramOut<MT>::KSO;                 // slabs per workgroup
   __shared__ double red[4][256];
   const int f = blockIdx.y;
   const int tile = blockIdx.x;

@@ -19,6 +19,9 @@
 
 #include "rowtile.hpp"
 
+#ifndef GRAM_UNIT_PAIRING
+#define GRAM_UNIT_PAIRING 1
+#endif
 #ifndef GRAM_ABLATE
 #define GRAM_ABLATE 0   // diagnostic builds: 1 = no MFMAs, 2 = no centring/loads in the loop, 3 = loads + raw LDS stores, no centring arithmetic
 #endif
@@ -369,7 +372,10 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_own_kernel(
   if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int unit = wave % NU, ks = wave / NU;
+  const int ks = wave / NU;
+  // waves w and w + 4 share a SIMD: unit u reads 16 - u operand fragments per k step, so the pairs (u, 7 - u) give every SIMD
+  // the same LDS-read count (25 of 100) instead of 28 / 26 / 24 / 22
+  const int unit = (GRAM_UNIT_PAIRING && NU == 8 && C::KS == 1) ? ((wave < 4) ? wave : 11 - wave) : wave % NU;
 #define GRAM_UNIT(UV)                                                                                          \
   case UV:                                                                                                     \
     if constexpr (UV < NU)                                                                                     \

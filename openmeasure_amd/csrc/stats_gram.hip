@@ -302,7 +302,7 @@ __device__ inline void gram_wave_own(const TX *__restrict__ X, int64_t ldx, int6
     const int64_t n2row0 = (c2 < nchunks) ? lo + c2 * R : hi;
     const TX *n2base = base_of(n2row0 < hi ? n2row0 : lo);
     const bool nfull = nrow0 + R <= hi;                    // wave-uniform
-    __syncthreads();
+    if (GRAM_ABLATE != 4) __syncthreads();               // GRAM_ABLATE=4 (diagnostic, wrong results): what the panel barrier costs
     const double *p = cur + frag;
     auto stage = [&](auto full_tag, int k) {
       constexpr bool FULL = decltype(full_tag)::value;

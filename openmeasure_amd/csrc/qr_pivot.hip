@@ -982,13 +982,37 @@ __global__ __launch_bounds__(PB_THREADS) void qr_pool_count_kernel(const double 
   }
 }
 
-// one workgroup: exclusive scan of the chunk counts (in place); pool_n = total, or -1 when the list would not fit
-__global__ void qr_pool_scan_kernel(int32_t *__restrict__ counts, int n_blocks, int64_t cap, int32_t *__restrict__ pool_n) {
-  if (threadIdx.x == 0) {
-    int64_t run = 0;
-    for (int b = 0; b < n_blocks; ++b) { const int c = counts[b]; counts[b] = (int32_t)(run < INT32_MAX ? run : INT32_MAX); run += c; }
-    *pool_n = run <= cap ? (int32_t)run : -1;
+// one workgroup: exclusive scan of the chunk counts (in place); pool_n = total, or -1 when the list would not fit.
+// Thread t owns the contiguous counts [t per, (t + 1) per); wave scan by shuffles, the 16 wave totals through LDS.
+__global__ __launch_bounds__(1024) void qr_pool_scan_kernel(int32_t *__restrict__ counts, int n_blocks, int64_t cap,
+                                                            int32_t *__restrict__ pool_n) {
+  constexpr int PER = (PB_MAX_BLOCKS + 1023) / 1024;
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int v[PER], mine = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int b = t * PER + i;
+    v[i] = b < n_blocks ? counts[b] : 0;
+    mine += v[i];
   }
+  int incl = mine;                                             // inclusive scan over the wave's threads
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) before += wsum[w]; total += wsum[w]; }
+  int run = before + incl - mine;                              // rows ahead of this thread's first chunk
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int b = t * PER + i;
+    if (b < n_blocks) counts[b] = run;
+    run += v[i];
+  }
+  if (t == 0) *pool_n = (int64_t)total <= cap ? total : -1;
 }
 
 __global__ __launch_bounds__(PB_THREADS) void qr_pool_fill_kernel(const double *__restrict__ nrm_e, int64_t n_rows,
@@ -1281,7 +1305,7 @@ extern "C" int spr_qr_pool_build(const double *d_nrm_e, int64_t n_rows, double t
   int32_t *counts = static_cast<int32_t *>(d_workspace);
   hipLaunchKernelGGL(qr_pool_count_kernel, dim3(blocks), dim3(PB_THREADS), 0, st, d_nrm_e, n_rows, chunk, theta, counts);
   SPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(qr_pool_scan_kernel, dim3(1), dim3(64), 0, st, counts, blocks, cap, d_pool_n);
+  hipLaunchKernelGGL(qr_pool_scan_kernel, dim3(1), dim3(1024), 0, st, counts, blocks, cap, d_pool_n);
   SPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(qr_pool_fill_kernel, dim3(blocks), dim3(PB_THREADS), 0, st, d_nrm_e, n_rows, chunk, theta, counts,
                      d_pool_n, d_pool);

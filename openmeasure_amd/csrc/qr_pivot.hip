@@ -582,14 +582,11 @@ __global__ __launch_bounds__(1024) void qr_cand_best_kernel(
 }
 
 // one workgroup: pick the winner among the ranks' records, certify it against tau, orthogonalise,
-// store q / pivot / flags
-__global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
-    const double *__restrict__ recs, int n_rec, const double *__restrict__ taus, int n_tau, int first, int r,
-    int step, double *__restrict__ Q, int64_t *__restrict__ piv, double *__restrict__ gap,
-    double *__restrict__ okflag) {
-  __shared__ double v[SPR_MAX_R_WIDE], c[SPR_MAX_R_WIDE];
-  __shared__ double red[QR_THREADS / 64];
-  __shared__ int win;
+// store q / pivot / flags.  v, c: r doubles of LDS each; red: one double per wave; win_p: one int (all LDS).
+__device__ inline void orth_step(const double *__restrict__ recs, int n_rec, const double *__restrict__ taus, int n_tau,
+                                 int first, int r, int step, double *__restrict__ Q, int64_t *__restrict__ piv,
+                                 double *__restrict__ gap, double *__restrict__ okflag, double *v, double *c, double *red,
+                                 int *win_p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int stride = r + 3;
   if (threadIdx.x == 0) {
@@ -598,7 +595,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
       const double vi = recs[(int64_t)i * stride], vw = recs[(int64_t)w * stride];
       if (vi > vw || (vi == vw && recs[(int64_t)i * stride + 1] < recs[(int64_t)w * stride + 1])) w = i;
     }
-    win = w;
+    *win_p = w;
     const double bestv = recs[(int64_t)w * stride];
     double second = recs[(int64_t)w * stride + 2];
     for (int i = 0; i < n_rec; ++i)
@@ -610,7 +607,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
     okflag[step] = (first || bestv > tau) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const double *row = recs + (int64_t)win * stride + 3;
+  const double *row = recs + (int64_t)(*win_p) * stride + 3;
   for (int k = threadIdx.x; k < r; k += QR_THREADS) v[k] = row[k];
   __syncthreads();
   for (int pass = 0; pass < 2; ++pass) {
@@ -637,6 +634,18 @@ __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
   for (int w = 0; w < QR_THREADS / 64; ++w) nn += red[w];
   const double inv = (nn > 0.0) ? 1.0 / sqrt(nn) : 0.0;
   for (int k = threadIdx.x; k < r; k += QR_THREADS) Q[(int64_t)step * r + k] = v[k] * inv;
+}
+
+
+__global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
+    const double *__restrict__ recs, int n_rec, const double *__restrict__ taus, int n_tau, int first, int r,
+    int step, double *__restrict__ Q, int64_t *__restrict__ piv, double *__restrict__ gap,
+    double *__restrict__ okflag, unsigned *__restrict__ zero_me) {
+  __shared__ double v[SPR_MAX_R_WIDE], c[SPR_MAX_R_WIDE];
+  __shared__ double red[QR_THREADS / 64];
+  __shared__ int win;
+  if (zero_me && threadIdx.x == 0) *zero_me = 0u;          // ticket counter of the fused step kernels that follow
+  orth_step(recs, n_rec, taus, n_tau, first, r, step, Q, piv, gap, okflag, v, c, red, &win);
 }
 
 // |p - c| < d_min with the reference's arithmetic (np.linalg.norm of the difference, :649-652)
@@ -673,10 +682,124 @@ __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_kernel(
     if (valid && lig == 0) {
       if (old < 0.0) v = old;
       if (cand_idx[c] == piv) v = -1.0;
-      if (xyz && within(xyz + (cand_idx[c] % n_points) * dim, pc, dim, d_min)) v = -1.0;
+      if (xyz && cand_idx[c] >= 0 && within(xyz + (cand_idx[c] % n_points) * dim, pc, dim, d_min)) v = -1.0;
       cand_res[c] = v;
     }
   }
+}
+
+// One launch per candidate step (one rank, r <= 128): the down-dating above, then every workgroup leaves its best / runner-up
+// and takes a ticket; the LAST one to finish merges the partials (any order gives the same result: ties go to the lowest
+// global row), writes the record, and -- unless this is the last step of the batch -- certifies and orthogonalises the
+// NEXT step's winner right away (orth_step), so that a step is one launch instead of three.  partial[b] = (best, its global
+// row, runner-up, its candidate slot); *ticket is zero on entry (qr_orth_kernel of the batch's first step, or the last
+// workgroup of the previous launch, reset it).
+template <int LPR>
+__global__ __launch_bounds__(QR_THREADS) void qr_step_fused_kernel(
+    const double *__restrict__ cand_U, int n_cand, int r, int ldc, const int64_t *__restrict__ cand_idx,
+    double *__restrict__ Q, int64_t *__restrict__ piv, double *__restrict__ gap, double *__restrict__ okflag, int step,
+    int do_next, const double *__restrict__ tau, double *__restrict__ cand_res, double *__restrict__ rec,
+    const double *__restrict__ xyz, int dim, int64_t n_points, double d_min, double *__restrict__ partial,
+    unsigned *__restrict__ ticket) {
+  constexpr int RPW = 64 / LPR, NWV = QR_THREADS / 64;
+  __shared__ double sv1[NWV], sv2[NWV];
+  __shared__ long long si1[NWV];
+  __shared__ int spos[NWV];
+  __shared__ int s_last;
+  __shared__ double ov[SPR_MAX_R], oc[SPR_MAX_R], ored[NWV];
+  __shared__ int owin;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / LPR, lig = lane % LPR;
+  const int k0 = 2 * lig;
+  const double *q = Q + (int64_t)step * r;
+  const double q0 = (k0 < r) ? q[k0] : 0.0;
+  const double q1 = (k0 + 1 < r) ? q[k0 + 1] : 0.0;
+  const int64_t pv = piv[step];
+  double pc[3] = {0.0, 0.0, 0.0};
+  if (xyz)
+    for (int d = 0; d < dim; ++d) pc[d] = xyz[(pv % n_points) * dim + d];
+  Best b; b.init();
+  int pos = -1;
+  const int stride = gridDim.x * NWV * RPW;
+  for (int c0 = (blockIdx.x * NWV + wave) * RPW; c0 < n_cand; c0 += stride) {
+    const int c = c0 + grp;
+    const bool valid = c < n_cand;
+    const f64x2 u = load_row_piece(cand_U + (int64_t)(valid ? c : 0) * ldc, k0, r, true, valid);
+    const double old = (valid && lig == 0) ? cand_res[c] : 0.0;
+    double v = downdate<LPR>(old, u, q0, q1);
+    if (valid && lig == 0) {
+      const int64_t gi = cand_idx[c];
+      if (old < 0.0) v = old;
+      if (gi == pv) v = -1.0;
+      if (xyz && gi >= 0 && within(xyz + (gi % n_points) * dim, pc, dim, d_min)) v = -1.0;
+      cand_res[c] = v;
+      if (gi >= 0) {
+        const bool better = v > b.v1 || (v == b.v1 && gi < b.i1);
+        b.push(v, gi);
+        pos = better ? c : pos;
+      }
+    }
+  }
+  auto wave_merge = [&]() {                                  // wave reduce carrying the winner's slot
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov1 = __shfl_xor(b.v1, o, 64);
+      const long long oi1 = __shfl_xor((long long)b.i1, o, 64);
+      const double ov2 = __shfl_xor(b.v2, o, 64);
+      const int op = __shfl_xor(pos, o, 64);
+      const bool take = ov1 > b.v1 || (ov1 == b.v1 && oi1 < b.i1);
+      b.merge(ov1, oi1, ov2);
+      pos = take ? op : pos;
+    }
+  };
+  auto block_merge = [&]() {                                 // -> thread 0 holds the workgroup's result
+    wave_merge();
+    if (lane == 0) { sv1[wave] = b.v1; si1[wave] = b.i1; sv2[wave] = b.v2; spos[wave] = pos; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      Best g; g.init(); int gp = -1;
+      for (int w = 0; w < NWV; ++w) {
+        const bool take = sv1[w] > g.v1 || (sv1[w] == g.v1 && si1[w] < g.i1);
+        g.merge(sv1[w], si1[w], sv2[w]);
+        gp = take ? spos[w] : gp;
+      }
+      b = g; pos = gp;
+    }
+  };
+  block_merge();
+  if (threadIdx.x == 0) {
+    double *pp = partial + 4 * (int64_t)blockIdx.x;
+    pp[0] = b.v1; pp[1] = (double)b.i1; pp[2] = b.v2; pp[3] = (double)pos;
+    __threadfence();                                         // the partial is visible before the ticket is
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // ---- last workgroup: merge the partials, write the record
+  b.init(); pos = -1;
+  for (int p = threadIdx.x; p < (int)gridDim.x; p += QR_THREADS) {
+    const volatile double *pp = partial + 4 * (int64_t)p;
+    const double v1 = pp[0], v2 = pp[2];
+    const long long i1 = (long long)pp[1];
+    const int ps = (int)pp[3];
+    const bool take = v1 > b.v1 || (v1 == b.v1 && i1 < b.i1);
+    b.merge(v1, i1, v2);
+    pos = take ? ps : pos;
+  }
+  __syncthreads();                                           // the per-wave staging arrays are reused
+  block_merge();
+  if (threadIdx.x == 0) {
+    rec[0] = b.v1; rec[1] = (double)b.i1; rec[2] = b.v2;
+    spos[0] = pos;
+    *ticket = 0u;
+  }
+  __syncthreads();
+  const int gp = spos[0];
+  for (int k = threadIdx.x; k < r; k += QR_THREADS) rec[3 + k] = (gp >= 0) ? cand_U[(int64_t)gp * ldc + k] : 0.0;
+  if (!do_next) return;
+  __syncthreads();                                           // the record is complete for every thread of this workgroup
+  orth_step(rec, 1, tau, 1, 0, r, step + 1, Q, piv, gap, okflag, ov, oc, ored, &owin);
 }
 
 // the same for rows longer than 128 entries: 64 lanes per row, each walks its column pairs
@@ -700,7 +823,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_cand_downdate_wide_kernel(
       v = v < 0.0 ? 0.0 : v;
       if (old < 0.0) v = old;
       if (cand_idx[c] == piv) v = -1.0;
-      if (xyz && within(xyz + (cand_idx[c] % n_points) * dim, pc, dim, d_min)) v = -1.0;
+      if (xyz && cand_idx[c] >= 0 && within(xyz + (cand_idx[c] % n_points) * dim, pc, dim, d_min)) v = -1.0;
       cand_res[c] = v;
     }
   }
@@ -1174,7 +1297,7 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   const int lpr = pick_lpr(r);
   const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows) * QR_TOPT;
   hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_recs, (int)n_rec, d_taus, (int)n_tau,
-                     (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok);
+                     (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok, (unsigned *)nullptr);
   SPR_LAUNCH_CHECK();
   const int rows_per_block = (QR_THREADS / 64) * (64 / lpr);
   int grid = (n_cand + rows_per_block - 1) / rows_per_block;
@@ -1218,6 +1341,45 @@ extern "C" int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_
                                 void *d_workspace, size_t workspace_bytes, void *stream) {
   SPR_REQUIRE(n_steps >= 1 && step0 >= 0 && step0 + n_steps <= r, SPR_E_INVALID,
               "spr_qr_steps_f64: steps [%d, %d) outside [0, %d)", step0, step0 + n_steps, r);
+  static const bool fused_on = [] { const char *e = getenv("SPR_QR_FUSED_STEPS"); return !(e && e[0] == '0'); }();
+  if (fused_on && r <= SPR_MAX_R) {
+    // one launch per step (qr_step_fused_kernel) behind the first step's orthogonalisation
+    SPR_REQUIRE(d_tau && d_Q && d_piv && d_ok && d_rec && d_workspace, SPR_E_INVALID, "spr_qr_steps_f64: NULL pointer");
+    SPR_REQUIRE(!d_xyz || (xyz_dim >= 1 && xyz_dim <= 3 && n_points > 0), SPR_E_INVALID,
+                "spr_qr_steps_f64: xyz needs 1..3 columns and n_points > 0");
+    SPR_REQUIRE(n_rows > 0 && r > 0, SPR_E_INVALID, "spr_qr_steps_f64: bad shape");
+    SPR_REQUIRE(workspace_bytes >= QrWs::bytes(r), SPR_E_WORKSPACE, "spr_qr_steps_f64: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    QrWs w(d_workspace, r);
+    const int lpr = pick_lpr(r);
+    const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows) * QR_TOPT;
+    const int rows_per_block = (QR_THREADS / 64) * (64 / lpr);
+    int grid = (n_cand + rows_per_block - 1) / rows_per_block;
+    if (grid > 256) grid = 256;
+    // the block lists of the last sweep are dead while steps run (build_candidates has consumed them): their space
+    // holds the workgroups' partial results and the ticket
+    double *partial = w.tops;
+    unsigned *ticket = reinterpret_cast<unsigned *>(w.tops + 4 * 256);
+    hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_rec, 1, d_tau, 1, (int)(first_exact != 0), (int)r,
+                       (int)step0, d_Q, d_piv, d_gap, d_ok, ticket);
+    SPR_LAUNCH_CHECK();
+    for (int t = 0; t < n_steps; ++t) {
+      const int step = step0 + t, do_next = (t + 1 < n_steps);
+#define FS(L) hipLaunchKernelGGL(qr_step_fused_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q, d_piv, d_gap, d_ok, step, do_next, d_tau, w.cand_res, d_rec, d_xyz, (int)xyz_dim, n_points, d_min, partial, ticket); break
+      switch (lpr) {
+        case 1: FS(1);
+        case 2: FS(2);
+        case 4: FS(4);
+        case 8: FS(8);
+        case 16: FS(16);
+        case 32: FS(32);
+        default: FS(64);
+      }
+#undef FS
+      SPR_LAUNCH_CHECK();
+    }
+    return SPR_OK;
+  }
   for (int t = 0; t < n_steps; ++t) {
     const int rc = spr_qr_step_f64(n_rows, r, step0 + t, d_rec, 1, d_tau, 1, t == 0 && first_exact, d_Q, d_piv, d_gap, d_ok, d_rec,
                                    d_xyz, xyz_dim, n_points, d_min, d_workspace, workspace_bytes, stream);

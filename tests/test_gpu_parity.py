@@ -552,6 +552,37 @@ def test_pivots_pooled_vs_oracle(eng, n, r, seed):
     assert 1 <= sweeps <= r and ('pool_sweeps' in stats) == (r > eng.qr_batch)   # one batch: nothing to refresh
 
 
+@pytest.mark.parametrize('seed', range(18))
+def test_placement_drivers_random_bases(eng, seed):
+    """Random bases through both placement drivers (refresh per batch; epoch sweeps with pools and one launch per step):
+    r from 16 to 128, 5k to 400k rows, iid / heavy-tailed / spatially clustered row norms, f64 and f32 storage, a shard
+    offset -- the order of dgeqp3 on the stored values, every time."""
+    import torch
+    from openmeasure_amd.sparse_sensing import pivot_loop
+    rng = np.random.default_rng(9000 + seed)
+    r = int([16, 32, 48, 64, 96, 128][seed % 6])
+    n = int(rng.integers(5_000, 400_000 if r <= 64 else 120_000))
+    kind = ['iid', 'heavy', 'clustered'][(seed // 2) % 3]
+    U = rng.standard_normal((n, r))
+    if kind == 'heavy':
+        U *= np.exp(rng.standard_normal((n, 1)))
+    elif kind == 'clustered':                      # the large rows sit together, as in a field with a localised feature
+        U *= (1.0 + 8.0 * np.exp(-((np.arange(n) - 0.37 * n) / (0.01 * n)) ** 2))[:, None]
+    U /= np.sqrt(n)
+    f32 = seed % 5 == 3
+    if f32:
+        U = U.astype(np.float32).astype(np.float64)
+    ref, _ = orc.qr_pivots(U)
+    Ud = eng.to_device(U.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(U)
+    row0 = int(rng.integers(0, 1000)) if seed % 2 else 0
+    for pools in (False, True):
+        st = eng.qr_begin(Ud, row0, r)
+        stats = {}
+        sweeps = pivot_loop(eng, st, r, pools=pools, stats=stats)
+        np.testing.assert_array_equal(eng.to_host(st['piv']) - row0, ref, err_msg=f'{kind} n={n} r={r} f32={f32} pools={pools}')
+        assert 1 <= sweeps <= 1 + (r - 1) // eng.qr_batch + r // 4
+
+
 def test_pool_build_is_the_sorted_set_of_rows_above_the_threshold(eng):
     import torch
     rng = np.random.default_rng(3)

@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef WS_ABLATE
+#define WS_ABLATE 0
+#endif
 constexpr int WS_WAVES = 8;
 constexpr int WS_ROWS = 16 * WS_WAVES;   // rows a workgroup consumes per step: one 16-row block per wave
 
@@ -153,8 +156,12 @@ __global__ __launch_bounds__(WS_WAVES * 64) void project_ws_kernel(
         const double a = ws_elem<TX>(areg[j], t);
 #pragma unroll
         for (int p = 0; p < RT / 2; ++p) {
+#if WS_ABLATE == 1                                           // diagnostic (wrong results): everything but the MFMAs
+          asm volatile("" ::"v"(a), "v"(bcur[p].x), "v"(bcur[p].y));
+#else
           acc[2 * p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[p].x, acc[2 * p], 0, 0, 0);
           acc[2 * p + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[p].y, acc[2 * p + 1], 0, 0, 0);
+#endif
         }
         if (t == 3) areg[j] = ws_load<VEC, TX>(rpn, 16 * j + 4 * kk, m);   // next block's piece j into the registers just freed
         __builtin_amdgcn_sched_group_barrier(0x100, RT / 2, 0);              // DS reads of the next step first,

@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, fixture, out_dir, bcast=False):
+def _worker(rank, world, port, fixture, out_dir, bcast=False, candidates=False):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -33,7 +33,7 @@ def _worker(rank, world, port, fixture, out_dir, bcast=False):
     try:
         from openmeasure_amd.sparse_sensing import SPR, RowShard
         from tests.conftest import load_golden
-        from tests.numpy_engine import NumpyEngine
+        from tests.numpy_engine import CandidateEngine, NumpyEngine
         g = load_golden(fixture)
         X = g['X']
         n = X.shape[0]
@@ -41,7 +41,7 @@ def _worker(rank, world, port, fixture, out_dir, bcast=False):
         assert n_loc * world == n
         row0 = rank * n_loc
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None,
-                  shard=RowShard(row0, n, broadcast_basis=bcast), engine=NumpyEngine())
+                  shard=RowShard(row0, n, broadcast_basis=bcast), engine=CandidateEngine() if candidates else NumpyEngine())
         spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'],
                 n_modes=g['n_modes'])
         mask = g.get('mask')
@@ -70,14 +70,21 @@ def test_sharded_path_with_basis_broadcast(tmp_path):       # RowShard(broadcast
     _run_sharded(tmp_path, 'g3_num8', 2, True)
 
 
-def _run_sharded(tmp_path, fixture, world, bcast):
+@pytest.mark.parametrize('fixture,world', [('g3_num8', 2), ('g3_num8', 4), ('g2_num4_mask', 2)])
+def test_sharded_path_on_the_candidate_model(tmp_path, fixture, world):
+    """the same fixtures with the candidate-set model under the SPR class: optimal_placement runs the epoch-sweep driver
+    (SPR.placement_pools) over gloo, batches of 4 steps, 16-row blocks -- the reference's sensors"""
+    _run_sharded(tmp_path, fixture, world, False, candidates=True)
+
+
+def _run_sharded(tmp_path, fixture, world, bcast, candidates=False):
     from tests.conftest import load_golden
     from tests.parity import REL_FRO, align_signs, rel_fro
     g = load_golden(fixture)
     n = g['X'].shape[0]
     if n % world:
         pytest.skip('rows do not divide')
-    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path), bcast), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path), bcast, candidates), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
     n_loc = n // world
     for r, o in enumerate(outs):

@@ -141,6 +141,21 @@ int spr_gram_combine_f64(const double *d_gram, const double *d_fstats_all, int32
                          int32_t n_features, int32_t m, int32_t scale_code, double *d_G, double *d_feat,
                          double *d_scale, double *d_inv_scale, void *stream);
 
+/* ---- K1 + K3a for 256 < m <= 512 without a pass for the full-row means (np.average :112 + Gram half of :272) ----
+ * The Gram matrix of row-centred data is P G_s P, P = I - 1 1^T / m, for the Gram matrix G_s of rows shifted by any
+ * per-row constant.  The three launches of the wide path therefore all shift by the mean of the FIRST 256 columns, which
+ * the first symmetric launch (spr_stats_gram_f64 on that slice, center = 1) forms anyway:
+ *   spr_stats_gram_shifted_*   the symmetric pass on another column slice with the given shifts (centre mode 2) that also
+ *                              writes the RAW row sums of its slice (d_rowsum[n_rows]);
+ *   spr_gram_cross_*           center = 2 with the same shifts (no row sums);
+ *   spr_gram_shift_finish_f64  d_rowmean <- (w_a d_rowmean + d_rowsum_b) / m (the means of the full rows) and
+ *                              G_f <- P G_f P for the F matrices. */
+int spr_stats_gram_shifted_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, const double *d_shift, double *d_rowsum,
+                               void *d_workspace, size_t workspace_bytes, void *stream);
+int spr_gram_shift_finish_f64(double *d_rowmean, const double *d_rowsum_b, int64_t n_rows, int32_t w_a, int32_t m,
+                              double *d_gram, int32_t n_features, void *stream);
+
 /* ---- K4 : basis projection  Ur = X0 . W,  W = V_r Sigma_r^-1 (m x r) ----------------
  * Replaces the U factor of np.linalg.svd (:272) and the truncation U[:, :r] (:336).
  * Second read of X.  center = 1: d_rowmean (the row means written by spr_stats_gram_f64)
@@ -463,6 +478,9 @@ int spr_project_stream_norms_x32_f64out(const float *d_X, int64_t n_rows, int32_
                                         const double *d_inv_scale, const double *d_rowmean, const double *d_W,
                                         int32_t r, double *d_Ur, int64_t ldu, double *d_rownorm2, void *d_workspace,
                                         size_t workspace_bytes, void *stream);
+int spr_stats_gram_shifted_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                               int64_t n_points, int32_t n_features, const double *d_shift, double *d_rowsum,
+                               void *d_workspace, size_t workspace_bytes, void *stream);
 int spr_scale_rows_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                        int64_t n_points, int32_t n_features, const double *d_rowmean,
                        const double *d_inv_scale, double *d_X0, int64_t ldo, void *stream);

@@ -37,6 +37,8 @@ PROTOTYPES = {
     'spr_stats_gram_workspace': (_sz, [_i32, _i32]),
     'spr_stats_gram_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),
     'spr_stats_gram_finalize_f64': (C.c_int, [_i64, _i32, _i64, _i64, _i32, _p, _sz, _p, _p, _i32, _i32, _p]),
+    'spr_stats_gram_shifted_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
+    'spr_gram_shift_finish_f64': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _i32, _p]),
     'spr_rowstats_workspace': (_sz, [_i32]),
     'spr_rowstats_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     'spr_gram_cross_workspace': (_sz, [_i32, _i32]),
@@ -97,7 +99,7 @@ class SprError(RuntimeError):
 PROTOTYPES['spr_project_x32_acc'] = (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p, _i64, _p])
 
 # f32-storage twins: identical argument lists (the typed pointer is a void* here)
-for _f64, _x32 in (('spr_stats_gram_f64', 'spr_stats_gram_x32'), ('spr_rowstats_f64', 'spr_rowstats_x32'),
+for _f64, _x32 in (('spr_stats_gram_f64', 'spr_stats_gram_x32'), ('spr_stats_gram_shifted_f64', 'spr_stats_gram_shifted_x32'), ('spr_rowstats_f64', 'spr_rowstats_x32'),
                    ('spr_gram_cross_f64', 'spr_gram_cross_x32'), ('spr_gram_cross_pair_f64', 'spr_gram_cross_pair_x32'), ('spr_project_f64', 'spr_project_x32'),
                    ('spr_project_f64', 'spr_project_x32_f64out'),
                    ('spr_project_stream_f64', 'spr_project_stream_x32'),

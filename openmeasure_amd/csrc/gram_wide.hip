@@ -379,3 +379,65 @@ extern "C" int spr_gram_cross_pair_x32(const float *d_X, int64_t n_rows, int32_t
   return gram_cross_entry("spr_gram_cross_pair_x32", d_X, n_rows, col_a, col_b, w_b, ldg, ldx, row0, n_points, n_features,
                           center, d_rowmean, d_gram, d_workspace, workspace_bytes, stream);
 }
+
+// ---- wide X (256 < m <= 512) without a pass for the full-row means ------------------------------------------------
+// The Gram matrix of row-centred data is P G_s P, P = I - 1 1^T / m, for the Gram matrix G_s of rows shifted by ANY
+// per-row constant c_i (P annihilates constants), and the cancellation in P G_s P is harmless while |mean_i - c_i| stays
+// within a few standard deviations of the row.  So the three launches of the wide path all centre with c_i = the mean of
+// the row's FIRST 256 columns -- which the first symmetric launch forms anyway (centre mode 1 on its slice) -- and the
+// cross block no longer sums 512 columns per row in both of its workgroup flavours.  What is left to do afterwards:
+//   mean_i = (wA c_i + sB_i) / m   with sB_i the raw sum of the row's other columns (spr_stats_gram_shifted_*), and
+//   G_f <- P G_f P  for every feature's m x m matrix.
+namespace {
+
+__global__ __launch_bounds__(256) void shift_means_kernel(double *__restrict__ rowmean, const double *__restrict__ rowsum_b,
+                                                          int64_t n_rows, double w_a, double inv_m) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * 256)
+    rowmean[i] = (w_a * rowmean[i] + rowsum_b[i]) * inv_m;
+}
+
+// one workgroup per feature: row sums r_j of G (fixed order), t = sum of all entries, G_jk <- G_jk - (r_j + r_k)/m + t/m^2
+__global__ __launch_bounds__(1024) void gram_pgp_kernel(double *__restrict__ gram, int m) {
+  __shared__ double rs[SPR_MAX_M_WIDE];
+  __shared__ double tot;
+  double *G = gram + (int64_t)blockIdx.x * m * m;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < m; j += 16) {                        // G is symmetric: row sums = column sums
+    double s = 0.0;
+    for (int k = lane; k < m; k += 64) s += G[(int64_t)j * m + k];
+    s = group_sum_t<64>(s);
+    if (lane == 0) rs[j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int j = 0; j < m; ++j) t += rs[j];
+    tot = t;
+  }
+  __syncthreads();
+  const double inv_m = 1.0 / (double)m, tt = tot * inv_m * inv_m;
+  for (int64_t e = threadIdx.x; e < (int64_t)m * m; e += 1024) {
+    const int j = (int)(e / m), k = (int)(e - (int64_t)j * m);
+    G[e] = G[e] - (rs[j] + rs[k]) * inv_m + tt;
+  }
+}
+
+}  // namespace
+
+// d_rowmean: in the means of the first w_a columns (the shift the three launches used), out the means of the full rows;
+// d_gram: in the F shifted Gram matrices (m x m each), out the centred ones.
+extern "C" int spr_gram_shift_finish_f64(double *d_rowmean, const double *d_rowsum_b, int64_t n_rows, int32_t w_a,
+                                         int32_t m, double *d_gram, int32_t n_features, void *stream) {
+  SPR_REQUIRE(d_rowmean && d_rowsum_b && d_gram, SPR_E_INVALID, "spr_gram_shift_finish_f64: NULL pointer");
+  SPR_REQUIRE(n_rows > 0 && w_a > 0 && m > w_a && m <= SPR_MAX_M_WIDE && n_features > 0, SPR_E_INVALID,
+              "spr_gram_shift_finish_f64: bad shape w_a=%d m=%d", w_a, m);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t blocks = (n_rows + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(shift_means_kernel, dim3((int)blocks), dim3(256), 0, st, d_rowmean, d_rowsum_b, n_rows, (double)w_a,
+                     1.0 / (double)m);
+  SPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_pgp_kernel, dim3(n_features), dim3(1024), 0, st, d_gram, (int)m);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}

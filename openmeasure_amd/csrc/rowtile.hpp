@@ -162,10 +162,12 @@ struct RowTile {
   // one pass of mean -> centre -> LDS; optionally stores the row means and feeds the running
   // statistics.  Split per pass so that a caller can slot the passes between the MFMA steps of
   // the previous panel.
+  // rowsum (centre mode 2 only, may be NULL): receives the RAW sum of the row's m staged values -- the caller shifted the
+  // rows by constants that are not their means and needs the sums to form the means afterwards (gram_wide.hip).
   template <bool WRITE_MEAN>
   __device__ inline void center_store_pass(int it, double *__restrict__ lds, int m, int center, int64_t crow0,
                                            int64_t seg_hi, int wave, int lane, double *__restrict__ rowmean,
-                                           RowStats *st) {
+                                           RowStats *st, double *__restrict__ rowsum = nullptr) {
     const int grp = lane / LPR, lig = lane % LPR;
     const double inv_m = 1.0 / (double)m;
     const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
@@ -174,11 +176,17 @@ struct RowTile {
     // wave-uniform fast path: whole pass inside the segment and no padded columns -> no selects
     const bool fast = ROWTILE_CENTER_FAST && (crow0 + (it + 1) * ROWS_PER_IT <= seg_hi) && (m == MPAD);
     if (fast) {
-      double s = 0.0;
+      double mean;
+      if constexpr (WRITE_MEAN) {
+        double s = 0.0;
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) { const f64x2 w = widen(pre[it][v]); s += w.x + w.y; }
-      s = group_sum_t<LPR>(s);
-      const double mean = center == 2 ? pmean[it] : (center ? s * inv_m : 0.0);
+        for (int v = 0; v < VPL; ++v) { const f64x2 w = widen(pre[it][v]); s += w.x + w.y; }
+        s = group_sum_t<LPR>(s);
+        mean = center == 2 ? pmean[it] : (center ? s * inv_m : 0.0);
+        if (rowsum && center == 2 && lig == 0) rowsum[lrow] = s;
+      } else {
+        mean = center ? pmean[it] : 0.0;                   // callers that do not write means run modes 0 and 2 only: no row sum
+      }
       if (WRITE_MEAN) {
         if (lig == 0 && center != 2) rowmean[lrow] = mean;
         st->push(mean, center != 2);
@@ -208,6 +216,7 @@ struct RowTile {
     const double mean = center == 2 ? pmean[it] : (center ? s * inv_m : 0.0);
     if (WRITE_MEAN) {
       if (rv && lig == 0 && center != 2) rowmean[lrow] = mean;
+      if (rowsum && center == 2 && rv && lig == 0) rowsum[lrow] = s;
       st->push(mean, rv && center != 2);
     }
 #pragma unroll
@@ -254,9 +263,10 @@ struct RowTile {
     }
   }
 
-  template <bool FULL, bool EXT>   // FULL: the whole pass lies inside the segment (wave-uniform, chosen by the caller): no selects
+  // SUMS (with EXT): the external constants are not the rows' means -- the raw row sums go to rowsum[] as well
+  template <bool FULL, bool EXT, bool SUMS = false>   // FULL: the whole pass lies inside the segment (wave-uniform): no selects
   __device__ inline void center_store_own(int it, double *__restrict__ lds, int64_t crow0, int64_t rows_left, int wave,
-                                          int lane, double *__restrict__ rowmean) {
+                                          int lane, double *__restrict__ rowmean, double *__restrict__ rowsum = nullptr) {
     const int grp = lane / LPR, lig = lane % LPR;
     constexpr double inv_m = 1.0 / (double)MPAD;
     const int rloc = it * ROWS_PER_IT + wave * RPW + grp;
@@ -267,6 +277,13 @@ struct RowTile {
     double mean;
     if (EXT) {
       mean = pmean[it];
+      if (SUMS) {
+        double s = w[0].x + w[0].y;
+#pragma unroll
+        for (int v = 1; v < VPL; ++v) s += w[v].x + w[v].y;
+        s = group_sum_t<LPR>(s);
+        if (rv && lig == 0) rowsum[crow0 + rloc] = s;
+      }
     } else {
       double s = w[0].x + w[0].y;
 #pragma unroll
@@ -320,9 +337,10 @@ struct RowTile {
 
   template <bool WRITE_MEAN>
   __device__ inline void center_store(double *__restrict__ lds, int m, int center, int64_t crow0, int64_t seg_hi,
-                                      int wave, int lane, double *__restrict__ rowmean, RowStats *st) {
+                                      int wave, int lane, double *__restrict__ rowmean, RowStats *st,
+                                      double *__restrict__ rowsum = nullptr) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
-      center_store_pass<WRITE_MEAN>(it, lds, m, center, crow0, seg_hi, wave, lane, rowmean, st);
+      center_store_pass<WRITE_MEAN>(it, lds, m, center, crow0, seg_hi, wave, lane, rowmean, st, rowsum);
   }
 };

@@ -89,7 +89,7 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
                                  int64_t lo, int64_t hi, int wl, int wpf, int ks, int wave, int lane,
                                  double *__restrict__ lds0, double *__restrict__ lds1,
                                  double *__restrict__ rowmean, double *__restrict__ stat_part,
-                                 double *__restrict__ slab) {
+                                 double *__restrict__ slab, double *__restrict__ rowsum) {
   using S = GramShape<MT>;
   using C = GramCfg<MT>;
   constexpr int R = C::R, KS = C::KS, NW = C::NW, MP = S::MP, T = S::T;
@@ -121,7 +121,7 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
   // body keeps one shape and stays a single basic block.
   const double *mean_in = rowmean;
   tile.template load<VEC>(X, ldx, m, lo + c * R, hi, wave, lane, mean_in);
-  tile.template center_store<true>(lds0, m, center, lo + c * R, hi, wave, lane, rowmean, &st);
+  tile.template center_store<true>(lds0, m, center, lo + c * R, hi, wave, lane, rowmean, &st, rowsum);
   int64_t cn = c + wpf;
   int64_t nrow0 = (cn < nchunks) ? lo + cn * R : hi;      // past-the-end panel: every row invalid
   tile.template load<VEC>(X, ldx, m, nrow0, hi, wave, lane, mean_in);
@@ -154,7 +154,7 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
         for (int it = 0; it < RT::IT; ++it)
           if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
             if (GRAM_ABLATE == 3) tile.raw_store_pass(it, nxt, m, nrow0, hi, wave, lane);
-            else tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
+            else tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st, rowsum);
             tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane, mean_in);   // panel c+2 into the freed registers
           }
       }
@@ -174,7 +174,7 @@ __device__ inline void gram_wave(const TX *__restrict__ X, int64_t ldx, int m, i
         for (int it = 0; it < RT::IT; ++it)
           if (GRAM_ABLATE != 2 && (it * KSTEPS) / RT::IT == k) {
             if (GRAM_ABLATE == 3) tile.raw_store_pass(it, nxt, m, nrow0, hi, wave, lane);
-            else tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st);
+            else tile.template center_store_pass<true>(it, nxt, m, center, nrow0, hi, wave, lane, rowmean, &st, rowsum);
             tile.template load_pass<VEC>(it, X, ldx, m, n2row0, hi, wave, lane, mean_in);   // panel c+2 into the freed registers
           }
       }
@@ -254,10 +254,10 @@ __device__ inline void chan_merge(double &n, double &mu, double &m2, double nb, 
 // workloads): the same tiles, operand reads and one-barrier pipeline, but the staging goes through load_pass_own /
 // center_store_own of rowtile.hpp (pointer offsets instead of a 64-bit row multiply, no centre-mode selects, no mean load,
 // no running statistics: gram_rowmean_stats_kernel forms those from the n row means afterwards).
-template <int MT, int U, typename TX, bool EXT>
+template <int MT, int U, typename TX, bool EXT, bool SUMS>
 __device__ inline void gram_wave_own(const TX *__restrict__ X, int64_t ldx, int64_t lo, int64_t hi, int wl, int wpf, int ks,
                                      int wave, int lane, double *__restrict__ lds0, double *__restrict__ lds1,
-                                     double *__restrict__ rowmean, double *__restrict__ slab) {
+                                     double *__restrict__ rowmean, double *__restrict__ slab, double *__restrict__ rowsum) {
   using S = GramShape<MT>;
   using C = GramCfg<MT>;
   constexpr int R = C::R, KS = C::KS, NW = C::NW, MP = S::MP, T = S::T;
@@ -284,10 +284,10 @@ __device__ inline void gram_wave_own(const TX *__restrict__ X, int64_t ldx, int6
   for (int it = 0; it < RT::IT; ++it) tile.template load_pass_own<EXT>(it, base_of(crow0), ldx, lane_off, hi - crow0, wave, lane, rowmean, crow0);
   if (crow0 + R <= hi) {
 #pragma unroll
-    for (int it = 0; it < RT::IT; ++it) tile.template center_store_own<true, EXT>(it, lds0, crow0, hi - crow0, wave, lane, rowmean);
+    for (int it = 0; it < RT::IT; ++it) tile.template center_store_own<true, EXT, SUMS>(it, lds0, crow0, hi - crow0, wave, lane, rowmean, rowsum);
   } else {
 #pragma unroll
-    for (int it = 0; it < RT::IT; ++it) tile.template center_store_own<false, EXT>(it, lds0, crow0, hi - crow0, wave, lane, rowmean);
+    for (int it = 0; it < RT::IT; ++it) tile.template center_store_own<false, EXT, SUMS>(it, lds0, crow0, hi - crow0, wave, lane, rowmean, rowsum);
   }
   int64_t cn = c + wpf;
   int64_t nrow0 = (cn < nchunks) ? lo + cn * R : hi;
@@ -309,7 +309,7 @@ __device__ inline void gram_wave_own(const TX *__restrict__ X, int64_t ldx, int6
 #pragma unroll
       for (int it = 0; it < RT::IT; ++it)
         if ((it * KSTEPS) / RT::IT == k) {
-          tile.template center_store_own<FULL, EXT>(it, nxt, nrow0, hi - nrow0, wave, lane, rowmean);
+          tile.template center_store_own<FULL, EXT, SUMS>(it, nxt, nrow0, hi - nrow0, wave, lane, rowmean, rowsum);
           tile.template load_pass_own<EXT>(it, n2base, ldx, lane_off, hi - n2row0, wave, lane, rowmean, n2row0 < hi ? n2row0 : lo);   // panel c+2
         }
     };
@@ -360,9 +360,10 @@ __device__ inline void gram_wave_own(const TX *__restrict__ X, int64_t ldx, int6
   }
 }
 
-template <int MT, typename TX, bool EXT>
+template <int MT, typename TX, bool EXT, bool SUMS>
 __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_own_kernel(
-    const TX *__restrict__ X, int64_t ldx, SegPlan plan, double *__restrict__ rowmean, double *__restrict__ slab) {
+    const TX *__restrict__ X, int64_t ldx, SegPlan plan, double *__restrict__ rowmean, double *__restrict__ slab,
+    double *__restrict__ rowsum) {
   using S = GramShape<MT>;
   using C = GramCfg<MT>;
   constexpr int NU = S::NU;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_own_kernel(
 #define GRAM_UNIT(UV)                                                                                          \
   case UV:                                                                                                     \
     if constexpr (UV < NU)                                                                                     \
-      gram_wave_own<MT, UV, TX, EXT>(X, ldx, lo, hi, wl, wpf, ks, wave, lane, lds[0], lds[1], rowmean, slab);       \
+      gram_wave_own<MT, UV, TX, EXT, SUMS>(X, ldx, lo, hi, wl, wpf, ks, wave, lane, lds[0], lds[1], rowmean, slab, rowsum); \
     break;
   switch (unit) {
     GRAM_UNIT(0) GRAM_UNIT(1) GRAM_UNIT(2) GRAM_UNIT(3) GRAM_UNIT(4) GRAM_UNIT(5) GRAM_UNIT(6) GRAM_UNIT(7)
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(RS_THREADS) void gram_rowmean_stats_kernel(const do
 template <int MT, int VEC, typename TX>
 __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
     const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan,
-    double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab) {
+    double *__restrict__ rowmean, double *__restrict__ stat_part, double *__restrict__ slab, double *__restrict__ rowsum) {
   using S = GramShape<MT>;
   using C = GramCfg<MT>;
   constexpr int NU = S::NU;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(GramCfg<MT>::NW * 64) void stats_gram_kernel(
   case UV:                                                                                                   \
     if constexpr (UV < NU)                                                                                   \
       gram_wave<MT, UV, VEC, TX>(X, ldx, m, center_i, lo, hi, wl, wpf, ks, wave, lane, lds[0],    \
-                        lds[1], rowmean, stat_part, slab);                                                   \
+                        lds[1], rowmean, stat_part, slab, rowsum);                                           \
     break;
   switch (unit) {
     GRAM_UNIT(0) GRAM_UNIT(1) GRAM_UNIT(2) GRAM_UNIT(3) GRAM_UNIT(4) GRAM_UNIT(5) GRAM_UNIT(6) GRAM_UNIT(7)
@@ -563,9 +564,11 @@ size_t workspace_bytes(int32_t n_features) {
 
 template <int MT, typename TX>
 int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points,
-           int32_t n_features, int center, double *rowmean, void *ws, size_t ws_bytes, hipStream_t st) {
+           int32_t n_features, int center, double *rowmean, void *ws, size_t ws_bytes, hipStream_t st,
+           double *rowsum = nullptr) {
   SPR_REQUIRE(ws_bytes >= workspace_bytes<MT>(n_features), SPR_E_WORKSPACE,
               "spr_stats_gram_f64: workspace %zu < %zu", ws_bytes, workspace_bytes<MT>(n_features));
+  SPR_REQUIRE(!rowsum || center == 2, SPR_E_INVALID, "spr_stats_gram: row sums are an output of centre mode 2 only");
   SegPlan plan = make_plan<MT>(n_rows, row0, n_points, n_features);
   const int grid = seg_total_wgs(plan);
   const int64_t max_grid = (int64_t)occupancy_wgs<MT>() + n_features;
@@ -577,7 +580,7 @@ int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, in
   const int lm = vec_ok ? ((m == 16 * MT) ? 2 : 1) : 0;
 #define SG_LAUNCH(LM)                                                                                         \
   hipLaunchKernelGGL((stats_gram_kernel<MT, LM, TX>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, (int)m, \
-                     center, plan, rowmean, stat_part, slab)
+                     center, plan, rowmean, stat_part, slab, rowsum)
   // own-means lane: centre mode 1 on packed, 16-byte-aligned rows of exactly 16 MT columns, MFMA-bound widths only
   // (below m = 128 the pass is HBM-bound and the extra statistics launch would cost more than the VALU work it saves)
   using RTL = RowTile<MT, GramCfg<MT>::R, GramShape<MT>::MP, GramCfg<MT>::NW, GramCfg<MT>::LPRMAX, TX>;
@@ -586,11 +589,14 @@ int launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, in
       (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
     if constexpr (MT >= 8) {
       if (center == 1)
-        hipLaunchKernelGGL((stats_gram_own_kernel<MT, TX, false>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, plan,
-                           rowmean, slab);
-      else   // external means: a column slice of a wider matrix, centred with the means of the full rows
-        hipLaunchKernelGGL((stats_gram_own_kernel<MT, TX, true>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx, plan,
-                           rowmean, slab);
+        hipLaunchKernelGGL((stats_gram_own_kernel<MT, TX, false, false>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx,
+                           plan, rowmean, slab, rowsum);
+      else if (!rowsum)   // external means: a column slice of a wider matrix, centred with the means of the full rows
+        hipLaunchKernelGGL((stats_gram_own_kernel<MT, TX, true, false>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx,
+                           plan, rowmean, slab, rowsum);
+      else                // external per-row constants that are NOT the means: the raw row sums come out as well
+        hipLaunchKernelGGL((stats_gram_own_kernel<MT, TX, true, true>), dim3(grid), dim3(GramCfg<MT>::NW * 64), 0, st, X, ldx,
+                           plan, rowmean, slab, rowsum);
       SPR_LAUNCH_CHECK();
       // statistics of the row means (own or external: the finalize call merges whatever the slots hold)
       hipLaunchKernelGGL(gram_rowmean_stats_kernel, dim3(grid), dim3(RS_THREADS), 0, st, rowmean, plan, (int)RTL::ROWS_PER_IT,
@@ -686,6 +692,39 @@ extern "C" int spr_stats_gram_x32(const float *d_X, int64_t n_rows, int32_t m, i
 #define RUN_CALL(MTV)                                                                                \
   rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_rowmean, d_workspace, \
                    workspace_bytes_, static_cast<hipStream_t>(stream))
+  SPR_DISPATCH_MT(spr_round_mt(m), RUN_CALL)
+#undef RUN_CALL
+  return rc;
+}
+
+// The same pass for a column slice whose rows are shifted by given per-row constants that are NOT their means (d_shift,
+// centre mode 2) -- the raw sums of the slice's rows come out in d_rowsum, so that the caller can form the true means
+// (spr_gram_shift_finish_f64, gram_wide.hip).
+extern "C" int spr_stats_gram_shifted_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                          int64_t n_points, int32_t n_features, const double *d_shift,
+                                          double *d_rowsum, void *d_workspace, size_t workspace_bytes_, void *stream) {
+  int rc = check_args("spr_stats_gram_shifted_f64", d_X, n_rows, m, ldx, row0, n_points, n_features);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_shift && d_rowsum && d_workspace, SPR_E_INVALID, "spr_stats_gram_shifted_f64: NULL pointer");
+  rc = SPR_E_UNSUPPORTED;
+#define RUN_CALL(MTV)                                                                                                    \
+  rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, 2, const_cast<double *>(d_shift), d_workspace,       \
+                   workspace_bytes_, static_cast<hipStream_t>(stream), d_rowsum)
+  SPR_DISPATCH_MT(spr_round_mt(m), RUN_CALL)
+#undef RUN_CALL
+  return rc;
+}
+
+extern "C" int spr_stats_gram_shifted_x32(const float *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                                          int64_t n_points, int32_t n_features, const double *d_shift,
+                                          double *d_rowsum, void *d_workspace, size_t workspace_bytes_, void *stream) {
+  int rc = check_args("spr_stats_gram_shifted_x32", d_X, n_rows, m, ldx, row0, n_points, n_features);
+  if (rc != SPR_OK) return rc;
+  SPR_REQUIRE(d_shift && d_rowsum && d_workspace, SPR_E_INVALID, "spr_stats_gram_shifted_x32: NULL pointer");
+  rc = SPR_E_UNSUPPORTED;
+#define RUN_CALL(MTV)                                                                                                    \
+  rc = launch<MTV>(d_X, n_rows, m, ldx, row0, n_points, n_features, 2, const_cast<double *>(d_shift), d_workspace,       \
+                   workspace_bytes_, static_cast<hipStream_t>(stream), d_rowsum)
   SPR_DISPATCH_MT(spr_round_mt(m), RUN_CALL)
 #undef RUN_CALL
   return rc;

@@ -171,9 +171,10 @@ class HipEngine:
         return rowmean, fstats, gram
 
     def _stats_gram_wide(self, X, row0, n_points, n_features, center):
-        """m > 256: the columns go in slices of 256.  Two slices (m <= 512): A^T B first (cross kernel, which forms the
-        means of the full rows itself), then A^T A, B^T B (symmetric kernel on column slices with external means).
-        More slices: a row-statistics pass, then every diagonal block and every slice pair -- see spr_hip.h."""
+        """m > 256: the columns go in slices of 256.  Two slices (m <= 512): A^T A (symmetric kernel, which forms the means
+        of its slice), A^T B (cross kernel) and B^T B shifted by those same per-row constants, then P G P and the true means
+        (spr_gram_shift_finish_f64).  More slices: a row-statistics pass, then every diagonal block and every slice pair --
+        see spr_hip.h."""
         n, m, ld = self._check_matrix(X)
         if m > _lib.SPR_MAX_M_WIDE:
             return self._stats_gram_slices(X, row0, n_points, n_features, center)
@@ -185,29 +186,43 @@ class HipEngine:
         tic()
         esz = X.element_size()
         wsx = self._workspace('cross', self.lib.spr_gram_cross_workspace(m, F))
-        if center:
-            # the cross block first, in centre mode 1: its panels hold whole rows, so it forms the row means itself and
-            # writes them (no separate row-statistics read of X); the feature statistics then come from the n means
-            rowmean = self.empty((n,))
-            _lib.check(self._x('spr_gram_cross', X)(_ptr(X), n, m, ld, row0, n_points, F, 1, _ptr(rowmean), _ptr(gram),
-                                                   _ptr(wsx), wsx.numel(), st), 'spr_gram_cross_f64')
-            ws = self._workspace('rowstats', self.lib.spr_rowstats_workspace(F))
-            _lib.check(self.lib.spr_rowmean_stats_f64(_ptr(rowmean), n, row0, n_points, F, _ptr(fstats), _ptr(ws),
-                                                      ws.numel(), st), 'spr_rowmean_stats_f64')
-        else:
+        if not center:
             rowmean = self.zeros((n,))
             _lib.check(self._x('spr_gram_cross', X)(_ptr(X), n, m, ld, row0, n_points, F, 0, _ptr(rowmean), _ptr(gram),
                                                    _ptr(wsx), wsx.numel(), st), 'spr_gram_cross_f64')
-        mode = 2 if center else 0
-        scratch = self.empty((F, 3))
-        for origin, width in ((0, mA), (mA, mB)):
-            ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(width, F))
-            xp = X.data_ptr() + origin * esz
-            _lib.check(self._x('spr_stats_gram', X)(xp, n, width, ld, row0, n_points, F, mode, _ptr(rowmean), _ptr(ws),
-                                                   ws.numel(), st), 'spr_stats_gram_f64')
-            _lib.check(self.lib.spr_stats_gram_finalize_f64(n, width, row0, n_points, F, _ptr(ws), ws.numel(),
-                                                            _ptr(scratch), _ptr(gram), m, origin, st),
-                       'spr_stats_gram_finalize_f64')
+            scratch = self.empty((F, 3))
+            for origin, width in ((0, mA), (mA, mB)):
+                ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(width, F))
+                xp = X.data_ptr() + origin * esz
+                _lib.check(self._x('spr_stats_gram', X)(xp, n, width, ld, row0, n_points, F, 0, _ptr(rowmean), _ptr(ws),
+                                                       ws.numel(), st), 'spr_stats_gram_f64')
+                _lib.check(self.lib.spr_stats_gram_finalize_f64(n, width, row0, n_points, F, _ptr(ws), ws.numel(),
+                                                                _ptr(scratch), _ptr(gram), m, origin, st),
+                           'spr_stats_gram_finalize_f64')
+            toc()
+            return rowmean, fstats, gram
+        # Centred: every launch shifts the rows by the mean of their FIRST 256 columns -- formed for free by the symmetric
+        # launch on that slice -- and P G P afterwards gives the Gram matrix of the row-centred data (spr_hip.h): the cross
+        # block, whose two workgroup flavours used to sum all 512 columns of every row for the full-row mean, only subtracts.
+        rowmean, rowsum_b, scratch = self.empty((n,)), self.empty((n,)), self.empty((F, 3))
+        ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(mA, F))
+        _lib.check(self._x('spr_stats_gram', X)(_ptr(X), n, mA, ld, row0, n_points, F, 1, _ptr(rowmean), _ptr(ws),
+                                               ws.numel(), st), 'spr_stats_gram_f64')
+        _lib.check(self.lib.spr_stats_gram_finalize_f64(n, mA, row0, n_points, F, _ptr(ws), ws.numel(), _ptr(scratch),
+                                                        _ptr(gram), m, 0, st), 'spr_stats_gram_finalize_f64')
+        _lib.check(self._x('spr_gram_cross', X)(_ptr(X), n, m, ld, row0, n_points, F, 2, _ptr(rowmean), _ptr(gram),
+                                               _ptr(wsx), wsx.numel(), st), 'spr_gram_cross_f64')
+        ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(mB, F))
+        _lib.check(self._x('spr_stats_gram_shifted', X)(X.data_ptr() + mA * esz, n, mB, ld, row0, n_points, F,
+                                                       _ptr(rowmean), _ptr(rowsum_b), _ptr(ws), ws.numel(), st),
+                   'spr_stats_gram_shifted_f64')
+        _lib.check(self.lib.spr_stats_gram_finalize_f64(n, mB, row0, n_points, F, _ptr(ws), ws.numel(), _ptr(scratch),
+                                                        _ptr(gram), m, mA, st), 'spr_stats_gram_finalize_f64')
+        _lib.check(self.lib.spr_gram_shift_finish_f64(_ptr(rowmean), _ptr(rowsum_b), n, mA, m, _ptr(gram), F, st),
+                   'spr_gram_shift_finish_f64')
+        ws = self._workspace('rowstats', self.lib.spr_rowstats_workspace(F))
+        _lib.check(self.lib.spr_rowmean_stats_f64(_ptr(rowmean), n, row0, n_points, F, _ptr(fstats), _ptr(ws),
+                                                  ws.numel(), st), 'spr_rowmean_stats_f64')
         toc()
         return rowmean, fstats, gram
 

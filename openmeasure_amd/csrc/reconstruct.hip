@@ -15,6 +15,10 @@
 // writes 16 consecutive field values per vector and no cross-lane reduction is needed at all.  r/4 MFMAs per
 // 16 rows are far below the HBM time of the panel.  The VALU form (dot product closed with a DPP butterfly,
 // 4 vectors per pass) is kept for cross-checks (SPR_RECONSTRUCT_VALU=1 at build time selects it).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "rowtile.hpp"
 
 #ifndef SPR_RECONSTRUCT_VALU
@@ -127,6 +131,91 @@ int launch_mfma(const TU *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t ro
   return SPR_OK;
 }
 
+// Register-direct form for an f32-stored basis (BASELINE config 5): its rows carry half the bytes for the same MFMAs and the
+// same fixed cost per LDS panel, which held the panel form at 3.1 TB/s (133 KB of LDS per workgroup at r = 128: one
+// workgroup, four waves, per CU).  Here -- as in qr_refresh_direct_kernel -- lane (j = l & 15, kk = l >> 4) of a wave owns row
+// j of the wave's 16-row block and loads the 16-byte pieces [16 g + 4 kk, +4) of it straight into the MFMA B operand
+// (contraction index permuted accordingly, the coefficient fragments are permuted the same way once per kernel): no LDS,
+// no barrier, every wave independent, the next block requested before this one is multiplied.
+template <int NG, typename TU>
+__global__ __launch_bounds__(RM_THREADS) void reconstruct_direct_kernel(
+    const TU *__restrict__ Ur, int r, int64_t ldu, SegPlan plan, const double *__restrict__ rowmean,
+    const double *__restrict__ scale, const double *__restrict__ rowscale, const double *__restrict__ A, int64_t lda,
+    int np0, int npb, double *__restrict__ out, int64_t ldo, int accumulate) {
+  constexpr int R = 64;
+  using P4 = typename std::conditional<std::is_same<TU, float>::value, float4, double4>::type;
+  int f, wl, wpf, base;
+  int64_t lo, hi;
+  if (!seg_locate(plan, blockIdx.x, f, wl, wpf, base, lo, hi)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kk = lane >> 4;
+  const double sc = scale[f];
+  double vfrag[4 * NG];          // A[i = li][k]: vector np0 + li, entry 16 g + 4 kk + t at MFMA step 4 g + t
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vfrag[4 * g + t] = (li < npb) ? A[(int64_t)(np0 + li) * lda + 16 * g + 4 * kk + t] : 0.0;
+  const int64_t npanels = (hi - lo + R - 1) / R;
+  auto load_block = [&](int64_t c, P4 (&dst)[NG]) {
+    int64_t row = lo + c * R + wave * 16 + li;
+    row = row < hi ? row : hi - 1;                             // past the segment: a harmless re-read, never stored
+    const TU *rp = Ur + row * ldu + 4 * kk;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) dst[g] = *reinterpret_cast<const P4 *>(rp + 16 * g);
+  };
+  int64_t c = wl;
+  if (c >= npanels) return;
+  P4 cur[NG], nxt[NG];
+  load_block(c, cur);
+  while (c < npanels) {
+    const int64_t cn = c + wpf;
+    load_block(cn < npanels ? cn : c, nxt);
+    const int64_t row = lo + c * R + wave * 16 + li;           // the row this lane's results belong to
+    const int64_t rc = row < hi ? row : hi - 1;
+    const double mu = rowmean[rc];
+    const double rs = rowscale ? rowscale[rc] : sc;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const double b4[4] = {(double)cur[g].x, (double)cur[g].y, (double)cur[g].z, (double)cur[g].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vfrag[4 * g + t], b4[t], acc, 0, 0, 0);
+    }
+    const double d[4] = {acc.x, acc.y, acc.z, acc.w};          // D[i = kk + 4 q][j = li] = a_{np0+i} . u_row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pv = 4 * q + kk;
+      if (pv < npb && row < hi) {
+        double *o = out + (int64_t)(np0 + pv) * ldo + row;
+        *o = rs * d[q] + (accumulate ? *o : mu);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
+    c = cn;
+  }
+}
+
+template <int NG, typename TU>
+int launch_direct(const TU *Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0, int64_t n_points,
+                  int32_t n_features, const double *rowmean, const double *scale, const double *rowscale,
+                  const double *A, int64_t lda, int32_t n_p, double *out, int64_t ldo, int accumulate, hipStream_t st) {
+  const int cus = spr_cached_cus();
+  SegPlan plan;
+  plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
+  plan.total_wg = 4 * (cus > 0 ? cus : 256);                   // no LDS: registers decide (16 waves per CU)
+  plan.chunk_rows = 64;
+  const int grid = seg_total_wgs(plan);
+  for (int p0 = 0; p0 < n_p; p0 += RM_PB) {
+    const int npb = (n_p - p0 < RM_PB) ? n_p - p0 : RM_PB;
+    hipLaunchKernelGGL((reconstruct_direct_kernel<NG, TU>), dim3(grid), dim3(RM_THREADS), 0, st, Ur, (int)r, ldu, plan,
+                       rowmean, scale, rowscale, A, lda, p0, npb, out, ldo, accumulate);
+    SPR_LAUNCH_CHECK();
+  }
+  return SPR_OK;
+}
+
 constexpr int RC_THREADS = 256;
 constexpr int RC_UNR = 4;
 constexpr int RC_PB = 4;  // coefficient vectors handled per pass over Ur
@@ -220,6 +309,26 @@ int reconstruct_groups(const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, i
   for (int g0 = 0; g0 < r; g0 += SPR_MAX_R) {
     const int rg = (r - g0 < SPR_MAX_R) ? r - g0 : SPR_MAX_R;
     int rc = SPR_OK;
+    if constexpr (std::is_same<TU, float>::value) {
+      // f32 basis, whole 16-column groups, 16-byte aligned rows: the register-direct form (SPR_RECONSTRUCT_DIRECT=0: panels)
+      static const bool direct_on = [] { const char *e = getenv("SPR_RECONSTRUCT_DIRECT"); return !(e && e[0] == '0'); }();
+      if (direct_on && rg % 16 == 0 && (ldu * sizeof(TU)) % 16 == 0 && (reinterpret_cast<uintptr_t>(d_Ur + g0) & 15) == 0) {
+#define RDF(NGV) rc = launch_direct<NGV, TU>(d_Ur + g0, n_rows, rg, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A + g0, r, n_p, d_Xrec, ldo, g0 > 0, st); break
+        switch (rg / 16) {
+          case 1: RDF(1);
+          case 2: RDF(2);
+          case 3: RDF(3);
+          case 4: RDF(4);
+          case 5: RDF(5);
+          case 6: RDF(6);
+          case 7: RDF(7);
+          default: RDF(8);
+        }
+#undef RDF
+        if (rc != SPR_OK) return rc;
+        continue;
+      }
+    }
 #define RMF(MTV) rc = launch_mfma<MTV, TU>(d_Ur + g0, n_rows, rg, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A + g0, r, n_p, d_Xrec, ldo, g0 > 0, st); break
     switch (spr_round_mt(rg)) {      // padded width of the group in 16-column tiles
       case 1: RMF(1);

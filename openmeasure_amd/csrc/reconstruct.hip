@@ -309,9 +309,12 @@ int reconstruct_groups(const TU *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, i
   for (int g0 = 0; g0 < r; g0 += SPR_MAX_R) {
     const int rg = (r - g0 < SPR_MAX_R) ? r - g0 : SPR_MAX_R;
     int rc = SPR_OK;
-    if constexpr (std::is_same<TU, float>::value) {
-      // f32 basis, whole 16-column groups, 16-byte aligned rows: the register-direct form (SPR_RECONSTRUCT_DIRECT=0: panels)
-      static const bool direct_on = [] { const char *e = getenv("SPR_RECONSTRUCT_DIRECT"); return !(e && e[0] == '0'); }();
+    {
+      // whole 16-column groups, 16-byte aligned rows: the register-direct form for an f32 basis and for f64 bases wider than
+      // 96 columns (whose LDS panels leave room for one workgroup per CU only: 3.5 -> 2.8 ms at the c5s shape).
+      // SPR_RECONSTRUCT_DIRECT=0: panels everywhere; =3: direct everywhere (A/B switches)
+      static const int direct_mode = [] { const char *e = getenv("SPR_RECONSTRUCT_DIRECT"); return e ? atoi(e) : 1; }();
+      const bool direct_on = direct_mode == 3 || (direct_mode != 0 && (std::is_same<TU, float>::value || rg > 96));
       if (direct_on && rg % 16 == 0 && (ldu * sizeof(TU)) % 16 == 0 && (reinterpret_cast<uintptr_t>(d_Ur + g0) & 15) == 0) {
 #define RDF(NGV) rc = launch_direct<NGV, TU>(d_Ur + g0, n_rows, rg, ldu, row0, n_points, n_features, d_rowmean, d_scale, d_rowscale, d_A + g0, r, n_p, d_Xrec, ldo, g0 > 0, st); break
         switch (rg / 16) {

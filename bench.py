@@ -60,6 +60,8 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F64_PEAK_TF = 78.6     # AMD public spec for MI355X FP64 matrix; tools/mfma_probe measures 73.6 on the box
+HBM_MEASURED_GBS = 6290.0   # MI355X_MICROARCH.md chip table: float4 copy, 79 % of spec
+MFMA_F64_MEASURED_TF = 73.6 # tools/mfma_probe.hip: 64 cycles per v_mfma_f64_16x16x4_f64 and SIMD at the clock held under load
 
 
 def log(*a):
@@ -166,11 +168,24 @@ def launch_ranks(n, argv, env_extra=None, timeout=None, relay=sys.stdout, grace=
     return rc
 
 
-def count_gpus():
-    """AMD GPUs of this node WITHOUT touching the HIP runtime (the launcher parent must stay GPU-free: its children are
-    the only processes that may initialise the device): KFD topology nodes with a gfx target, else DRM render nodes.
-    None when neither is readable."""
+def _visible_limit(env=None):
+    """How many devices the visibility variables leave (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES,
+    comma-separated indices or UUIDs; an empty string hides every device).  None when none of them is set."""
+    env = os.environ if env is None else env
+    lim = None
+    for key in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if key in env:
+            k = len([t for t in env[key].split(',') if t.strip() != ''])
+            lim = k if lim is None else min(lim, k)
+    return lim
+
+
+def count_gpus(env=None):
+    """AMD GPUs THIS process's children can use, WITHOUT touching the HIP runtime (the launcher parent must stay GPU-free:
+    its children are the only processes that may initialise the device): KFD topology nodes with a gfx target, else the DRM
+    render nodes whose PCI vendor is AMD (0x1002), capped by the visibility variables.  None when nothing is readable."""
     import glob
+    k = None
     nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
     if nodes:
         k = 0
@@ -181,9 +196,37 @@ def count_gpus():
                 k += int(props.get('gfx_target_version', '0')) != 0
             except (OSError, ValueError):
                 pass
-        return k
-    rd = glob.glob('/dev/dri/renderD*')
-    return len(rd) if rd else None
+    else:
+        rd = glob.glob('/sys/class/drm/renderD*')
+        if rd:
+            k = 0
+            for p in rd:
+                try:
+                    with open(os.path.join(p, 'device', 'vendor')) as f:
+                        k += f.read().strip().lower() == '0x1002'
+                except OSError:
+                    pass
+    if k is None:
+        return None
+    lim = _visible_limit(env)
+    return k if lim is None else min(k, lim)
+
+
+def comm_summary(comm_main, comm_sync, dist_on, sync_gather, F, m, world, n_loc):
+    """The `comm` object of the JSON line from the mean bracket times (ms) of the headline loop and of the sync-gather loop
+    (ROM.comm_timing keys 'allreduce', 'gather', 'gather_exposed').  None = no such collective ran."""
+    src = comm_sync if comm_sync else comm_main
+    comm = dict(allreduce_ms=comm_main.get('allreduce'), gather_ms=src.get('gather'),
+                gather_exposed_ms=comm_main.get('gather_exposed', 0.0 if (dist_on and not sync_gather) else None),
+                allreduce_bytes=(F * m * m + world * F * 3) * 8 if dist_on else 0,
+                gather_bytes_per_rank=n_loc * 8 if dist_on else 0,
+                note=('mean per step over the timed steps; allreduce_ms: bracket around the call on the compute stream; '
+                      'gather_ms: issue to join in the sync-gather loop; gather_exposed_ms: the join of the pipelined loop '
+                      '(what did not hide under the next Gram pass)') if dist_on else 'no collectives at N = 1')
+    for k_ in ('allreduce_ms', 'gather_ms', 'gather_exposed_ms'):
+        if comm[k_] is not None:
+            comm[k_] = round(comm[k_], 4)
+    return comm
 
 
 def parse_args(argv=None):
@@ -196,9 +239,12 @@ def parse_args(argv=None):
     ap.add_argument('--scaling', default='auto', choices=('auto', 'weak', 'strong'),
                     help="auto = the workload's own mode (c4: strong, the others: weak)")
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline / parity leg')
-    ap.add_argument('--extra', action='store_true', help='also time placement/train/predict')
+    ap.add_argument('--extra', action='store_true',
+                    help='more lines: A/B of the row norms fit() leaves for the placement, reconstruct() with its '
+                         "reference output contract (host ndarray), upload rate of a host ndarray X")
     ap.add_argument('--sync-gather', action='store_true',
-                    help='join the field all-gather at the end of every step instead of overlapping it with the next Gram pass')
+                    help='the headline loop joins the field all-gather at the end of every step (default: it overlaps the '
+                         'next Gram pass; both forms are timed in every N > 1 run)')
     ap.add_argument('--share-of', type=int, default=0, metavar='N',
                     help="developer aid: run ONE rank's shard of an N-rank job on this GPU (collectives in a 1-rank RCCL "
                          'group); the line says so and is not an N-GPU number')
@@ -298,38 +344,62 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    dist_on = world > 1 or force_dist
     spr.fit(select_modes='number', n_modes=s)     # first call: allocations, RCCL warm-up
     a_d = eng.to_device(spr.Ar[:1].copy())        # (1, r) coefficient vector, resident
+    if dist_on:
+        spr.comm_timing = {}                      # event pairs around every collective (ROM.comm_timing)
 
     def done(f):
         return f.wait() if hasattr(f, 'wait') else f
 
-    def step(prev=None, timers=None):
-        if timers is not None:
-            timers.append((eng.time_next('stats_gram'), eng.time_next('project'), eng.time_next('reconstruct')))
-        spr.fit(select_modes='number', n_modes=s)
-        done(prev)                                # the previous field's all-gather ran under this fit: join it now
-        # field all-gather left in flight: it overlaps the next step's (MFMA-bound) Gram pass
-        return spr.reconstruct(a_d, to_host=False, wait=args.sync_gather)
+    def timed_loop(sync_gather):
+        """W warm-up steps, then K steps bracketed by barrier + device sync on both sides.  -> (seconds, max over ranks;
+        per-step kernel event triples; mean ms of every collective bracket; the last field)"""
+        def step(prev=None, timers=None):
+            if timers is not None:
+                timers.append((eng.time_next('stats_gram'), eng.time_next('project'), eng.time_next('reconstruct')))
+            spr.fit(select_modes='number', n_modes=s)
+            done(prev)                            # the previous field's all-gather ran under this fit: join it now
+            # default: the gather is left in flight and overlaps the next step's (MFMA-bound) Gram pass
+            return spr.reconstruct(a_d, to_host=False, wait=sync_gather)
 
-    field = None
-    for _ in range(args.warmup):
-        field = step(field)
-    done(field)
-    field = None
-    timers = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        field = step(field, timers)
-    field = done(field)                           # the last gather joins the compute stream inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1 or force_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        field = None
+        for _ in range(args.warmup):
+            field = step(field)
+        done(field)
+        field = None
+        timers = []
+        if dist_on:
+            spr.comm_timing.clear()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            field = step(field, timers)
+        field = done(field)                       # the last gather joins the compute stream inside the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            tt = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        comm = {}
+        if dist_on:
+            for key, pairs in spr.comm_timing.items():
+                comm[key] = float(np.mean([eng.elapsed_ms(e0, e1) for e0, e1 in pairs])) if pairs else None
+        return dt, timers, comm, field
+
+    dt, timers, comm_main, field = timed_loop(args.sync_gather)
+    dt_sync, comm_sync = None, {}
+    if dist_on and not args.sync_gather:
+        # the same K steps once more with the gather joined inside every step: what the pipelining hides, and the
+        # duration of the gather itself (its bracket closes behind the join)
+        dt_sync, _, comm_sync, _ = timed_loop(True)
     ms_per_step = 1e3 * dt / args.steps
+    # collectives, from event pairs on the stream each one is ordered on (ROM.comm_timing): the ONE all-reduce of fit(), the
+    # field all-gather of reconstruct() timed where it is joined inside the step, and what of it stays exposed when it is
+    # left in flight under the next Gram pass (the wait of the join).  None = no such collective ran (N = 1).
+    comm = comm_summary(comm_main, comm_sync, dist_on, args.sync_gather, F, m, world, n_loc)
     # never print a number for a run that computed garbage: spectrum, basis sample and field must be finite
     fld = field if torch.is_tensor(field) else None
     if not (np.all(np.isfinite(spr.S_[:s])) and bool(torch.isfinite(spr._d['Ur'][:4096].double()).all())
@@ -348,8 +418,19 @@ def run_rank(args):
         'project': dict(bytes=n_loc * m * B + n_loc * r * B, flops=2.0 * n_loc * m * r),
         'reconstruct': dict(bytes=n_loc * r * B + 2 * n_loc * 8, flops=2.0 * n_loc * r),
     }
-    phases = {k: dict(ms=round(k_ms[k], 4), GBs=round(alg[k]['bytes'] / k_ms[k] / 1e6, 1),
-                      TFLOPs=round(alg[k]['flops'] / k_ms[k] / 1e9, 3)) for k in k_ms}
+    def phase_of(k, ms):
+        """achieved rates of one kernel, its binding bound (the larger of t_bytes and t_flops at the SPEC peaks)
+        and the fraction of that bound's spec peak and of the peak measured on this chip"""
+        gbs, tfs = alg[k]['bytes'] / ms / 1e6, alg[k]['flops'] / ms / 1e9
+        mfma_bound = alg[k]['flops'] / (MFMA_F64_PEAK_TF * 1e12) > alg[k]['bytes'] / (HBM_PEAK_GBS * 1e9)
+        ach, spec, meas = (tfs, MFMA_F64_PEAK_TF, MFMA_F64_MEASURED_TF) if mfma_bound else (gbs, HBM_PEAK_GBS, HBM_MEASURED_GBS)
+        return dict(ms=round(ms, 4), GBs=round(gbs, 1), TFLOPs=round(tfs, 3), bound='mfma' if mfma_bound else 'hbm',
+                    frac_spec=round(ach / spec, 4), frac_measured_peak=round(ach / meas, 4),
+                    frac_hbm_spec=round(gbs / HBM_PEAK_GBS, 4), frac_mfma_spec=round(tfs / MFMA_F64_PEAK_TF, 4))
+
+    phases = {k: phase_of(k, k_ms[k]) for k in k_ms}
+    phases['peaks'] = dict(hbm_spec_GBs=HBM_PEAK_GBS, hbm_measured_GBs=HBM_MEASURED_GBS, mfma_f64_spec_TFLOPs=MFMA_F64_PEAK_TF,
+                           mfma_f64_measured_TFLOPs=MFMA_F64_MEASURED_TF)
 
     def roofline_of(kms):
         dom = max(kms, key=kms.get)
@@ -395,33 +476,50 @@ def run_rank(args):
     step_bytes = (2 * m + 2 * r) * float(n_job) * B + 24.0 * n_job
     hbm_frac = step_bytes / (dt / args.steps) / (world * HBM_PEAK_GBS * 1e9)
 
+    def timed3(fn):
+        """median wall time of three calls, each bracketed by barrier + device sync"""
+        ts = []
+        for _ in range(3):
+            barrier(); t_a = time.perf_counter()
+            fn()
+            barrier(); ts.append(time.perf_counter() - t_a)
+        return 1e3 * sorted(ts)[1]
+
+    # The rest of the path, in every run (SURVEY 8(d): "timed and reported as separate lines"): optimal_placement('qr'),
+    # train, predict.  Two untimed calls first: code objects, allocator growth and the interpreter's first full GC pass
+    # all land in the first two placements (tools/placement_probe.py: 180 / 105 / 55 / 55 / 55 ms at config 3)
+    spr.optimal_placement()
+    piv_first = spr.sensors_.copy()
+    spr.optimal_placement()
+    t_place = timed3(spr.optimal_placement)
+    assert np.array_equal(piv_first, spr.sensors_), 'pivots not reproducible run to run'
+    C = spr._placed[0]
+    spr.train(C)
+    t_train = timed3(lambda: spr.train(C))
+    rows = eng.to_device(spr.sensors_, dtype=torch.int64)
+    yv = eng.to_host(eng.synth_gather(rows, n_points, m, R, eps, seed))
+    y = np.zeros((s, 3)); y[:, 0] = yv; y[:, 2] = spr.sensors_ // n_points
+    spr.predict(y)
+    t_pred = timed3(lambda: spr.predict(y))
+    gap_min = float(spr.pivot_gap_.min())
+    f32_basis = f32
+    path = dict(optimal_placement_ms=round(t_place, 3), train_ms=round(t_train, 3), predict_ms=round(t_pred, 3),
+                pivot_sweeps=int(spr.pivot_sweeps_), pivot_pool_sweeps=int(spr.pivot_pool_sweeps_),
+                min_pivot_gap=gap_min, placement_from_row_norms=bool(spr.placement_from_norms_),
+                placement_GBs_of_basis=round(n_loc * r * B / t_place / 1e6, 1),
+                timing='median of 3 calls after 2 warm-up calls, barrier + device sync on both sides')
+    if f32_basis:
+        # f32-stored basis (config 5): the sensors are those of the STORED basis; every pick led its runner-up by at least
+        # min_pivot_gap (relative), to be read against the rounding of an f32 entry, 2^-24 = 6e-8.  Equality with the
+        # sensors of the f64 basis (the reference's) is CHECKED on the CPU-sized sample (parity.sensors_equal) and at full
+        # size INFERRED from this margin -- a property of the data's spectrum, not of the code.
+        path['min_pivot_gap_over_f32_rounding'] = round(gap_min / 2.0 ** -24, 1)
+        path['sensors_vs_f64_basis'] = 'inferred from min_pivot_gap at full size; checked exactly on the parity sample'
+
     extra = {}
     if args.extra:
-        def timed3(fn):
-            """median wall time of three calls, each bracketed by barrier + device sync"""
-            ts = []
-            for _ in range(3):
-                barrier(); t_a = time.perf_counter()
-                fn()
-                barrier(); ts.append(time.perf_counter() - t_a)
-            return 1e3 * sorted(ts)[1]
-        # two untimed calls first: code objects, allocator growth and the interpreter's first full GC pass all
-        # land in the first two placements (tools/placement_probe.py: 180 / 105 / 55 / 55 / 55 ms at config 3)
-        spr.optimal_placement()
-        piv_first = spr.sensors_.copy()
-        spr.optimal_placement()
-        t_place = timed3(spr.optimal_placement)
-        assert np.array_equal(piv_first, spr.sensors_), 'pivots not reproducible run to run'
-        C = spr._placed[0]
-        spr.train(C)
-        t_train = timed3(lambda: spr.train(C))
-        rows = eng.to_device(spr.sensors_, dtype=torch.int64)
-        yv = eng.to_host(eng.synth_gather(rows, n_points, m, R, eps, seed))
-        y = np.zeros((s, 3)); y[:, 0] = yv; y[:, 2] = spr.sensors_ // n_points
-        spr.predict(y)
-        t_pred = timed3(lambda: spr.predict(y))
-        extra = dict(optimal_placement_ms=round(t_place, 3), train_ms=round(t_train, 3), predict_ms=round(t_pred, 3),
-                     min_pivot_gap=float(spr.pivot_gap_.min()), pivot_sweeps=int(spr.pivot_sweeps_),
+        extra = dict(optimal_placement_ms=path['optimal_placement_ms'], train_ms=path['train_ms'],
+                     predict_ms=path['predict_ms'], min_pivot_gap=gap_min, pivot_sweeps=path['pivot_sweeps'],
                      timing='median of 3 calls after 2 warm-up calls')
         extra['placement_from_row_norms'] = bool(spr.placement_from_norms_)
         # A/B of ROM.placement_norms (the squared row norms fit() leaves for the placement): what the projection pays for
@@ -510,6 +608,13 @@ def run_rank(args):
             'config': {'workload': what, 'rows_per_gpu': n_loc, 'rows_total': n_job,
                        'snapshot_GB_per_gpu': round(n_loc * m * B / 1e9, 3), 'storage': 'f32' if f32 else 'f64'},
             'hbm_roofline_frac_step': round(hbm_frac, 4),
+            # the same K steps with the field all-gather joined inside every step (N > 1; at N = 1 there is no gather)
+            'ms_per_step_sync_gather': (round(1e3 * dt_sync / args.steps, 4) if dt_sync is not None
+                                        else round(ms_per_step, 4)),
+            'headline_loop': 'sync gather' if (args.sync_gather or not dist_on) else 'gather overlaps the next Gram pass',
+            'comm': comm,
+            'placement_ms': path['optimal_placement_ms'], 'train_ms': path['train_ms'], 'predict_ms': path['predict_ms'],
+            'pivot_sweeps': path['pivot_sweeps'], 'min_pivot_gap': path['min_pivot_gap'], 'path': path,
             **({'rehearsal': f'{backend} backend, all ranks on one GPU: exercises the code path, measures nothing'}
                if (backend != 'nccl' or os.environ.get('SPR_BENCH_ONE_GPU') == '1') else {}),
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,

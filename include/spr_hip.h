@@ -44,6 +44,11 @@ extern "C" {
 #define SPR_MAX_R 128        /* retained modes / sensors ONE launch handles; callers go in column groups beyond      */
 #define SPR_MAX_R_WIDE 1024  /* ... the widest basis the placement / solve kernels accept (r <= m in the reference, :336) */
 
+/* Bumped whenever an entry point changes its argument list or meaning (round 3 -> 4: spr_qr_steps_f64 gained
+ * first_exact, the keep-alive and layout entry points arrived).  A binding written for another value must refuse to
+ * call into this library: openmeasure_amd/_lib.py compares spr_abi_version() with the value its prototypes were
+ * written for. */
+#define SPR_ABI_VERSION 2
 int spr_abi_version(void);
 const char *spr_last_error(void);
 /* number of compute units of the current device (used to size persistent grids) */
@@ -54,6 +59,17 @@ int spr_device_cus(int *out_cus);
  * (sparse_sensing.py:272-279), X_scl per feature (:115), the coefficient vectors of reconstruct (:371) -- to
  * the device.  The source may be rewritten once work queued after this call on the stream has completed. */
 int spr_upload_bytes(void *d_dst, const void *h_pinned_src, int64_t n_bytes, void *stream);
+/* Clock keep-alive for the host gap of fit() (csrc/keepalive.hip): between the Gram pass and the projection the host
+ * eigen-solves the m x m Gram matrix -- the reference's np.linalg.svd call site (sparse_sensing.py:272) -- and the idle
+ * device drops its clock, which the projection then pays for (tools/idle_gap_probe.py).  One workgroup per CU issues
+ * v_mfma_f64 (mode & 1), streams d_stream_src round and round (mode & 2) and stages what it streams through LDS like
+ * the Gram kernel does (mode & 8; mode & 4: a resident but sleeping grid, diagnostic) until the HOST stores a
+ * value >= `generation` into the page-locked word h_pinned_flag, or until max_ms (clamped to 20 ms) have passed --
+ * whichever comes first: the grid always drains.  d_flag is a device word the library relays the host's value through
+ * (initialise it once to 0; generations must increase from call to call); d_sink one writable double.  Work queued on
+ * `stream` behind this call starts when the kernel has left. */
+int spr_keepalive_start(const int32_t *h_pinned_flag, int32_t *d_flag, int32_t generation, double max_ms, int32_t mode,
+                        const double *d_stream_src, int64_t stream_elems, double *d_sink, void *stream);
 
 /* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
  * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised

@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SPR_HIP_LIBRARY: load another build of the same library (the ASan host build of `make asan`, tests only)
 LIB_PATH = os.environ.get('SPR_HIP_LIBRARY') or os.path.join(_HERE, 'libspr_hip.so')
 
+SPR_ABI_VERSION = 2          # include/spr_hip.h: the value these prototypes were written for
 SPR_MAX_M = 256
 SPR_MAX_M_WIDE = 512
 SPR_MAX_R = 128
@@ -34,6 +35,7 @@ PROTOTYPES = {
     'spr_last_error': (C.c_char_p, []),
     'spr_device_cus': (C.c_int, [C.POINTER(C.c_int)]),
     'spr_upload_bytes': (C.c_int, [_p, _p, _i64, _p]),
+    'spr_keepalive_start': (C.c_int, [_p, _p, _i32, _dbl, _i32, _p, _i64, _p, _p]),
     'spr_stats_gram_workspace': (_sz, [_i32, _i32]),
     'spr_stats_gram_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),
     'spr_stats_gram_finalize_f64': (C.c_int, [_i64, _i32, _i64, _i64, _i32, _p, _sz, _p, _p, _i32, _i32, _p]),
@@ -133,6 +135,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
+    have = lib.spr_abi_version()
+    if have != SPR_ABI_VERSION:
+        # a changed argument list under an unchanged name would pass shifted arguments -- wild pointers on the GPU
+        raise RuntimeError(f'{LIB_PATH} reports ABI version {have}, this binding was written for {SPR_ABI_VERSION}: '
+                           'rebuild the library (make -C openmeasure_amd/csrc) or use the matching package')
     _lib = lib
     return lib
 

@@ -1,0 +1,124 @@
+// Clock keep-alive for the host gap of fit().
+//
+// Between the Gram pass and the projection the device has nothing to do: the host downloads the m x m Gram matrix and
+// eigen-solves it (2.7 ms at m = 256, the reference's np.linalg.svd call site, sparse_sensing.py:272).  The chip lowers
+// its clock within a millisecond of idling and raises it again over several milliseconds, so the projection that follows
+// a 3 ms gap runs 10 % slower than one launched back to back (tools/idle_gap_probe.py), which is 0.6 ms of a 7 ms kernel on
+// one rank's block of BASELINE config 4.  This kernel keeps the matrix pipes (and, optionally, the memory fabric) loaded
+// while the host works and leaves as soon as the host says so.
+//
+// Exit conditions, every wave reaches one of them:
+//   * the host wrote a generation number >= `gen` into the pinned flag word (relayed through a device word so that only
+//     ONE wave polls host memory over PCIe; all others poll the device word, L2-served);
+//   * the constant 100 MHz clock (s_memrealtime) has advanced by more than max_ticks since the wave started -- a hard
+//     bound the host cannot forget to release (the entry point clamps it to 20 ms).
+#include "common.hpp"
+
+namespace {
+
+constexpr int KA_THREADS = 512;          // two waves per SIMD, like the Gram and projection kernels
+constexpr int KA_LDS = 8192;             // doubles: 64 KB, a private 8 KB region per wave
+
+// mode bits: 1 = v_mfma_f64 on the operands, 2 = stream `src` (16-byte loads, a window per workgroup, round and round),
+// 4 = nothing but s_sleep (diagnostic: a resident but idle grid), 8 = stage the streamed pieces through LDS and read the MFMA
+// operands back from there (ds_write_b128 / ds_read_b64, the mix of the Gram kernel).  Measured on one rank's block of
+// config 4 at N = 8 with a 3 ms gap (tools/keepalive_probe.py): kernels behind an idle gap 19.9 ms, behind mode 1 19.3,
+// mode 3 19.1, behind a real Gram launch as the filler 18.9, back to back 18.6.
+__global__ __launch_bounds__(KA_THREADS) void keepalive_kernel(const int *__restrict__ host_flag, int *__restrict__ dev_flag,
+                                                               int gen, uint64_t max_ticks, int mode,
+                                                               const double *__restrict__ src, int64_t src_elems,
+                                                               double *__restrict__ sink) {
+  __shared__ double lds[KA_LDS];
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  const bool poller = (blockIdx.x == 0) && (threadIdx.x == 0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *wl = lds + wave * (KA_LDS / (KA_THREADS / 64));            // this wave's 1024 doubles
+  // operands with full-width random mantissas: what the matrix pipes draw depends on the data (near-constant operands made
+  // a first version of this kernel a light load that did not hold the clock; tools/keepalive_probe.py)
+  auto rnd = [](uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    uint64_t h = (uint64_t)x * 0x9E3779B97F4A7C15ULL;
+    h ^= h >> 29;
+    const uint64_t bits = (h & 0x800FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;   // +-[1, 2)
+    return __longlong_as_double((long long)bits);
+  };
+  const uint32_t tid = blockIdx.x * KA_THREADS + threadIdx.x;
+  for (int i = lane; i < KA_LDS / (KA_THREADS / 64); i += 64) wl[i] = rnd(tid * 2048u + i);
+  f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  double a = rnd(tid * 4u + 1u), b = rnd(tid * 4u + 2u), c2 = rnd(tid * 4u + 3u), d2 = rnd(tid * 4u);
+  double s = 0.0;
+  const int64_t win = src_elems / (gridDim.x > 0 ? gridDim.x : 1);
+  const bool streaming = (mode & 2) && win >= 2 * KA_THREADS * 8;
+  const double *wp = src + (int64_t)blockIdx.x * win;
+  int64_t pos = threadIdx.x * 2;
+  for (;;) {
+    f64x2 v[8];
+    if (streaming) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(wp + pos));
+        pos += 2 * KA_THREADS;
+        if (pos + 2 > win) pos = threadIdx.x * 2;
+      }
+    }
+    if (mode & 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (mode & 8) {                                    // operands from LDS, as the Gram kernel reads its fragments
+          a = wl[(16 * i + lane) & 1023];
+          b = wl[(16 * i + 512 + lane) & 1023];
+        }
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c2, d2, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, c2, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(d2, a, acc3, 0, 0, 0);
+      }
+    } else if (mode & 4) {
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (streaming) {
+      if (mode & 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f64x2 *>(wl + ((2 * lane + 128 * i) & 1023)) = v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y;
+      }
+    }
+    int seen;
+    if (poller) {
+      seen = __hip_atomic_load(host_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seen - gen >= 0) __hip_atomic_store(dev_flag, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      seen = __hip_atomic_load(dev_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    seen = __builtin_amdgcn_readfirstlane(seen);
+    if (seen - gen >= 0) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) {
+      // the bound: also tell the others, so that the grid drains together
+      if (poller) __hip_atomic_store(dev_flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  // results nobody reads: keep the arithmetic alive without writing in the common case
+  const double t = acc0.x + acc1.y + acc2.z + acc3.w + s + wl[lane];
+  if (t == 123.456789) sink[0] = t;
+}
+
+}  // namespace
+
+extern "C" int spr_keepalive_start(const int32_t *h_pinned_flag, int32_t *d_flag, int32_t generation, double max_ms,
+                                   int32_t mode, const double *d_stream_src, int64_t stream_elems, double *d_sink,
+                                   void *stream) {
+  SPR_REQUIRE(h_pinned_flag && d_flag && d_sink, SPR_E_INVALID, "spr_keepalive_start: NULL pointer");
+  SPR_REQUIRE(max_ms > 0.0, SPR_E_INVALID, "spr_keepalive_start: max_ms must be positive");
+  SPR_REQUIRE(!(mode & 2) || (d_stream_src && stream_elems > 0), SPR_E_INVALID,
+              "spr_keepalive_start: mode 2 needs a buffer to stream");
+  if (max_ms > 20.0) max_ms = 20.0;                       // never hold the device for longer, whatever the caller asks
+  const int cus = spr_cached_cus();
+  const int grid = cus > 0 ? cus : 256;
+  hipLaunchKernelGGL(keepalive_kernel, dim3(grid), dim3(KA_THREADS), 0, static_cast<hipStream_t>(stream), h_pinned_flag,
+                     d_flag, generation, (uint64_t)(max_ms * 1e5), mode, d_stream_src, stream_elems, d_sink);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}

@@ -25,7 +25,7 @@ int spr_cached_cus() {
   return cus;
 }
 
-extern "C" int spr_abi_version(void) { return 1; }
+extern "C" int spr_abi_version(void) { return SPR_ABI_VERSION; }
 
 extern "C" const char *spr_last_error(void) { return g_err; }
 

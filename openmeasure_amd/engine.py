@@ -41,6 +41,7 @@ class HipEngine:
         self._force_stream = os.environ.get('SPR_PROJECT_STREAM') == '1'   # A/B runs: streamed-W projection for every shape
         self._stage = None                                   # ring of pinned host staging buffers for small uploads
         self._dstage = None                                  # pinned landing buffer for small downloads
+        self._ka = None                                      # keep-alive state (keepalive_start / keepalive_stop)
 
     # ---- plumbing ---------------------------------------------------------------------
     def _stream(self):
@@ -90,8 +91,9 @@ class HipEngine:
 
     _HOST_STAGE_BYTES = 64 << 20
 
-    def to_host(self, t):
-        """Device tensor -> fresh host ndarray.  Results up to 64 MiB (statistics, Gram blocks, flags, Theta,
+    def to_host(self, t, then=None):
+        """Device tensor -> fresh host ndarray.  ``then``: called after the copy has been ENQUEUED and before the host
+        blocks on it -- work it launches queues up behind the copy (fit()'s gap filler).  Results up to 64 MiB (statistics, Gram blocks, flags, Theta,
         coefficient vectors) come back through a pinned buffer: a D2H copy into pageable memory in the middle of
         fit() left the compute queue stalled for 10/20/30 ms in every other call at config 3 (tools/fit_probe.py:
         gap between the Gram and projection kernels 3.9 ms with the pinned target, 4-37 ms without)."""
@@ -99,7 +101,10 @@ class HipEngine:
         t = t.detach()
         nbytes = t.numel() * t.element_size()
         if nbytes == 0 or nbytes > self._HOST_STAGE_BYTES or not t.is_cuda:
-            return t.cpu().numpy()
+            out = t.cpu().numpy()
+            if then is not None:
+                then()
+            return out
         if self._dstage is None or self._dstage.numel() < nbytes:
             self._dstage = None
             self._dstage = torch.empty(max(1 << 20, -(-nbytes // (1 << 20)) << 20), dtype=torch.uint8, pin_memory=True)
@@ -107,8 +112,49 @@ class HipEngine:
         buf = self._dstage[:nbytes].view(t.dtype).view(t.shape)
         buf.copy_(t, non_blocking=True)
         self._dstage_ev.record(torch.cuda.current_stream(self.device))
+        if then is not None:
+            then()
         self._dstage_ev.synchronize()
         return buf.numpy().copy()
+
+    # ---- clock keep-alive for the host gap of fit() (csrc/keepalive.hip) ---------------------------------
+    def keepalive_start(self, mode=1, max_ms=8.0, stream_src=None):
+        """Keep the matrix pipes (mode & 1) and / or the memory fabric (mode & 2, needs `stream_src`: any float64 device
+        tensor to read round and round) busy on the current stream until keepalive_stop() -- or max_ms, whichever
+        comes first: the kernel always leaves by itself.  Work enqueued afterwards starts when it has left."""
+        torch = self.torch
+        if self._ka is None:
+            flag = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            self._ka = dict(flag=flag, flag_np=flag.numpy(), dflag=self.zeros((1,), dtype=torch.int32),
+                            sink=self.zeros((1,)), gen=0, live=False)
+        ka = self._ka
+        ka['gen'] += 1
+        src_p, elems = (None, 0)
+        if mode & 2:
+            if stream_src is None or stream_src.dtype != torch.float64 or not stream_src.is_contiguous():
+                raise ValueError('keepalive_start(mode & 2) needs a contiguous float64 device tensor to stream')
+            src_p, elems = stream_src.data_ptr(), stream_src.numel()
+        _lib.check(self.lib.spr_keepalive_start(ka['flag'].data_ptr(), ka['dflag'].data_ptr(), ka['gen'], float(max_ms),
+                                                int(mode), src_p, elems, ka['sink'].data_ptr(), self._stream()),
+                   'spr_keepalive_start')
+        ka['live'] = True
+
+    def keepalive_stop(self):
+        """Release the keep-alive kernel (a plain store into the page-locked flag word it polls); idempotent."""
+        ka = self._ka
+        if ka is not None and ka['live']:
+            ka['flag_np'][0] = ka['gen']
+            ka['live'] = False
+
+    def timing_event(self):
+        """An event recorded NOW on the current stream; pairs are read with elapsed_ms() after a synchronisation."""
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return ev
+
+    @staticmethod
+    def elapsed_ms(e0, e1):
+        return e0.elapsed_time(e1)
 
     def _workspace(self, key, nbytes):
         cur = self._ws.get(key)
@@ -263,6 +309,20 @@ class HipEngine:
             fstats.zero_()
         toc()
         return rowmean, fstats, gram
+
+    def gram_filler(self, X, rows, row0, n_points, n_features):
+        """The Gram pass once more over the first `rows` rows of X, results discarded: real work of the real kernel, queued
+        into the host gap of fit() so that the chip does not drop its clock while the host eigen-solves (see
+        ROM.gap_filler).  Uses the Gram workspace (its slabs have been consumed by the finalize call in front) and a
+        scratch vector for the row means."""
+        n, m, ld = self._check_matrix(X)
+        rows = int(min(rows, n))
+        if rows <= 0 or m > _lib.SPR_MAX_M:
+            return
+        scratch = self._workspace('fillmean', rows * 8)
+        ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(m, n_features))
+        _lib.check(self._x('spr_stats_gram', X)(_ptr(X), rows, m, ld, row0, n_points, n_features, 1, scratch.data_ptr(),
+                                               _ptr(ws), ws.numel(), self._stream()), 'spr_stats_gram_f64')
 
     # ---- K3b: device-side spectrum (m <= 64) ------------------------------------------------------
     SCALE_CODES = {'std': 0, 'none': 1, 'pareto': 2, 'vast': 3, 'level': 4, 'variance': 5, 'poisson': 6, 'l2-norm': 7}

@@ -253,20 +253,28 @@ class PendingField:
     ranks may still be in flight on the communication stream.  ``wait()`` makes the current stream wait for it and
     returns the tensor; nothing else may read the tensor before that."""
 
-    def __init__(self, tensor, works=(), keep=()):
+    def __init__(self, tensor, works=(), keep=(), on_wait=None):
         self._tensor = tensor
         self._works = list(works)
         self._keep = keep                      # the gather's source buffers stay alive until it has been joined
+        self._on_wait = on_wait                # ROM.comm_timing: brackets the join with two stream events
 
     @property
     def shape(self):
         return tuple(self._tensor.shape)
 
     def wait(self):
-        for w in self._works:
-            w.wait()
+        if self._works and self._on_wait is not None:
+            done = self._on_wait()
+            for w in self._works:
+                w.wait()
+            done()
+        else:
+            for w in self._works:
+                w.wait()
         self._works = []
         self._keep = ()
+        self._on_wait = None
         return self._tensor
 
 
@@ -325,14 +333,66 @@ def _one_blas_thread():
 def _eigh_small(G):
     """All eigenpairs of the symmetric (m, m) matrix G (ascending): LAPACK dsyevd called directly on one BLAS thread --
     2.65 ms at m = 256 on the GPU host against 3.0 ms through np.linalg.eigh (and 4 ms / 95 ms at m = 256 / 512 with the
-    host's default 128-thread pool).  A route that computes only the r retained eigenvectors (dsytrd + dstemr + dormqr)
-    was tried in round 3 and dropped: 4.75 ms on that host, slower than dsyevd on everything."""
+    host's default 128-thread pool)."""
     from scipy.linalg import lapack
     with _one_blas_thread():
         w, v, info = lapack.dsyevd(np.asarray(G, dtype=np.float64).T, compute_v=1, lower=1)   # G.T: Fortran view, no copy
     if info != 0:
         raise np.linalg.LinAlgError('Eigenvalues did not converge')
     return w, v
+
+
+_EIGH_TOP_MIN_M = 96           # below this dsyevd is a fraction of a millisecond: nothing to gain
+_LWORK = {}
+
+
+def _eigh_tridiagonal(G):
+    """First half of the top-r route: G = Q T Q^T (dsytrd) and ALL eigenvalues of T (dsterf, ascending).
+    -> (lam, factorisation) ; raises LinAlgError like _eigh_small."""
+    from scipy.linalg import lapack
+    m = G.shape[0]
+    with _one_blas_thread():
+        lw = _LWORK.get(('trd', m))
+        if lw is None:
+            lw = _LWORK[('trd', m)] = int(lapack.dsytrd_lwork(m, lower=1)[0])
+        c, d, e, tau, info = lapack.dsytrd(np.asarray(G, dtype=np.float64).T, lower=1, lwork=lw)
+        if info == 0:
+            lam, info = lapack.dsterf(d, e)
+    if info != 0:
+        raise np.linalg.LinAlgError('Eigenvalues did not converge')
+    return lam, (c, d, e, tau)
+
+
+def _eigvecs_top(fac, lam, r):
+    """Second half: eigenvectors of the r LARGEST eigenvalues only -- inverse iteration on the tridiagonal matrix (dstein,
+    with its re-orthogonalisation inside clusters) and back-transformation of those r vectors (dormqr on the reflectors
+    dsytrd left below the sub-diagonal).  O(m^2 r) instead of dsyevd's O(m^3): 0.6 + 0.4 + ~0.5 + 0.2 ms against 2.65 ms
+    at m = 256, r = 64 on the GPU host (tools/eigh_pieces_probe.py).  -> V (m, r), columns in DESCENDING order of
+    eigenvalue, or None when dstein reports a failure or the vectors are not orthonormal to 1e-12 (the caller then
+    takes dsyevd)."""
+    from scipy.linalg import lapack
+    c, d, e, tau = fac
+    m = d.shape[0]
+    w = np.ascontiguousarray(lam[m - r:])
+    iblock = np.ones(m, dtype=np.int32)
+    isplit = np.zeros(m, dtype=np.int32)
+    isplit[0] = m
+    with _one_blas_thread():
+        z, info = lapack.dstein(d, e, w, iblock, isplit)
+        if info != 0:
+            return None
+        Z = np.asfortranarray(z[:, :r])
+        cq = np.asfortranarray(c[1:, :m - 1])
+        lw = _LWORK.get(('mqr', m, r))
+        if lw is None:
+            lw = _LWORK[('mqr', m, r)] = int(lapack.dormqr('L', 'N', cq, tau, np.asfortranarray(Z[1:]), lwork=-1)[1][0])
+        out, _, info = lapack.dormqr('L', 'N', cq, tau, np.asfortranarray(Z[1:]), lwork=lw)
+        if info != 0:
+            return None
+        V = np.ascontiguousarray(np.vstack([Z[:1], out])[:, ::-1])      # contiguous first: the check below then runs in BLAS
+        if not np.all(np.isfinite(V)) or np.abs(V.T @ V - np.eye(r)).max() > 1e-12:
+            return None
+    return V
 
 
 _POOL_FRACTION = 1.0 / 16       # share of the rows a pool sweep visits
@@ -499,6 +559,36 @@ class ROM:
     #: and the streamed-W kernel: every BASELINE shape but config 1/2); True: always (m <= 256 shapes outside the
     #: W-stationary kernel's range then run the streamed-W kernel); False (ROM, whose users never place sensors): never.
     placement_norms = False
+
+    #: Gap filler.  Between the Gram pass and the projection the device waits for the host (download of the m x m Gram
+    #: matrix, eigen-solve, upload of W: 3.6 ms at m = 256), and a chip that idles for a few milliseconds lowers its clock
+    #: and takes several more to raise it again: the kernels of a fit() + reconstruct() step on one rank's block of
+    #: BASELINE config 4 at N = 8 take 19.9 ms behind such a gap against 18.6 ms back to back (tools/keepalive_probe.py).
+    #: With the filler on, fit() queues the Gram kernel ONCE MORE over the first rows of X, sized to 85 % of the shortest
+    #: host gap of the last fits, before it blocks on the download; the results are discarded.  It costs energy, not time:
+    #: the device has nothing else to do, and the projection never waits for more than the filler overshoots.  Only for
+    #: m >= 128 (shorter eigen-solves leave no gap worth filling); SPR_GAP_FILLER=0 or ``rom.gap_filler = False`` turns it off.
+    gap_filler = True
+    _GAP_FILL_FRACTION = 0.85
+    _GAP_FILL_MIN_M = 128
+
+    #: Collective timing (bench.py): set to a dict and every collective of fit() / reconstruct() appends a pair of
+    #: engine timing events (recorded on the stream the collective is ordered on) under 'allreduce' (the ONE all-reduce
+    #: of fit), 'gather' (reconstruct's field all-gather when it is joined inside the call) or 'gather_exposed' (the
+    #: join of a gather that was left in flight, PendingField.wait(): what of it did NOT hide under the next pass).
+    comm_timing = None
+
+    def _comm_bracket(self, key):
+        """-> a function that closes the bracket opened now (no-op when comm_timing is off)."""
+        ct = self.comm_timing
+        eng = self._engine()
+        if ct is None or not hasattr(eng, 'timing_event'):
+            return lambda: None
+        e0 = eng.timing_event()
+
+        def close():
+            ct.setdefault(key, []).append((e0, eng.timing_event()))
+        return close
 
     def __getattr__(self, name):
         # only reached when normal lookup fails: results of the sync-free device fit (m <= 64) stay in HBM
@@ -744,18 +834,66 @@ class ROM:
         Returns rowmean (n_local,), gram (F, m, m) summed over ranks, fstats_all (world, F, 3)."""
         eng = self._engine()
         F, m = self.n_features, Xd.shape[1]
+        fill = self._filler_wanted(Xd)
+        e0 = eng.timing_event() if fill else None
         if not self._dist():
             rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+            if fill:
+                self._gram_events = (e0, eng.timing_event())
             self._trace.mark('stats_gram')
             return rowmean, gram, fstats[None]
         world, rank = self._world(), self._shard.rank
         buf = eng.zeros((F * m * m + world * F * 3,))
         rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+        if fill:
+            self._gram_events = (e0, eng.timing_event())
         self._trace.mark('stats_gram')
         buf[:F * m * m].copy_(gram.reshape(-1))
         buf[F * m * m + rank * F * 3:F * m * m + (rank + 1) * F * 3].copy_(fstats.reshape(-1))
+        close = self._comm_bracket('allreduce')
         self._all_reduce(buf)
+        close()
         return rowmean, buf[:F * m * m].view(F, m, m), buf[F * m * m:].view(world, F, 3)
+
+    def _filler_wanted(self, Xd):
+        import os
+        eng = self._engine()
+        tr = self.__dict__.get('_trace')
+        return bool(self.gap_filler and hasattr(eng, 'gram_filler') and self._GAP_FILL_MIN_M <= Xd.shape[1] <= 256
+                    and os.environ.get('SPR_GAP_FILLER', '1') != '0'
+                    and not (tr is not None and tr.on))        # SPR_TRACE synchronises at every mark: its gaps are not fit()'s
+
+    def _queue_gap_filler(self, Xd):
+        """Called between the enqueue of the Gram download and the host's wait for it (see gap_filler)."""
+        eng = self._engine()
+        hist = self.__dict__.get('_gap_hist')
+        ev = self.__dict__.pop('_gram_events', None)
+        rate = self.__dict__.get('_gram_rows_per_ms')
+        self._gap_fill_rows = 0
+        if hist and rate:
+            rows = int(self._GAP_FILL_FRACTION * min(hist) * rate) // 4096 * 4096
+            rows = min(rows, Xd.shape[0])
+            if rows >= 65536:
+                eng.gram_filler(Xd, rows, self._row0, self.n_points, self.n_features)
+                self._gap_fill_rows = rows
+        self._gram_events_pending = ev
+
+    def _close_gap(self):
+        """The projection is about to be launched: record the host gap this fit() had, and the rate of its Gram pass."""
+        t0 = self.__dict__.pop('_gap_t0', None)
+        if t0 is None:
+            return
+        import time
+        from collections import deque
+        eng = self._engine()
+        gap_ms = 1e3 * (time.perf_counter() - t0)
+        hist = self.__dict__.setdefault('_gap_hist', deque(maxlen=8))
+        hist.append(gap_ms)
+        ev = self.__dict__.pop('_gram_events_pending', None)
+        if ev is not None:
+            ms = eng.elapsed_ms(*ev)                     # both events lie in front of the download the host has waited for
+            if ms > 0:
+                self._gram_rows_per_ms = self._Xd().shape[0] / ms
 
     def _merge_stats(self, gram, fs_d, rowmean, scale_type, axis_cnt):
         """Per-feature Gram blocks (all-reduced) + per-rank feature statistics -> X_scl per feature and the Gram matrix
@@ -769,7 +907,12 @@ class ROM:
             # statistics merge, feature scales and G = sum_f G_f / scl_f^2 on the device (csrc/combine.hip): one
             # download of m^2 + 5F doubles, the scales never leave HBM
             packed_d, scale_d, inv_d = eng.gram_combine(gram, fs_d, scale_type)
-            packed = eng.to_host(packed_d)
+            if self._filler_wanted(Xd) and getattr(self, '_fit_fills_gap', False):
+                packed = eng.to_host(packed_d, then=lambda: self._queue_gap_filler(Xd))
+                import time
+                self._gap_t0 = time.perf_counter()
+            else:
+                packed = eng.to_host(packed_d)
             tr_.mark('collect')
             feat = packed[m * m:].reshape(F, 5)
             self._G = packed[:m * m].reshape(m, m)
@@ -960,11 +1103,26 @@ class ROM:
         lam_pos = np.maximum(lam, 0.0)
         return 100 * np.cumsum(lam_pos) / np.sum(lam_pos)      # :274-275
 
-    def _spectrum(self, G):
-        """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275)."""
+    def _spectrum(self, G, rank_of=None):
+        """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275).
+        ``rank_of(exp_variance) -> r``: the caller only needs the r leading vectors -- V then has r columns whenever
+        the top-r route applies (m >= 96, r <= m/2, sigma_1/sigma_r within the plain Gram route's range: the
+        refinement pass needs all of V) and all m otherwise."""
         if not np.all(np.isfinite(G)):
             # a constant feature (X_scl = 0 -> X0 = nan/inf, :169) or a NaN/Inf in X: np.linalg.svd(X0) (:272) raises
             raise np.linalg.LinAlgError('SVD did not converge')
+        m = G.shape[0]
+        if rank_of is not None and m >= _EIGH_TOP_MIN_M:
+            lam_a, fac = _eigh_tridiagonal(G)
+            lam = lam_a[::-1]
+            S = np.sqrt(np.maximum(lam, 0.0))
+            expv = self._expvar(lam)
+            r = rank_of(expv)
+            if 2 * r <= m and np.isfinite(S[0]) and not S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
+                V = _eigvecs_top(fac, lam_a, r)
+                if V is not None:
+                    lam, V = self._same_on_all_ranks(lam.copy(), V)
+                    return np.sqrt(np.maximum(lam, 0.0)), _sign_fix(V), self._expvar(lam)
         lam, V = _eigh_small(G)
         lam, V = self._same_on_all_ranks(lam, V)
         lam = lam[::-1]
@@ -1034,7 +1192,7 @@ class ROM:
         eng = self._engine()
         Xd = self._Xd()
         m = Xd.shape[1]
-        S, V, exp_variance = self._spectrum(G)
+        S, V, exp_variance = self._spectrum(G, lambda ev: self._select_rank(ev, m, select_modes, n_modes))
         self._trace.mark('eigh')
         r = self._select_rank(exp_variance, m, select_modes, n_modes)
         self.gram_refine_passes_ = 0
@@ -1054,6 +1212,7 @@ class ROM:
         self.precentered_ = bool(center and self._needs_precenter(S[0] / S_safe[-1]))
         nrm0 = self._norms_buffer(Xd, r, self.precentered_ and center)
         kw = {} if nrm0 is None else {'norms': nrm0}
+        self._close_gap()
         Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, W_d,
                            center=center, out=self._d.pop('Ur', None), rowmean=self._d.get('rowmean'),
                            basis_dtype=self._basis_dtype(), precenter=self.precentered_, **kw)
@@ -1080,8 +1239,8 @@ class ROM:
             _, _, gram = eng.stats_gram(X0d, 0, X0d.shape[0], 1, center=False)
             G = eng.to_host(self._all_reduce(gram))[0]
             ones = eng.to_device(np.ones(1))
-            S, V, exp_variance = self._spectrum(G)
             m = X0d.shape[1]
+            S, V, exp_variance = self._spectrum(G, lambda ev: self._select_rank(ev, m, select_modes, n_modes))
             r = self._select_rank(exp_variance, m, select_modes, n_modes)
             floor = S[0] * np.sqrt(m * np.finfo(float).eps)
             if S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
@@ -1112,7 +1271,11 @@ class ROM:
         if took is True:
             return
         if took != 'merged':                                  # 'merged': the device route left its statistics behind
-            self._stats_pass(scale_type, axis_cnt)
+            self._fit_fills_gap = basis is None               # the host eigen-solve follows: see gap_filler
+            try:
+                self._stats_pass(scale_type, axis_cnt)
+            finally:
+                self._fit_fills_gap = False
         self._host.clear()
         if basis is None:
             Ur_d, Ar, expv, S, r, V_r = self._basis_from_gram(self._G, select_modes, n_modes, True, self._d['inv_scale'])
@@ -1228,15 +1391,19 @@ class ROM:
             # ONE all-gather for all n_p columns: rank q's (n_p, n_loc) block lands at stage[q]; for one column that is
             # the field itself, for several the columns are put side by side afterwards (a device-side permute)
             stage = eng.empty((world, n_p, n_loc))
+            close = self._comm_bracket('gather')              # issue -> join, when the join happens inside this call
             work = dist.all_gather_into_tensor(stage.view(-1), loc.contiguous().view(-1), group=self._shard.group,
                                                async_op=True)
             if n_p == 1:
                 out = stage.view(1, world * n_loc)
                 if not to_host and not wait:
-                    return PendingField(out, [work], keep=(loc, stage))
+                    return PendingField(out, [work], keep=(loc, stage),
+                                        on_wait=lambda: self._comm_bracket('gather_exposed'))
                 work.wait()
+                close()
             else:
                 work.wait()
+                close()
                 out = stage.permute(1, 0, 2).reshape(n_p, world * n_loc)
                 if not to_host and not wait:
                     return PendingField(out)

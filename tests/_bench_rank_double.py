@@ -56,13 +56,35 @@ def main():
     X = make_X(plan['n_glob'], wl['m'], wl['features'])
     Xl = np.ascontiguousarray(X[plan['row0']:plan['row0'] + plan['n_loc']])
     spr = SPR(Xl, wl['features'], None, shard=RowShard(plan['row0'], plan['n_glob']), engine=NumpyEngine())
+    spr.comm_timing = {}
     spr.fit(select_modes='number', n_modes=wl['s'])
     field = spr.reconstruct(spr.Ar[0])
+    # the two loop forms of bench.py's timed region: gather joined inside the step / left in flight and joined later
+    eng = spr._engine()
+    a = eng.to_device(spr.Ar[:1].copy())
+
+    def loop(sync):
+        spr.comm_timing.clear()
+        prev = None
+        for _ in range(3):
+            spr.fit(select_modes='number', n_modes=wl['s'])
+            if prev is not None and hasattr(prev, 'wait'):
+                prev.wait()
+            prev = spr.reconstruct(a, to_host=False, wait=sync)
+        if hasattr(prev, 'wait'):
+            prev.wait()
+        return {k: float(np.mean([eng.elapsed_ms(e0, e1) for e0, e1 in v])) for k, v in spr.comm_timing.items()}, \
+               {k: len(v) for k, v in spr.comm_timing.items()}
+
+    comm_main, n_main = loop(False)
+    comm_sync, n_sync = loop(True)
+    comm = bench.comm_summary(comm_main, comm_sync, True, False, wl['features'], wl['m'], world, plan['n_loc'])
     if rank == 0:
         if args.out:
             np.save(args.out, field)
         print(json.dumps(dict(n_gpus=dist.get_world_size(), scaling=plan['scaling'], rows_total=plan['n_glob'],
-                              rows_per_gpu=plan['n_loc'], n_points=plan['n_points'])), flush=True)
+                              rows_per_gpu=plan['n_loc'], n_points=plan['n_points'], comm=comm,
+                              brackets_pipelined=n_main, brackets_sync=n_sync)), flush=True)
     dist.destroy_process_group()
 
 

@@ -19,6 +19,18 @@ class NumpyEngine:
         self.device = torch.device('cpu')
 
     # plumbing
+    class _Tick:                                              # stand-in for a stream event: the host clock
+        def __init__(self):
+            import time
+            self.t = time.perf_counter()
+
+    def timing_event(self):
+        return NumpyEngine._Tick()
+
+    @staticmethod
+    def elapsed_ms(e0, e1):
+        return 1e3 * (e1.t - e0.t)
+
     def empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or torch.float64)
 

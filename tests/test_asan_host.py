@@ -19,7 +19,7 @@ sys.path.insert(0, %(root)r)
 from openmeasure_amd import _lib
 assert _lib.LIB_PATH.endswith('libspr_hip_asan.so'), _lib.LIB_PATH
 lib = _lib.load()
-assert lib.spr_abi_version() == 1
+assert lib.spr_abi_version() == _lib.SPR_ABI_VERSION
 n = 0
 for name, (res, args) in sorted(_lib.PROTOTYPES.items()):
     if res is not C.c_int or not args or name in ('spr_abi_version', 'spr_device_cus', 'spr_project_norms_supported', 'spr_qr_epoch_supported',

@@ -57,6 +57,13 @@ def test_launcher_runs_sharded_job_over_gloo(tmp_path, world):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == world and rec['scaling'] == 'strong'
     assert rec['rows_total'] == 360 and rec['rows_per_gpu'] * world == 360
+    # collective timing (bench.py's `comm` object): one all-reduce bracket per fit in both loop forms; the gather is timed
+    # issue -> join where it is joined inside the step, and its exposed wait where it is left in flight
+    assert rec['brackets_pipelined'] == {'allreduce': 3, 'gather_exposed': 3}
+    assert rec['brackets_sync'] == {'allreduce': 3, 'gather': 3}
+    comm = rec['comm']
+    assert comm['allreduce_ms'] > 0 and comm['gather_ms'] > 0 and comm['gather_exposed_ms'] >= 0
+    assert comm['allreduce_bytes'] == (3 * 10 * 10 + world * 3 * 3) * 8 and comm['gather_bytes_per_rank'] == 8 * 360 // world
     # same job in one process with the same engine: the gathered field agrees
     from openmeasure_amd.sparse_sensing import SPR
     from tests._bench_rank_double import make_X

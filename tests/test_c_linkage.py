@@ -13,7 +13,7 @@ C_SRC = r'''
 #include <string.h>
 #include "spr_hip.h"
 int main(void) {
-  if (spr_abi_version() != 1) return 1;
+  if (spr_abi_version() != SPR_ABI_VERSION) return 1;
   /* argument validation happens before any device work */
   int rc = spr_reconstruct_f64(NULL, 10, 4, 4, 0, 10, 1, NULL, NULL, NULL, NULL, 1, NULL, 10, NULL);
   if (rc != SPR_E_INVALID) return 2;

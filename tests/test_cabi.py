@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_loader_and_error_text():
     lib = _lib.load()
-    assert lib.spr_abi_version() == 1
+    assert lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 2
     # argument validation happens before any device work: a NULL matrix is rejected on a CPU-only box
     rc = lib.spr_reconstruct_f64(None, 10, 4, 4, 0, 10, 1, None, None, None, None, 1, None, 10, None)
     assert rc == -1
@@ -72,3 +72,13 @@ def test_integration_doc_matches_prototypes():
         want = _lib.PROTOTYPES[fn][1]
         got = [names[a.strip()] for a in args.split(',') if a.strip()]
         assert got == list(want), fn
+
+
+def test_loader_refuses_another_abi_version(monkeypatch):
+    """A binding written for another argument layout must not call into the library (a signature that changes
+    under an unchanged name would pass shifted arguments -- wild pointers on the GPU)."""
+    _lib.load()
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'SPR_ABI_VERSION', _lib.SPR_ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match='ABI version'):
+        _lib.load()

@@ -35,7 +35,8 @@ def test_native_library_is_loaded(eng):
     import os
     maps = open(f'/proc/{os.getpid()}/maps').read()
     assert 'libspr_hip.so' in maps
-    assert eng.lib.spr_abi_version() == 1
+    from openmeasure_amd import _lib
+    assert eng.lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 2
 
 
 def test_golden_fixture(golden, eng):
@@ -1442,3 +1443,30 @@ def test_solve_ols_wide_vs_oracle(eng, s_, r, cond):
         assert np.linalg.norm(Ar[k] - A_ref[k]) <= 1e-9 * cond * np.linalg.norm(A_ref[k]), (k, info[k])
     assert np.linalg.norm(As[1] - S_ref[1]) <= 1e-9 * cond * np.linalg.norm(S_ref[1]) and not As[0].any()
     np.testing.assert_allclose(eng.to_host(y0)[1, :, 1], ys[1][:, 1])
+
+
+def test_gap_filler_changes_nothing_but_the_clock(eng, monkeypatch):
+    """ROM.gap_filler: from the second fit() on, the Gram kernel is queued once more (results discarded) into the host
+    gap between the Gram pass and the projection.  Every fitted quantity is bit for bit what a fit without the filler
+    gives, and the top-r eigen route (m >= 96) gives the sensors of the oracle."""
+    from openmeasure_amd.sparse_sensing import SPR
+    n_points, F, m, r = 30_000, 3, 256, 64
+    X = synth_host(n_points, F, m, 100, 0.93, 1e-3, 11)
+    a = SPR(X, F, None, engine=eng)
+    fills = []
+    for _ in range(4):
+        a.fit(select_modes='number', n_modes=r)
+        fills.append(a._gap_fill_rows)
+    assert fills[0] == 0 and fills[-1] >= 65536, fills      # no history in the first call; later ones fill the gap
+    monkeypatch.setenv('SPR_GAP_FILLER', '0')
+    b = SPR(X, F, None, engine=eng)
+    b.fit(select_modes='number', n_modes=r)
+    assert not hasattr(b, '_gap_fill_rows')
+    for name in ('Ur', 'X_cnt', 'Sigma_r', 'Ar'):
+        np.testing.assert_array_equal(getattr(a, name), getattr(b, name))
+    a.optimal_placement(); b.optimal_placement()
+    np.testing.assert_array_equal(a.sensors_, b.sensors_)
+    st = orc.fit(X, F, select_modes='number', n_modes=r)
+    piv, _ = orc.qr_pivots(st['Ur'])
+    np.testing.assert_array_equal(a.sensors_, piv)
+    np.testing.assert_allclose(a.Sigma_r, st['Sigma_r'], rtol=1e-8)

@@ -397,3 +397,61 @@ def test_pivot_drivers_on_the_candidate_model(name, U, pools):
             assert kinds.count('pool') >= 1 and sweeps <= plain and (sweeps < plain or r <= 2 * eng.qr_batch)
     else:
         assert set(kinds) <= {'refresh'} and sweeps == 1 + len(kinds)
+
+
+@pytest.mark.parametrize('m,modes', [(128, ('number', 16)), (160, ('number', 40)), (128, ('variance', 99.0)), (96, ('number', 48))])
+def test_top_r_eigen_route_matches_full_solve(m, modes, monkeypatch):
+    """fit() above m = 96 takes only the r leading eigenvectors of the Gram matrix (dsytrd + dsterf + dstein + dormqr,
+    sparse_sensing._eigvecs_top) instead of dsyevd's full decomposition (reference :272 computes all of them and :336
+    slices): same rank, spectrum, basis (up to sign), sensors and field -- against the full solve on the same data and
+    against the oracle."""
+    import openmeasure_amd.sparse_sensing as ss
+    from oracle import spr_oracle as orc
+    X = _synth(400, 3, m, 60, 0.85, 1e-3, seed=m)
+    select, n_modes = modes
+    used = []
+    real_top = ss._eigvecs_top
+
+    def spy(fac, lam, r):
+        V = real_top(fac, lam, r)
+        used.append((r, V is not None))
+        return V
+    monkeypatch.setattr(ss, '_eigvecs_top', spy)
+    a = SPR(X, 3, None, engine=NumpyEngine())
+    a.fit(select_modes=select, n_modes=n_modes)
+    assert used and used[-1][1] and used[-1][0] == a.r, 'the top-r route did not run'
+    monkeypatch.setattr(ss, '_EIGH_TOP_MIN_M', 10 ** 9)            # the full dsyevd route on the same data
+    b = SPR(X, 3, None, engine=NumpyEngine())
+    b.fit(select_modes=select, n_modes=n_modes)
+    assert a.r == b.r and 2 * a.r <= m
+    np.testing.assert_allclose(a.S_ ** 2, b.S_ ** 2, rtol=0, atol=1e-12 * b.S_[0] ** 2)   # eigenvalues: dsterf vs dsyevd
+    np.testing.assert_allclose(a.exp_variance_, b.exp_variance_, rtol=1e-12)
+    sg = np.sign(np.sum(a.Ur * b.Ur, axis=0))
+    assert np.abs(a.Ur * sg - b.Ur).max() <= 1e-9 * np.abs(b.Ur).max()
+    # orthonormal to what the Gram route gives at this sigma_1/sigma_r (eps kappa^2), and no worse than the full solve
+    oa, ob = np.abs(a.Ur.T @ a.Ur - np.eye(a.r)).max(), np.abs(b.Ur.T @ b.Ur - np.eye(b.r)).max()
+    assert oa < 1e-8 and oa < 10 * ob + 1e-13
+    a.optimal_placement(); b.optimal_placement()
+    np.testing.assert_array_equal(a.sensors_, b.sensors_)
+    st = orc.fit(X, 3, select_modes=select, n_modes=n_modes) if hasattr(orc, 'fit') else None
+    if st is not None:
+        assert st['r'] == a.r
+        np.testing.assert_allclose(a.Sigma_r, st['Sigma_r'], rtol=1e-8)
+        piv, _ = orc.qr_pivots(st['Ur'])
+        np.testing.assert_array_equal(a.sensors_, piv)
+
+
+def test_top_r_route_falls_back(monkeypatch):
+    """r > m/2, a spectrum that needs the refinement pass, or vectors that fail the orthogonality check: dsyevd as before."""
+    import openmeasure_amd.sparse_sensing as ss
+    X = _synth(300, 2, 128, 100, 0.97, 1e-3, seed=3)
+    calls = []
+    real_top = ss._eigvecs_top
+    monkeypatch.setattr(ss, '_eigvecs_top', lambda fac, lam, r: calls.append(r) or real_top(fac, lam, r))
+    a = SPR(X, 2, None, engine=NumpyEngine())
+    a.fit(select_modes='number', n_modes=100)                      # r > m/2: full solve, the top-r half never runs
+    assert calls == [] and a.r == 100 and a.Ur.shape[1] == 100
+    monkeypatch.setattr(ss, '_eigvecs_top', lambda fac, lam, r: None)   # a failed dstein / orthogonality check
+    b = SPR(X, 2, None, engine=NumpyEngine())
+    b.fit(select_modes='number', n_modes=12)
+    assert b.r == 12 and np.abs(b.Ur.T @ b.Ur - np.eye(12)).max() < 1e-10

@@ -21,6 +21,18 @@
  *     enqueued asynchronously on it, nothing synchronises the host;
  *   - return value: 0 = ok, <0 = error (SPR_E_*); spr_last_error() gives the text for
  *     the calling thread.  No C++ exception crosses this boundary.
+ *
+ * Environment switches read by the library (A/B measurements only -- every setting computes the same results through
+ * another kernel of the same family; each is read once per process, at the first call that consults it):
+ *   SPR_GRAM_OWN=0            spr_stats_gram_*: the generic row staging instead of the own-means lane (m >= 128)
+ *   SPR_PROJECT_WS=0          spr_project_*: the general (register-resident W) kernel also where the W-stationary one fits
+ *   SPR_RECONSTRUCT_DIRECT=0|1|3   spr_reconstruct_*: LDS panels everywhere | register-direct rows for f32 bases and
+ *                             f64 bases wider than 96 columns (default) | register-direct everywhere
+ *   SPR_QR_DIRECT=0           spr_qr_init_* / spr_qr_refresh_*: LDS-panel sweeps only
+ *   SPR_QR_FUSED_STEPS=0      spr_qr_steps_f64: three launches per candidate step instead of the fused one
+ * and by the Python layer (openmeasure_amd/): SPR_PROJECT_STREAM=1 (streamed-W projection for every shape),
+ * SPR_GAP_FILLER=0 (no filler launch in fit()'s host gap, ROM.gap_filler), SPR_TRACE=1 (per-phase wall clock of fit(),
+ * synchronising), SPR_HIP_LIBRARY=<path> (another build of this library).  None of them is needed in production.
  */
 #ifndef SPR_HIP_H
 #define SPR_HIP_H
@@ -45,7 +57,7 @@ extern "C" {
 #define SPR_MAX_R_WIDE 1024  /* ... the widest basis the placement / solve kernels accept (r <= m in the reference, :336) */
 
 /* Bumped whenever an entry point changes its argument list or meaning (round 3 -> 4: spr_qr_steps_f64 gained
- * first_exact, the keep-alive and layout entry points arrived).  A binding written for another value must refuse to
+ * first_exact, new entry points arrived).  A binding written for another value must refuse to
  * call into this library: openmeasure_amd/_lib.py compares spr_abi_version() with the value its prototypes were
  * written for. */
 #define SPR_ABI_VERSION 2
@@ -59,17 +71,6 @@ int spr_device_cus(int *out_cus);
  * (sparse_sensing.py:272-279), X_scl per feature (:115), the coefficient vectors of reconstruct (:371) -- to
  * the device.  The source may be rewritten once work queued after this call on the stream has completed. */
 int spr_upload_bytes(void *d_dst, const void *h_pinned_src, int64_t n_bytes, void *stream);
-/* Clock keep-alive for the host gap of fit() (csrc/keepalive.hip): between the Gram pass and the projection the host
- * eigen-solves the m x m Gram matrix -- the reference's np.linalg.svd call site (sparse_sensing.py:272) -- and the idle
- * device drops its clock, which the projection then pays for (tools/idle_gap_probe.py).  One workgroup per CU issues
- * v_mfma_f64 (mode & 1), streams d_stream_src round and round (mode & 2) and stages what it streams through LDS like
- * the Gram kernel does (mode & 8; mode & 4: a resident but sleeping grid, diagnostic) until the HOST stores a
- * value >= `generation` into the page-locked word h_pinned_flag, or until max_ms (clamped to 20 ms) have passed --
- * whichever comes first: the grid always drains.  d_flag is a device word the library relays the host's value through
- * (initialise it once to 0; generations must increase from call to call); d_sink one writable double.  Work queued on
- * `stream` behind this call starts when the kernel has left. */
-int spr_keepalive_start(const int32_t *h_pinned_flag, int32_t *d_flag, int32_t generation, double max_ms, int32_t mode,
-                        const double *d_stream_src, int64_t stream_elems, double *d_sink, void *stream);
 
 /* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
  * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised
@@ -138,7 +139,8 @@ int spr_gram_cross_pair_f64(const double *d_X, int64_t n_rows, int32_t col_a, in
  * needs no host synchronisation.  d_gram [F][m][m] and d_fstats_all [n_ranks][F][3] are the
  * (all-reduced / all-gathered) outputs of spr_stats_gram_finalize_f64.  scale_code: 0 'std',
  * 1 'none', 2 'pareto', 3 'vast', 4 'level', 5 'variance', 6 'poisson', 7 'l2-norm'.
- * Outputs: d_feat [F][5] = (count, block mean, block variance, scale, 1/scale); d_scale, d_inv_scale
+ * Outputs: d_feat [F][5] = (count, block mean, block variance, scale, variance of the row-centred values =
+ * trace(G_f) / (count m)); d_scale, d_inv_scale
  * [F]; d_lam, d_S, d_expvar [m] (descending); d_V [m][m] (columns = eigenvectors, largest-magnitude
  * entry positive); d_W = V_r S_r^-1 and d_Ar = V_r S_r [m][r]; d_info = (Jacobi sweeps, off^2, diag^2). */
 int32_t spr_spectrum_max_m(void);
@@ -150,7 +152,8 @@ int spr_spectrum_f64(const double *d_gram, const double *d_fstats_all, int32_t n
 /* ---- K3a' : per-feature Gram blocks -> the scaled m x m Gram matrix --------------------
  * G = sum_f G_f / X_scl_f^2 is the Gram matrix of the reference's X0 = (X - X_cnt)/X_scl (:169) whose SVD :272 takes.
  * Inputs as for spr_spectrum_f64 (all-reduced d_gram [F][m][m], all-gathered d_fstats_all [n_ranks][F][3], scale_code
- * 0..7); outputs d_G [m][m], d_feat [F][5] = (count, block mean, block variance (:115), scale, 1/scale), and the scales
+ * 0..7); outputs d_G [m][m], d_feat [F][5] = (count, block mean, block variance (:115), scale, variance of the
+ * row-centred values), and the scales
  * d_scale / d_inv_scale [F] that the projection and reconstruction kernels read.  Replaces the host merge of fit():
  * one download of m^2 + 5 F doubles instead of F m^2, no upload. */
 int spr_gram_combine_f64(const double *d_gram, const double *d_fstats_all, int32_t n_ranks,
@@ -380,7 +383,8 @@ int spr_measure_csr_f64(const int64_t *d_indptr, const int64_t *d_indices,
  * Per vector: y0 = ((y-cnt)/scl, sigma/scl); W = I if every sigma is 0 else diag(1/y0_sigma);
  * normal equations (W Theta)^T (W Theta) a = (W Theta)^T W y0 by f64 MFMA + Cholesky.
  * Outputs: d_Ar, d_Ar_sigma (n_p x r), d_y0 (n_p x s x 2, may be NULL),
- * d_info (n_p x 2: [0] = 0 ok / 1 Cholesky breakdown, [1] = (max L_jj / min L_jj)^2). */
+ * d_info (n_p x 2: [0] = 0 ok / 1 Cholesky breakdown / 2 a weight 1/sigma that is not finite -- an uncertainty that is zero or
+ * NaN for SOME sensors makes W = diag(1/0) at :872 and np.linalg.pinv raises LinAlgError --, [1] = (max L_jj / min L_jj)^2). */
 int spr_solve_ols_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt,
                       const double *d_scale, int32_t n_features, const double *d_y,
                       int32_t n_p, double *d_Ar, double *d_Ar_sigma, double *d_y0,
@@ -401,7 +405,8 @@ int spr_solve_ols_wide_f64(const double *d_Theta, int32_t s, int32_t r, const do
  * triangular factor (streaming Householder QR, only when s > r) and a one-sided Jacobi SVD of that factor gives
  * a = sum_{sigma_i > rcond sigma_max} v_i (u_i^T b) / sigma_i.  predict() takes this path when s < r, on Cholesky
  * breakdown, or when the fast path reports cond^2 > 1e13.  s_cnt = entries of d_cnt (must equal s).
- * d_info (n_p x 4): [0] Jacobi sweeps (negative = not converged), [1] rank kept, [2] sigma_max, [3] smallest
+ * d_info (n_p x 4): [0] Jacobi sweeps (negative = not converged, or a non-finite weight 1/sigma as in spr_solve_ols_f64:
+ * the reference's pinv raises LinAlgError for both), [1] rank kept, [2] sigma_max, [3] smallest
  * singular value kept. */
 int spr_solve_pinv_f64(const double *d_Theta, int32_t s, int32_t r, const double *d_cnt, int32_t s_cnt,
                        const double *d_scale, int32_t n_features, const double *d_y, int32_t n_p,

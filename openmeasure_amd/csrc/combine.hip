@@ -17,7 +17,7 @@ constexpr int CB_MAXF = 1024;
 
 __global__ __launch_bounds__(CB_THREADS) void gram_combine_kernel(
     const double *__restrict__ gram, const double *__restrict__ fstats_all, int n_ranks, int n_features, int m,
-    int scale_code, double *__restrict__ G_out, double *__restrict__ feat_out /*[F][5]: cnt, mu, var, scl, 1/scl*/,
+    int scale_code, double *__restrict__ G_out, double *__restrict__ feat_out /*[F][5]: cnt, mu, var, scl, fluctuation variance*/,
     double *__restrict__ scale, double *__restrict__ inv_scale) {
   __shared__ double scl2[CB_MAXF];
   const int tid = threadIdx.x;
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(CB_THREADS) void gram_combine_kernel(
     scl2[f] = scl * scl;
     if (blockIdx.x == 0) {
       feat_out[5 * f] = n; feat_out[5 * f + 1] = mu; feat_out[5 * f + 2] = var;
-      feat_out[5 * f + 3] = scl; feat_out[5 * f + 4] = 1.0 / scl;
+      // slot 4: variance of the ROW-CENTRED values, trace(G_f) / (n m) -- var minus the spread of the row means; what the
+      // host compares the row means with when it decides how the projection removes them (ROM._needs_precenter)
+      feat_out[5 * f + 3] = scl; feat_out[5 * f + 4] = present ? trs[f] / (n * m) : 0.0;
       scale[f] = scl;
       inv_scale[f] = 1.0 / scl;
     }

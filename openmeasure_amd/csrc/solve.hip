@@ -52,14 +52,14 @@ __global__ __launch_bounds__(SV_THREADS) void solve_ols_kernel(
   __shared__ double dsc[C::RMAX];
   __shared__ double xs[2][C::RMAX];
   __shared__ double sw[SC], sv[SC], ss[SC];
-  __shared__ int flags[2];  // [0] any sigma != 0, [1] Cholesky breakdown
+  __shared__ int flags[3];  // [0] any sigma != 0, [1] Cholesky breakdown, [2] a non-finite weight 1/sigma
 
   const int p = blockIdx.x;
   const double *y = y_all + (int64_t)p * s * 3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  if (tid < 2) flags[tid] = 0;
+  if (tid < 3) flags[tid] = 0;
   __syncthreads();
   {
     int any = 0;
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(SV_THREADS) void solve_ols_kernel(
         v0 = (y[3 * k] - cnt[k]) / scl;
         s0 = y[3 * k + 1] / scl;
         w = weighted ? 1.0 / s0 : 1.0;
+        if (!isfinite(w)) flags[2] = 1;     // sigma zero or NaN for SOME sensors: W = diag(1/0) in the reference (:872)
         if (y0_all) {
           y0_all[((int64_t)p * s + k) * 2] = v0;
           y0_all[((int64_t)p * s + k) * 2 + 1] = s0;
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(SV_THREADS) void solve_ols_kernel(
         v0 = (y[3 * k] - cnt[k]) / scl;
         s0 = y[3 * k + 1] / scl;
         w = weighted ? 1.0 / s0 : 1.0;
+        if (!isfinite(w)) flags[2] = 1;     // sigma zero or NaN for SOME sensors: W = diag(1/0) in the reference (:872)
       }
       sw[tid] = w; sv[tid] = v0; ss[tid] = s0;
     }
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(SV_THREADS) void solve_ols_kernel(
       if (d > dmax) dmax = d;
       if (d < dmin) dmin = d;
     }
-    info[2 * p] = (double)flags[1];
+    info[2 * p] = flags[2] ? 2.0 : (double)flags[1];     // 2: non-finite weights (np.linalg.pinv raises), 1: Cholesky breakdown
     info[2 * p + 1] = (dmax / dmin) * (dmax / dmin);
   }
 }
@@ -298,11 +300,11 @@ __global__ __launch_bounds__(SW_THREADS) void solve_ols_wide_kernel(
   double *N = A + (int64_t)s * nc;                        // r x LDN
   double *rhs0 = N + (int64_t)r * LDN, *rhs1 = rhs0 + r, *sol0 = rhs1 + r, *sol1 = sol0 + r, *dsc = sol1 + r;
   double *xs0 = dsc + r, *xs1 = xs0 + r, *res0 = xs1 + r, *res1 = res0 + s;   // residuals: s entries each
-  __shared__ int flags[2];
+  __shared__ int flags[3];
   __shared__ double piv[2];
   const int p = blockIdx.x, tid = threadIdx.x;
   const double *y = y_all + (int64_t)p * s * 3;
-  if (tid < 2) flags[tid] = 0;
+  if (tid < 3) flags[tid] = 0;
   __syncthreads();
   {
     int any = 0;
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(SW_THREADS) void solve_ols_wide_kernel(
     const double scl = scale[f];
     const double v0 = (y[3 * k] - cnt[k]) / scl, s0 = y[3 * k + 1] / scl;
     const double w = weighted ? 1.0 / s0 : 1.0;
+    if (!isfinite(w)) flags[2] = 1;         // sigma zero or NaN for SOME sensors: W = diag(1/0) in the reference (:872)
     if (y0_all) {
       y0_all[((int64_t)p * s + k) * 2] = v0;
       y0_all[((int64_t)p * s + k) * 2 + 1] = s0;
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(SW_THREADS) void solve_ols_wide_kernel(
       if (d > dmax) dmax = d;
       if (d < dmin) dmin = d;
     }
-    info[2 * p] = (double)flags[1];
+    info[2 * p] = flags[2] ? 2.0 : (double)flags[1];     // 2: non-finite weights (np.linalg.pinv raises), 1: Cholesky breakdown
     info[2 * p + 1] = (dmax / dmin) * (dmax / dmin);
   }
 }

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(PV_THREADS) void solve_pinv_kernel(
   __shared__ double sw[SC], sv[SC], ss[SC];
   __shared__ double hv[2];
   __shared__ double sig2[RMAX];
-  __shared__ int flags[2];   // [0] any sigma != 0, [1] rotations in the current sweep
+  __shared__ int flags[3];   // [0] any sigma != 0, [1] rotations in the current sweep, [2] a non-finite weight 1/sigma
 
   const int p = blockIdx.x;
   const double *y = y_all + (int64_t)p * s * 3;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(PV_THREADS) void solve_pinv_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nc = r + 2;
 
-  if (tid < 2) flags[tid] = 0;
+  if (tid < 3) flags[tid] = 0;
   __syncthreads();
   {
     int any = 0;
@@ -74,6 +74,8 @@ __global__ __launch_bounds__(PV_THREADS) void solve_pinv_kernel(
         v0 = (y[3 * k] - cnt[k]) / scl;
         s0 = y[3 * k + 1] / scl;
         w = weighted ? 1.0 / s0 : 1.0;
+        // an uncertainty that is zero (or NaN) for SOME sensors: W = diag(1/0) in the reference (:872), whose pinv raises
+        if (!isfinite(w)) flags[2] = 1;
         if (y0_all) {
           y0_all[((int64_t)p * s + k) * 2] = v0;
           y0_all[((int64_t)p * s + k) * 2 + 1] = s0;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(PV_THREADS) void solve_pinv_kernel(
     double smin = 0.0;
     for (int i = 0; i < q; ++i)
       if (sqrt(sig2[i]) > cut) { ++rank; smin = (rank == 1 || sig2[i] < smin) ? sig2[i] : smin; }
-    info[4 * p] = converged ? (double)sweeps : -(double)sweeps;
+    info[4 * p] = (converged && !flags[2]) ? (double)sweeps : -(double)(sweeps > 0 ? sweeps : 1);   // < 0: LinAlgError on the host
     info[4 * p + 1] = (double)rank;
     info[4 * p + 2] = sqrt(s2max);
     info[4 * p + 3] = sqrt(smin);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(PW_THREADS) void solve_pinv_wide_kernel(
   __shared__ double sw[SC], sv[SC], ss[SC];
   __shared__ double hv[2];
   __shared__ double sig2[SPR_MAX_R_WIDE];
-  __shared__ int flags[2];
+  __shared__ int flags[3];
 
   const int p = blockIdx.x;
   const double *y = y_all + (int64_t)p * s * 3;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(PW_THREADS) void solve_pinv_wide_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nc = r + 2;
 
-  if (tid < 2) flags[tid] = 0;
+  if (tid < 3) flags[tid] = 0;
   __syncthreads();
   {
     int any = 0;
@@ -283,6 +285,8 @@ __global__ __launch_bounds__(PW_THREADS) void solve_pinv_wide_kernel(
         v0 = (y[3 * k] - cnt[k]) / scl;
         s0 = y[3 * k + 1] / scl;
         w = weighted ? 1.0 / s0 : 1.0;
+        // an uncertainty that is zero (or NaN) for SOME sensors: W = diag(1/0) in the reference (:872), whose pinv raises
+        if (!isfinite(w)) flags[2] = 1;
         if (y0_all) {
           y0_all[((int64_t)p * s + k) * 2] = v0;
           y0_all[((int64_t)p * s + k) * 2 + 1] = s0;
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(PW_THREADS) void solve_pinv_wide_kernel(
     double smin = 0.0;
     for (int i = 0; i < q; ++i)
       if (sqrt(sig2[i]) > cut) { ++rank; smin = (rank == 1 || sig2[i] < smin) ? sig2[i] : smin; }
-    info[4 * p] = converged ? (double)sweeps : -(double)sweeps;
+    info[4 * p] = (converged && !flags[2]) ? (double)sweeps : -(double)(sweeps > 0 ? sweeps : 1);   // < 0: LinAlgError on the host
     info[4 * p + 1] = (double)rank;
     info[4 * p + 2] = sqrt(s2max);
     info[4 * p + 3] = sqrt(smin);

@@ -82,7 +82,7 @@ __device__ inline void rotation(double app, double aqq, double apq, double &c, d
 
 __global__ __launch_bounds__(SP_THREADS) void spectrum_kernel(
     const double *__restrict__ gram, const double *__restrict__ fstats_all, int n_ranks, int n_features, int m,
-    int scale_code, int r, double *__restrict__ feat_out /*[F][5]: cnt, mu, var, scl, 1/scl*/,
+    int scale_code, int r, double *__restrict__ feat_out /*[F][5]: cnt, mu, var, scl, fluctuation variance*/,
     double *__restrict__ scale, double *__restrict__ inv_scale, double *__restrict__ lam_out,
     double *__restrict__ S_out, double *__restrict__ expvar_out, double *__restrict__ V_out,
     double *__restrict__ W_out, double *__restrict__ Ar_out, double *__restrict__ info) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(SP_THREADS) void spectrum_kernel(
       }
       if (!present) scl = 1.0;
       feat_out[5 * f] = n; feat_out[5 * f + 1] = mu; feat_out[5 * f + 2] = var;
-      feat_out[5 * f + 3] = scl; feat_out[5 * f + 4] = 1.0 / scl;
+      feat_out[5 * f + 3] = scl; feat_out[5 * f + 4] = present ? tr / (n * m) : 0.0;   // variance of the row-centred values (combine.hip)
       scale[f] = scl;
       inv_scale[f] = 1.0 / scl;
       inv2[tid] = 1.0 / (scl * scl);

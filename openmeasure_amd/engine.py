@@ -41,7 +41,6 @@ class HipEngine:
         self._force_stream = os.environ.get('SPR_PROJECT_STREAM') == '1'   # A/B runs: streamed-W projection for every shape
         self._stage = None                                   # ring of pinned host staging buffers for small uploads
         self._dstage = None                                  # pinned landing buffer for small downloads
-        self._ka = None                                      # keep-alive state (keepalive_start / keepalive_stop)
 
     # ---- plumbing ---------------------------------------------------------------------
     def _stream(self):
@@ -116,35 +115,6 @@ class HipEngine:
             then()
         self._dstage_ev.synchronize()
         return buf.numpy().copy()
-
-    # ---- clock keep-alive for the host gap of fit() (csrc/keepalive.hip) ---------------------------------
-    def keepalive_start(self, mode=1, max_ms=8.0, stream_src=None):
-        """Keep the matrix pipes (mode & 1) and / or the memory fabric (mode & 2, needs `stream_src`: any float64 device
-        tensor to read round and round) busy on the current stream until keepalive_stop() -- or max_ms, whichever
-        comes first: the kernel always leaves by itself.  Work enqueued afterwards starts when it has left."""
-        torch = self.torch
-        if self._ka is None:
-            flag = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-            self._ka = dict(flag=flag, flag_np=flag.numpy(), dflag=self.zeros((1,), dtype=torch.int32),
-                            sink=self.zeros((1,)), gen=0, live=False)
-        ka = self._ka
-        ka['gen'] += 1
-        src_p, elems = (None, 0)
-        if mode & 2:
-            if stream_src is None or stream_src.dtype != torch.float64 or not stream_src.is_contiguous():
-                raise ValueError('keepalive_start(mode & 2) needs a contiguous float64 device tensor to stream')
-            src_p, elems = stream_src.data_ptr(), stream_src.numel()
-        _lib.check(self.lib.spr_keepalive_start(ka['flag'].data_ptr(), ka['dflag'].data_ptr(), ka['gen'], float(max_ms),
-                                                int(mode), src_p, elems, ka['sink'].data_ptr(), self._stream()),
-                   'spr_keepalive_start')
-        ka['live'] = True
-
-    def keepalive_stop(self):
-        """Release the keep-alive kernel (a plain store into the page-locked flag word it polls); idempotent."""
-        ka = self._ka
-        if ka is not None and ka['live']:
-            ka['flag_np'][0] = ka['gen']
-            ka['live'] = False
 
     def timing_event(self):
         """An event recorded NOW on the current stream; pairs are read with elapsed_ms() after a synchronisation."""

@@ -46,6 +46,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from ._lib import SPR_MAX_R_WIDE
+
 __all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix', 'PendingField', 'OneHotRows']
 
 _DEVICE_SPECTRUM_MAX_M = 24   # above this the single-workgroup Jacobi is slower than host dsyevd (csrc/spectrum.hip)
@@ -224,6 +226,8 @@ class OneHotRows:
                 return OneHotRows([row], self.n, _vector=True)
             if isinstance(ci, (int, np.integer)):
                 k = int(ci) + (self.n if ci < 0 else 0)
+                if not 0 <= k < self.n:                        # the dense matrix this stands in for raises as well
+                    raise IndexError(f'index {int(ci)} is out of bounds for axis 1 with size {self.n}')
                 return np.float64(1.0 if k == row else 0.0)
             return np.asarray(OneHotRows([row], self.n, _vector=True))[ci]
         if full_cols:
@@ -746,10 +750,14 @@ class ROM:
         if scale_type not in known:
             raise NotImplementedError('The scaling method selected has not been implemented yet')   # :164
         if scale_type not in self._DEVICE_SCALINGS:
-            # the reference's own 'vast_2/3/4' branches assign scipy's per-column kurtosis (an m-vector) to a
-            # column of n_points rows (:147-157) and fail with a broadcast error unless n_points == m
-            raise NotImplementedError(f"scale_type={scale_type!r} has no device implementation (per-column kurtosis, "
-                                      'ill-defined in the reference itself); no CPU fallback.')
+            # the reference's own 'vast_2/3/4' branches assign scipy's per-COLUMN kurtosis (an m-vector, :148 / :152 / :156)
+            # to a slice of n_points rows: NumPy refuses that assignment with a ValueError unless m == n_points (or
+            # m == 1, which broadcasts) -- the same exception here, before any device work
+            m = self.X.shape[1]
+            if m not in (1, self.n_points):
+                raise ValueError(f'could not broadcast input array from shape ({m},) into shape ({self.n_points},)')
+            raise NotImplementedError(f"scale_type={scale_type!r} has no device implementation (per-column kurtosis "
+                                      'assigned to rows: only defined in the reference when n_points == m); no CPU fallback.')
         if axis_cnt not in (1, None):
             raise NotImplementedError(f'axis_cnt={axis_cnt!r}: row centring (1) and scalar centring (None) have a '
                                       'device implementation; no CPU fallback for the rest.')
@@ -919,6 +927,7 @@ class ROM:
             self._scl_f = feat[:, 3].copy()
             self._var_f = self._scl_f ** 2
             self._mu_f = feat[:, 1].copy()
+            self._set_precenter_ratio(feat[:, 1], feat[:, 2], feat[:, 4], axis_cnt)
             self._d['rowmean'] = rowmean
             self._d['scale'] = scale_d
             self._d['inv_scale'] = inv_d
@@ -951,6 +960,9 @@ class ROM:
         self._scl_f = np.where(present, scl, 1.0)
         self._var_f = self._scl_f ** 2                        # what the Gram blocks are divided by
         self._mu_f = mu.copy()
+        with np.errstate(invalid='ignore', divide='ignore'):
+            fluct = np.where(present, tr / np.where(present, cnt * m, 1.0), 0.0)
+        self._set_precenter_ratio(mu, var_f, fluct, axis_cnt)
         if axis_cnt is None:
             # scalar centre per feature (:112 with axis=None): turn the row-centred Gram blocks into those
             # of (X - mu_f) with the two column-sum vectors, and make X_cnt the per-feature constant
@@ -958,7 +970,6 @@ class ROM:
             v = cs[:, 1, :] - mu[:, None] * cs[:, 0, :]       # sum_i (mean_i - mu_f) c_i
             G_f = G_f + v[:, :, None] + v[:, None, :] + m2[:, None, None]
             rowmean = eng.fill_feature(Xd.shape[0], self._row0, self.n_points, eng.to_device(mu))
-            self._mu_f = np.zeros(F)                          # the centre is a per-feature constant: nothing to cancel
         with np.errstate(invalid='ignore', divide='ignore'):
             self._G = np.sum(G_f / self._var_f[:, None, None], axis=0)   # Gram matrix of X0 = (X - X_cnt)/X_scl
         self._d['rowmean'] = rowmean
@@ -975,12 +986,23 @@ class ROM:
     # (spr_project_stream_* centre mode 2) -- the reference's own order of operations (:169).
     _PRECENTER_ABOVE = 1e6
 
-    def _needs_precenter(self, kappa):
-        mu, scl = getattr(self, '_mu_f', None), getattr(self, '_scl_f', None)
-        if mu is None or scl is None or not np.isfinite(kappa):
-            return False
+    def _set_precenter_ratio(self, mu, var, fluct, axis_cnt):
+        """Per feature: how large the centre the projection's epilogue has to cancel is, relative to what is left after the
+        cancellation.  Row centring (axis_cnt = 1): the rows' own means -- the block mean plus four standard deviations
+        of the row means, sqrt(var - fluct), as a stand-in for max_i |mean_i| -- over the rms of the row-centred values,
+        sqrt(fluct) = sqrt(trace(G_f) / (count m)): the block std would not do, it contains the spread of the means.
+        Scalar centring (axis_cnt = None): X_cnt is the block mean itself and what remains is the whole block's spread."""
+        mu, var, fluct = (np.asarray(a, dtype=np.float64) for a in (mu, var, fluct))
         with np.errstate(invalid='ignore', divide='ignore'):
-            ratio = np.abs(mu) / np.abs(scl)
+            if axis_cnt is None:
+                self._pc_ratio = np.abs(mu) / np.sqrt(var)
+            else:
+                self._pc_ratio = (np.abs(mu) + 4.0 * np.sqrt(np.maximum(var - fluct, 0.0))) / np.sqrt(fluct)
+
+    def _needs_precenter(self, kappa):
+        ratio = getattr(self, '_pc_ratio', None)
+        if ratio is None or not np.isfinite(kappa):
+            return False
         ratio = ratio[np.isfinite(ratio)]
         return bool(ratio.size and ratio.max() * kappa > self._PRECENTER_ABOVE)
 
@@ -1334,6 +1356,7 @@ class ROM:
         chk = eng.to_host(eng.torch.cat([sp['S'][:1], sp['S'][r - 1:r], sp['info'], sp['feat'].reshape(-1)]))
         feat = chk[5:].reshape(F, 5)
         self._scl_f, self._mu_f = feat[:, 3].copy(), feat[:, 1].copy()
+        self._set_precenter_ratio(feat[:, 1], feat[:, 2], feat[:, 4], axis_cnt)
         good = bool(np.all(np.isfinite(chk)))
         if good:
             converged = chk[2] < eng.spectrum_max_sweeps or chk[3] <= 1e-24 * chk[4]
@@ -1424,6 +1447,13 @@ class SPR(ROM):
     def __init__(self, X, n_features, xyz, shard=None, engine=None):
         super().__init__(X, n_features, xyz, shard=shard, engine=engine)
 
+    def _check_rank_cap(self, what):
+        """The placement and solve kernels are built for bases of up to SPR_MAX_R_WIDE columns (the reference takes any
+        r <= m, :336, :739): say so BEFORE any device work, naming the cap."""
+        if self.r > SPR_MAX_R_WIDE:
+            raise ValueError(f'{what}: r = {self.r} retained modes exceed the {SPR_MAX_R_WIDE} the placement and solve '
+                             'kernels are built for (fit and reconstruct take any r); keep fewer modes.')
+
     # ------------------------------------------------------------------ a6 optimal_placement
     def optimal_placement(self, calc_type='qr', n_sensors=10, mask=None, d_min=0., verbose=False):
         """Reference :700-756.  Returns the one-hot measurement matrix C of shape (s, n): the reference's dense ndarray
@@ -1436,6 +1466,7 @@ class SPR(ROM):
         eng = self._engine()
         n = self._n_global
         Ur_d = self._fitted('Ur', 'Ur')
+        self._check_rank_cap('optimal_placement')
         if mask is not None:
             mask = np.asarray(mask)
             if mask.dtype != np.bool_ or mask.shape != (Ur_d.shape[0],):
@@ -1481,6 +1512,7 @@ class SPR(ROM):
         eng = self._engine()
         Ur_d = self._fitted('Ur', 'Ur')
         r = self.r
+        self._check_rank_cap("optimal_placement('gem')")
         if type(n_sensors) is not int or n_sensors < 1:
             raise ValueError('n_sensors must be a positive integer.')
         if r < 3:
@@ -1656,6 +1688,7 @@ class SPR(ROM):
         if 'cnt' not in self._d:
             raise AttributeError("'SPR' object has no attribute 'C'")      # reference fails at self.C (:573)
         Theta_d, cnt_d = self._d['Theta'], self._d['cnt']
+        self._check_rank_cap('predict')
         if cnt_d.shape[0] != Theta_d.shape[0]:
             # train(Theta, is_Theta=True) after train(C) with another sensor count: C.dot(X_cnt) (:573) no longer
             # matches the rows of y -- the reference fails with a broadcast error at :578
@@ -1676,6 +1709,10 @@ class SPR(ROM):
         if s >= r and r <= getattr(eng, 'ols_max_r', r):      # the normal-equations kernel keeps its factor in LDS
             Ar_d, As_d, y0_d, info_d = eng.solve_ols(Theta_d, cnt_d, self._d['scale'], Y)
             info = eng.to_host(info_d)
+            if np.any(info[:, 0] == 2):
+                # an uncertainty that is zero (or NaN) for SOME sensors of a vector: W = diag(1/0) (:872) and
+                # np.linalg.pinv(W @ Theta) (:873) raises -- flagged by the kernel, no second solve
+                raise np.linalg.LinAlgError('SVD did not converge')
             # the kernel's refinement step (corrected semi-normal equations) is as accurate as a QR solve while
             # cond(W Theta)^2 eps < 1; info[:, 1] estimates cond^2 from the Cholesky pivots
             if not (np.any(info[:, 0] != 0) or np.any(info[:, 1] > 1e13) or not np.all(np.isfinite(info[:, 1]))):

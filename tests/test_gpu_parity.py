@@ -1470,3 +1470,79 @@ def test_gap_filler_changes_nothing_but_the_clock(eng, monkeypatch):
     piv, _ = orc.qr_pivots(st['Ur'])
     np.testing.assert_array_equal(a.sensors_, piv)
     np.testing.assert_allclose(a.Sigma_r, st['Sigma_r'], rtol=1e-8)
+
+
+@pytest.mark.parametrize('axis_cnt,m,r', [(1, 24, 6), (None, 24, 6), (1, 256, 32), (None, 256, 32), (1, 300, 20)])
+def test_fit_precentres_large_offsets(eng, axis_cnt, m, r):
+    """Fit-level check of the pre-centring safeguard: data whose centre is 1e6-1e7 times its fluctuation.  fit()
+    must choose the pre-centred projection on its own (precentered_), for row centring and for scalar centring, on the
+    device-spectrum route (m <= 24), the host route and the wide route; the basis then agrees with a fit of the SAME
+    fluctuation without the offset -- for which the epilogue form is exact -- far better than the epilogue form would."""
+    from openmeasure_amd.sparse_sensing import SPR
+    rng = np.random.default_rng(3 * m + (axis_cnt or 0))
+    n_points, F = 6000, 1               # one feature: the block scale is then a common factor that Ur = X0 V / S does not see
+    n = n_points * F
+    fl = rng.standard_normal((n, 12)) @ ((0.7 ** np.arange(12))[:, None] * rng.standard_normal((12, m))) + 1e-3 * rng.standard_normal((n, m))
+    if axis_cnt == 1:
+        fl = fl - fl.mean(axis=1, keepdims=True)
+        X = 1e6 * (1.0 + rng.random((n, 1))) + fl
+    else:
+        X = 1e7 + fl
+    a = SPR(np.ascontiguousarray(X), F, None, engine=eng)
+    a.fit(axis_cnt=axis_cnt, select_modes='number', n_modes=r)
+    assert a.precentered_ is True
+    b = SPR(np.ascontiguousarray(fl), F, None, engine=eng)              # offset removed before the data is handed over
+    b.fit(axis_cnt=axis_cnt, select_modes='number', n_modes=r)
+    assert b.precentered_ is False
+    # X = offset + fl is rounded to f64 at magnitude 1e6-1e7: the data themselves differ by 1e-10 relative to the fluctuation,
+    # amplified by sigma_1/sigma_i in the small modes
+    kappa = b.Sigma_r[0] / b.Sigma_r
+    sg = np.sign(np.sum(a.Ur * b.Ur, axis=0))
+    err = np.abs(a.Ur * sg - b.Ur).max(axis=0) / np.abs(b.Ur).max()
+    assert np.all(err <= 2e-9 * kappa), (err / kappa).max()
+    np.testing.assert_allclose(a.Sigma_r / a.Sigma_r[0], b.Sigma_r / b.Sigma_r[0], rtol=1e-7)   # up to the common block scale
+
+
+@pytest.mark.parametrize('r,s_extra', [(4, 0), (16, 8), (40, 0), (200, 0)])
+def test_predict_failure_modes_on_the_device(eng, r, s_extra):
+    """The reference's failure modes of predict() (:868-878), sent through solve.hip / solve_pinv.hip (and their wide twins):
+    uncertainties that are zero for SOME sensors make W = diag(1/0) (:872) and np.linalg.pinv raises LinAlgError; a NaN
+    measurement raises nothing and returns NaN coefficients; an infinite measurement likewise propagates."""
+    from openmeasure_amd.sparse_sensing import SPR
+    rng = np.random.default_rng(r)
+    n_points, F, m = 1500, 2, max(2 * r, 24)
+    X = synth_host(n_points, F, m, min(m, r + 8), 0.9, 1e-3, 50 + r)
+    spr = SPR(X, F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    C = spr.optimal_placement()
+    piv = spr.sensors_
+    if s_extra:                                                       # more sensors than modes: a general measurement matrix
+        more = rng.choice(np.setdiff1d(np.arange(X.shape[0]), piv), s_extra, replace=False)
+        piv = np.concatenate([piv, more])
+        import scipy.sparse as sp
+        C = sp.csr_matrix((np.ones(len(piv)), (np.arange(len(piv)), piv)), shape=(len(piv), X.shape[0]))
+    spr.train(C)
+    s = len(piv)
+    y = np.zeros((s, 3)); y[:, 0] = X[piv, 1]; y[:, 2] = piv // n_points
+    y[:, 1] = 0.01 * (1 + rng.random(s))
+    a_ok, sig_ok = spr.predict(y)
+    assert np.all(np.isfinite(a_ok)) and np.all(np.isfinite(sig_ok))
+    # (i) partially-zero uncertainties: 1/0 in W -> LinAlgError (the reference: SVD did not converge, :873)
+    ybad = y.copy(); ybad[s // 2, 1] = 0.0
+    with pytest.raises(np.linalg.LinAlgError):
+        spr.predict(ybad)
+    # ... also inside a batch whose other vectors are fine
+    with pytest.raises(np.linalg.LinAlgError):
+        spr.predict([y, ybad, y])
+    # (ii) a NaN measurement: no exception in the reference (pinv sees only W Theta), NaN coefficients
+    ynan = y.copy(); ynan[0, 0] = np.nan
+    a_nan, sig_nan = spr.predict(ynan)
+    assert np.all(np.isnan(a_nan)) and np.all(np.isfinite(sig_nan))
+    np.testing.assert_allclose(sig_nan, sig_ok, rtol=1e-9)
+    # (iii) a NaN uncertainty poisons W Theta itself: pinv raises
+    ynu = y.copy(); ynu[1, 1] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        spr.predict(ynu)
+    # the object is still usable afterwards
+    a_again, _ = spr.predict(y)
+    np.testing.assert_array_equal(a_again, a_ok)

@@ -95,8 +95,15 @@ def test_mode_selection_errors(small):                 # :314-333
 def test_unsupported_options_raise_not_fallback(small):
     X, F, xyz = small
     spr = SPR(X, F, xyz, engine=NumpyEngine())
-    with pytest.raises(NotImplementedError):
-        spr.fit(scale_type='vast_2')
+    # 'vast_2/3/4' (:147-157) put scipy's per-COLUMN kurtosis (m values) into a slice of n_points rows: the reference itself
+    # fails with NumPy's broadcast ValueError unless m == n_points (or m == 1) -- same type and text here (checked against
+    # the imported reference: 'could not broadcast input array from shape (5,) into shape (10,)')
+    for st in ('vast_2', 'vast_3', 'vast_4'):
+        with pytest.raises(ValueError, match=r'could not broadcast input array from shape \(5,\) into shape \(10,\)'):
+            spr.fit(scale_type=st)
+    sq = SPR(np.random.default_rng(2).random((10, 5)) + 1, 2, None, engine=NumpyEngine())      # n_points == m: defined there,
+    with pytest.raises(NotImplementedError):                                                   # no device implementation here
+        sq.fit(scale_type='vast_2')
     with pytest.raises(NotImplementedError):
         spr.fit(scale_type='bogus')                    # :164
     with pytest.raises(NotImplementedError):
@@ -455,3 +462,67 @@ def test_top_r_route_falls_back(monkeypatch):
     b = SPR(X, 2, None, engine=NumpyEngine())
     b.fit(select_modes='number', n_modes=12)
     assert b.r == 12 and np.abs(b.Ur.T @ b.Ur - np.eye(12)).max() < 1e-10
+
+
+def _offset_data(axis_cnt, seed=5):
+    """Fields whose centre dwarfs their fluctuation (pressure / temperature): row means 1e6 x the fluctuation and different from
+    row to row (axis_cnt = 1); a block mean 1e7 x the block's spread (axis_cnt = None)."""
+    rng = np.random.default_rng(seed)
+    n_points, F, m = 600, 2, 24
+    n = n_points * F
+    fl = rng.standard_normal((n, 8)) @ ((0.7 ** np.arange(8))[:, None] * rng.standard_normal((8, m))) + 1e-3 * rng.standard_normal((n, m))
+    if axis_cnt == 1:
+        return 1e6 * (1.0 + rng.random((n, 1))) + fl, F
+    return 1e7 + fl, F
+
+
+@pytest.mark.parametrize('axis_cnt', [1, None])
+def test_fit_chooses_the_precentred_projection_on_large_offsets(axis_cnt):
+    """the safeguard has to compare the centre the projection's epilogue cancels with what is left AFTER the
+    cancellation -- the rows' own fluctuation for row centring (the block std contains the spread of the row means and hid
+    a ratio of 1e6 behind a 5), the block's spread for scalar centring (where the safeguard used to be switched off)."""
+    X, F = _offset_data(axis_cnt)
+    spr = SPR(X, F, None, engine=NumpyEngine())
+    spr.fit(axis_cnt=axis_cnt, select_modes='number', n_modes=6)
+    assert spr.precentered_ is True
+    assert spr._pc_ratio.max() > 1e5
+    Y, _ = _offset_data(axis_cnt)
+    Y = Y - Y.mean(axis=1, keepdims=True) if axis_cnt == 1 else Y - 1e7            # the same fluctuation without the offset
+    ref = SPR(np.ascontiguousarray(Y + 0.0), F, None, engine=NumpyEngine())
+    ref.fit(axis_cnt=axis_cnt, select_modes='number', n_modes=6)
+    assert ref.precentered_ is False
+
+
+def test_rank_beyond_the_kernel_cap_is_a_value_error(monkeypatch):
+    """r > SPR_MAX_R_WIDE retained modes: fit and reconstruct take them (:336 slices any r <= m); the placement and solve
+    kernels do not -- a ValueError naming the cap, before any device work, instead of a failure inside the engine."""
+    import openmeasure_amd.sparse_sensing as ss
+    monkeypatch.setattr(ss, 'SPR_MAX_R_WIDE', 6)
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((60, 12))
+    spr = SPR(X, 2, rng.random((30, 3)), engine=NumpyEngine())
+    spr.fit(select_modes='number', n_modes=8)
+    assert spr.reconstruct(spr.Ar[0]).shape == (60, 1)
+    for call in (spr.optimal_placement, lambda: spr.optimal_placement(calc_type='gem', n_sensors=3)):
+        with pytest.raises(ValueError, match='exceed the 6 '):
+            call()
+    spr.fit(select_modes='number', n_modes=6)
+    C = spr.optimal_placement()
+    spr.train(C)
+    spr.r = 8                                                       # a predict on a basis beyond the cap
+    with pytest.raises(ValueError, match='exceed the 6 '):
+        spr._solve([np.zeros((6, 3))])
+
+
+def test_one_hot_rows_scalar_index_out_of_range():
+    """C[i, j] with j outside [-n, n) raises like the dense ndarray it stands in for."""
+    from openmeasure_amd.sparse_sensing import OneHotRows
+    C = OneHotRows([3, 7], 10)
+    dense = np.asarray(C)
+    for j in (-10, -1, 0, 3, 9):
+        assert C[0, j] == dense[0, j] and C[1, j] == dense[1, j]
+    for j in (10, 12, -11):
+        with pytest.raises(IndexError):
+            dense[1, j]
+        with pytest.raises(IndexError):
+            C[1, j]

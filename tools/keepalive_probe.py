@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Does a keep-alive kernel in the host gap of fit() pay?  (GPU box.)
+"""Does a keep-alive kernel in the host gap of fit() pay?  (GPU box; round-4 record in profiles/r04_gap_filler_probe.txt.)
+The spinner variants need the lab kernel tools/lab/keepalive.hip built into the library (see its header); without it only the
+idle / real-kernel-filler variants run.
 
 One rank's block of BASELINE config 4 at N = 8 (11.25M rows x 256): the step's kernel sequence
 Gram -> [3 ms host gap] -> projection -> reconstruct, repeated, each kernel timed with events, for the gap left idle and
@@ -13,6 +15,7 @@ from openmeasure_amd.engine import HipEngine
 from openmeasure_amd.synth import make_R
 
 eng = HipEngine()
+HAVE_SPINNER = hasattr(eng, 'keepalive_start')
 cells, F, m, r = 1_250_000, 9, 256, 64
 n = cells * F
 gap_ms = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
@@ -81,5 +84,7 @@ for rep in range(2):
                                          ('real Gram slice 2.9 ms as filler', 0, gap_ms, False, 2),
                                          ('Gram slice 2.5 ms + keep-alive mfma', 0, gap_ms, False, 3),
                                          ('real projection slice 2.6 ms as filler', 0, gap_ms, False, 4)):
+        if (mode or filler == 3) and not HAVE_SPINNER:
+            continue
         g, gp, p, rc, tot = run(mode, gap, pre, filler)
         print(f'{name:38s} gram {g:7.3f}  gap {gp:6.3f}  project {p:6.3f}  reconstruct {rc:6.3f}  total {tot:7.3f} ms', flush=True)

@@ -1,4 +1,7 @@
-// Clock keep-alive for the host gap of fit().
+// Clock keep-alive for the host gap of fit() -- LAB COPY, not part of libspr_hip.so.  Round 4 measured it against re-queuing the
+// real Gram kernel into the gap (ROM.gap_filler): the spinner recovers 0.45-0.55 ms of the 0.9-1.2 ms the kernels of a step lose
+// behind a 3 ms gap, the real kernel 0.8-1.2 ms (profiles/r04_gap_filler_probe.txt), so the product ships the filler.  To probe it
+// again: add this file to SRCS in openmeasure_amd/csrc/Makefile, declare spr_keepalive_start in spr_hip.h / _lib.py.
 //
 // Between the Gram pass and the projection the device has nothing to do: the host downloads the m x m Gram matrix and
 // eigen-solves it (2.7 ms at m = 256, the reference's np.linalg.svd call site, sparse_sensing.py:272).  The chip lowers

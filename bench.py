@@ -49,6 +49,9 @@ WORKLOADS = {
     'c4': dict(cells=10_000_000, features=9, m=256, s=64, cpu_cells=100_000, scaling='strong'),
     'c3s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000),   # c3 at 1/10 of the rows
     'c4s': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000, scaling='strong'),   # c4 at 1/10 (rehearsals)
+    # config-3 shape at 1M cells with a designed sigma_1/sigma_s = 1e6: the conditioning refinement of fit() at scale
+    # (one more pass over X: projection onto all m first-stage vectors + Gram of the result), reported as refine_ms
+    'c3k': dict(cells=1_000_000, features=9, m=256, s=64, cpu_cells=100_000, ratio=1e6, eps=1e-9),
     # config-5 shape (16 features x 512 snapshots, 128 sensors) in f64 at 1M cells/GPU (65.5 GB): the column-split path
     'c5s': dict(cells=1_000_000, features=16, m=512, s=128, cpu_cells=15_000),
     # config 5 as BASELINE.json states it: 50M cells x 16 features x 512 snapshots over 8 GPUs = 6.25M cells (100M
@@ -321,10 +324,10 @@ def run_rank(args):
     else:
         plan = shard_plan(wl, world, rank, args.scaling)
     n_points, n_glob, n_loc, row0 = plan['n_points'], plan['n_glob'], plan['n_loc'], plan['row0']
-    seed, eps = 1234, 1e-3
+    seed, eps = 1234, wl.get('eps', 1e-3)
 
     eng = HipEngine(f'cuda:{local_rank}')
-    R = eng.to_device(make_R(m, s, seed=seed))
+    R = eng.to_device(make_R(m, s, seed=seed, ratio=wl.get('ratio', 1e3)))
     t0 = time.time()
     Xd = eng.synth(n_loc, m, row0, n_points, R, eps, seed, dtype=torch.float32 if f32 else None)
     torch.cuda.synchronize()
@@ -613,6 +616,16 @@ def run_rank(args):
                                         else round(ms_per_step, 4)),
             'headline_loop': 'sync gather' if (args.sync_gather or not dist_on) else 'gather overlaps the next Gram pass',
             'comm': comm,
+            **({'refine': dict(gram_refine_passes=int(spr.gram_refine_passes_), refine_ms=round(float(spr.refine_ms_), 3),
+                               refine_over_plain_gram=round(float(spr.refine_ms_) / k_ms['stats_gram'], 3),
+                               refine_device_ms=round(spr.refine_profile_['device_ms'], 3),
+                               refine_host_ms=round(spr.refine_profile_['host_ms'], 3),
+                               refine_host_pieces={k: round(v, 3) for k, v in spr.refine_profile_.items() if k.endswith('_ms') and k not in ('device_ms', 'host_ms')},
+                               sigma1_over_sigma_s=float(spr.Sigma_r[0] / spr.Sigma_r[-1]),
+                               note='fit() above sigma_1/sigma_r = 1e4: one more pass over X per refinement pass -- 2 n m^2 '
+                                    'flops of projection onto all m first-stage vectors + n m^2 of Gram, 3x the plain Gram '
+                                    'pass by flop count; refine_ms is host wall time of the whole refinement, inside ms_per_step')}
+               if getattr(spr, 'gram_refine_passes_', 0) else {}),
             'placement_ms': path['optimal_placement_ms'], 'train_ms': path['train_ms'], 'predict_ms': path['predict_ms'],
             'pivot_sweeps': path['pivot_sweeps'], 'min_pivot_gap': path['min_pivot_gap'], 'path': path,
             **({'rehearsal': f'{backend} backend, all ranks on one GPU: exercises the code path, measures nothing'}

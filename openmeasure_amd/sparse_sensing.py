@@ -1171,8 +1171,11 @@ class ROM:
         block = int(max(1 << 16, min(n_loc, (1 << 31) // (8 * (m + (m & 1))))))
         Y = eng.empty((min(block, n_loc), m + (m & 1)))
         passes = 0
+        import time
+        prof = self.refine_profile_ = dict(device_ms=0.0, host_ms=0.0)
         while True:
             passes += 1
+            t_a = time.perf_counter()
             floor = S[0] * np.sqrt(m * eps)
             d = np.maximum(S, floor if floor > 0 else 1.0)
             W2 = eng.to_device(V / d)
@@ -1186,19 +1189,30 @@ class ROM:
                 _, _, g = eng.stats_gram(Yb, 0, rows, 1, center=False)
                 H_d = g[0].clone() if H_d is None else H_d.add_(g[0])
             H = eng.to_host(self._all_reduce(H_d))
+            t_b = time.perf_counter()
             H = 0.5 * (H + H.T)
             lamH, Z = _eigh_small(H)
-            M = (np.sqrt(np.maximum(lamH, 0.0))[:, None] * Z.T) * d[None, :] @ V.T
-            _, S_new, Vt = np.linalg.svd(M)
+            t_c = time.perf_counter()
+            with _one_blas_thread():                           # m x m: a many-core BLAS pool only gets in the way
+                M = (np.sqrt(np.maximum(lamH, 0.0))[:, None] * Z.T) * d[None, :] @ V.T
+                t_d = time.perf_counter()
+                _, S_new, Vt = np.linalg.svd(M)
+            t_e = time.perf_counter()
+            prof['eigh_ms'] = prof.get('eigh_ms', 0.0) + 1e3 * (t_c - t_b)
+            prof['M_ms'] = prof.get('M_ms', 0.0) + 1e3 * (t_d - t_c)
+            prof['svd_ms'] = prof.get('svd_ms', 0.0) + 1e3 * (t_e - t_d)
             S_new, Vt = self._same_on_all_ranks(S_new, Vt)
+            prof['device_ms'] += 1e3 * (t_b - t_a)
             # is the pass converged?  The retained columns of Y must have come out nearly orthonormal.  Modes below
             # 1e-12 sigma_1 (the null mode that row-centring creates when all m modes are kept) are rounding noise
             # in the reference as well and are left out of the verdict.
             keep = np.flatnonzero(S_new[:r] > 1e-12 * S_new[0])
             dn = np.sqrt(np.maximum(np.diag(H), np.finfo(float).tiny))
-            ev = np.linalg.eigvalsh((H / dn[:, None] / dn[None, :])[np.ix_(keep, keep)])
+            with _one_blas_thread():
+                ev = np.linalg.eigvalsh((H / dn[:, None] / dn[None, :])[np.ix_(keep, keep)])
             cond_r = ev[-1] / max(ev[0], np.finfo(float).tiny)
             S, V = S_new, _sign_fix(Vt.T.copy())
+            prof['host_ms'] += 1e3 * (time.perf_counter() - t_b)
             if cond_r < 4.0:                                   # |off-diagonal| of the retained block well below 1
                 break
             if passes >= _GRAM_REFINE_MAX_PASSES:
@@ -1219,9 +1233,12 @@ class ROM:
         r = self._select_rank(exp_variance, m, select_modes, n_modes)
         self.gram_refine_passes_ = 0
         if S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
+            import time
+            t_ref = time.perf_counter()
             S, V, exp_variance, self.gram_refine_passes_ = self._refine_spectrum(
                 S, V, r, Xd, self._row0, self.n_points, self.n_features, inv_scale_d, self._d.get('rowmean'), center)
             r = self._select_rank(exp_variance, m, select_modes, n_modes)
+            self.refine_ms_ = 1e3 * (time.perf_counter() - t_ref)      # host wall time of the refinement (it synchronises)
             self._trace.mark('refine')
         # modes below sqrt(m eps) sigma_1 carry no information on the Gram route; keep the
         # projection finite for them (their reference counterparts are LAPACK rounding noise)

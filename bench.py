@@ -541,6 +541,29 @@ def run_rank(args):
                      pivot_sweeps_without_row_norms=int(spr.pivot_sweeps_))
         del spr.placement_norms                                # back to the class default
         fit_only()
+        # The reference's output contract: reconstruct() returns a HOST (n, n_p) ndarray (:371-375).  One vector and eight;
+        # the field leaves in row chunks whose D2H copies overlap the next chunk's kernel (engine.reconstruct_to_host)
+        a_host = spr.Ar[:1].copy()
+        A8 = np.vstack([a_host * (1.0 + 0.01 * j) for j in range(8)])
+        x1 = spr.reconstruct(a_host)
+        assert x1.shape == (n_glob if not share else n_loc, 1)
+        t_h1 = timed3(lambda: spr.reconstruct(a_host))
+        del x1
+        x8 = spr.reconstruct(A8)
+        t_h8 = timed3(lambda: spr.reconstruct(A8))
+        nb1 = float(x8.shape[0]) * 8
+        del x8
+        extra.update(reconstruct_to_host_ms=round(t_h1, 3), reconstruct_to_host_GBs=round(nb1 / t_h1 / 1e6, 1),
+                     reconstruct_to_host_8_ms=round(t_h8, 3), reconstruct_to_host_8_GBs=round(8 * nb1 / t_h8 / 1e6, 1),
+                     reconstruct_device_only_ms=round(k_ms['reconstruct'], 3))
+        # ... and its input contract: X handed over as a host ndarray (:74); rate of the upload on a 2 GB sample
+        hs = np.ones((min(n_loc, 4_000_000), 64))
+        eng.to_device(hs[:1024])
+        barrier(); t_a = time.perf_counter()
+        hd = eng.to_device(hs)
+        barrier(); t_up = time.perf_counter() - t_a
+        extra.update(upload_GBs=round(hs.nbytes / t_up / 1e9, 1), upload_sample_GB=round(hs.nbytes / 1e9, 2))
+        del hd, hs
 
     cpu = None
     parity = None

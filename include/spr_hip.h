@@ -277,6 +277,12 @@ int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t l
                         const double *d_rowmean, const double *d_scale, const double *d_rowscale,
                         const double *d_A, int32_t n_p, double *d_Xrec, int64_t ldo,
                         void *stream);
+/* Sharded reconstruct() with n_p > 1 coefficient vectors: the one all-gather of the ranks' (n_p, n_loc) result blocks
+ * leaves d_stage[world][n_p][n_loc]; this copies it into the layout the reference returns (:371-375: the vectors as columns
+ * of the WHOLE field), d_out[v * ldo + q * n_loc + i] = d_stage[q][v][i].  (One vector needs nothing: the staged blocks are
+ * the field.) */
+int spr_field_unstage_f64(const double *d_stage, int32_t world, int32_t n_p, int64_t n_loc, double *d_out, int64_t ldo,
+                          void *stream);
 
 /* ---- K6 : QR column pivoting of Ur^T (sensor selection) -----------------------------
  * Replaces scipy.linalg.qr(Ur.T, pivoting=True) (:739) -- only the first s pivots are

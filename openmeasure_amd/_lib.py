@@ -64,6 +64,7 @@ PROTOTYPES = {
     'spr_colsums_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     'spr_fill_feature_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p]),
     'spr_reconstruct_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p]),
+    'spr_field_unstage_f64': (C.c_int, [_p, _i32, _i32, _i64, _p, _i64, _p]),
     'spr_qr_workspace': (_sz, [_i64]),
     'spr_qr_workspace_r': (_sz, [_i64, _i32]),
     'spr_qr_batch': (_i32, []),

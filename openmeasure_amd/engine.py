@@ -100,7 +100,7 @@ class HipEngine:
         t = t.detach()
         nbytes = t.numel() * t.element_size()
         if nbytes == 0 or nbytes > self._HOST_STAGE_BYTES or not t.is_cuda:
-            out = t.cpu().numpy()
+            out = self._to_host_big(t) if (t.is_cuda and nbytes) else t.cpu().numpy()
             if then is not None:
                 then()
             return out
@@ -115,6 +115,93 @@ class HipEngine:
             then()
         self._dstage_ev.synchronize()
         return buf.numpy().copy()
+
+    _PINNED_RESULT_BYTES = 8 << 30
+
+    def _pinned_result(self, shape, dtype):
+        """A page-locked host tensor for a big result, or None when it cannot be had (then the pageable copy runs).
+        PyTorch caches page-locked blocks: the first result of a size pays the pinning (59 ms for 720 MB), later ones
+        reuse the blocks earlier results have returned."""
+        torch = self.torch
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        if nbytes > self._PINNED_RESULT_BYTES:
+            return None
+        try:
+            return torch.empty(shape, dtype=dtype, pin_memory=True)
+        except RuntimeError:
+            return None
+
+    def _to_host_big(self, t):
+        """Results above 64 MiB -- the (n, n_p) field reconstruct() returns to the caller, sparse_sensing.py:371-375 -- land in
+        a page-locked tensor of their own, one asynchronous copy at the PCIe rate (57 GB/s against 10 GB/s into pageable
+        memory, tools/transfer_probe.py); the ndarray handed back is that memory."""
+        torch = self.torch
+        h = self._pinned_result(tuple(t.shape), t.dtype)
+        if h is None:
+            return t.cpu().numpy()
+        h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ev.synchronize()
+        return h.numpy()
+
+    def reconstruct_to_host(self, Ur, row0, n_points, n_features, rowmean, scale, A, chunks=8):
+        """reconstruct() with the reference's output contract: the field as a HOST array.  -> ndarray (n_p, n) in
+        page-locked memory, or None when that memory cannot be had / the result is small (callers then take
+        reconstruct() + to_host()).  The rows go in `chunks` launches; each chunk's D2H copy runs on a side stream under
+        the next chunk's kernel, so the call costs about max(kernel, PCIe) instead of their sum."""
+        torch = self.torch
+        n, r, ldu = self._check_matrix(Ur)
+        n_p = A.shape[0]
+        if n * n_p * 8 <= self._HOST_STAGE_BYTES or rowmean.shape[0] != n:
+            return None
+        host = self._pinned_result((n_p, n), torch.float64)
+        if host is None:
+            return None
+        out = self.empty((n_p, n))
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        main = torch.cuda.current_stream(self.device)
+        rows = -(-n // max(1, int(chunks)))
+        rows = max(1 << 16, (rows + 4095) // 4096 * 4096)
+        for i0 in range(0, n, rows):
+            i1 = min(n, i0 + rows)
+            self.reconstruct(Ur[i0:i1], row0 + i0, n_points, n_features, rowmean[i0:i1], scale, A, out=out[:, i0:i1])
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                for v in range(n_p):                          # contiguous pieces: a strided 2-D copy runs at a tenth of the rate
+                    host[v, i0:i1].copy_(out[v, i0:i1], non_blocking=True)
+        out.record_stream(self._side)
+        self._side.synchronize()
+        return host.numpy()
+
+    def field_unstage(self, stage, out=None):
+        """stage (world, n_p, n_loc) as the all-gather left it -> (n_p, world * n_loc), the vectors side by side
+        (spr_field_unstage_f64)."""
+        world, n_p, n_loc = stage.shape
+        if out is None:
+            out = self.empty((n_p, world * n_loc))
+        _lib.check(self.lib.spr_field_unstage_f64(_ptr(stage.contiguous()), world, n_p, n_loc, _ptr(out), out.stride(0),
+                                                  self._stream()), 'spr_field_unstage_f64')
+        return out
+
+    def stage_to_host(self, stage):
+        """The same re-arrangement on the way to the host: block (q, v) of the staged field is copied straight to its place
+        in a page-locked (n_p, world * n_loc) result -- no pass over the field on the device.  None: no pinned memory."""
+        torch = self.torch
+        world, n_p, n_loc = stage.shape
+        host = self._pinned_result((n_p, world * n_loc), stage.dtype)
+        if host is None:
+            return None
+        for q in range(world):
+            for v in range(n_p):                              # contiguous pieces (see reconstruct_to_host)
+                host[v, q * n_loc:(q + 1) * n_loc].copy_(stage[q, v], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ev.synchronize()
+        return host.numpy()
 
     def timing_event(self):
         """An event recorded NOW on the current stream; pairs are read with elapsed_ms() after a synchronisation."""

@@ -1422,6 +1422,13 @@ class ROM:
         n_p = A_d.shape[0]
         world = self._world()
         if not self._dist():
+            if to_host and hasattr(eng, 'reconstruct_to_host'):
+                # the reference's contract (:371-375): a host ndarray.  Big fields go out in row chunks whose copies run
+                # under the next chunk's kernel, into page-locked memory (engine.reconstruct_to_host)
+                host = eng.reconstruct_to_host(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
+                                               self._d['scale'], A_d)
+                if host is not None:
+                    return host.T
             out = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
                                   self._d['scale'], A_d)
         else:
@@ -1429,7 +1436,9 @@ class ROM:
             loc = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
                                   self._d['scale'], A_d)
             # ONE all-gather for all n_p columns: rank q's (n_p, n_loc) block lands at stage[q]; for one column that is
-            # the field itself, for several the columns are put side by side afterwards (a device-side permute)
+            # the field itself, for several the columns are put side by side afterwards -- on the way to the host when
+            # the caller wants a host array (block copies, no pass over the field on the device), by
+            # spr_field_unstage_f64 when the field stays in HBM
             stage = eng.empty((world, n_p, n_loc))
             close = self._comm_bracket('gather')              # issue -> join, when the join happens inside this call
             work = dist.all_gather_into_tensor(stage.view(-1), loc.contiguous().view(-1), group=self._shard.group,
@@ -1444,7 +1453,11 @@ class ROM:
             else:
                 work.wait()
                 close()
-                out = stage.permute(1, 0, 2).reshape(n_p, world * n_loc)
+                if to_host and hasattr(eng, 'stage_to_host'):
+                    host = eng.stage_to_host(stage)
+                    if host is not None:
+                        return host.T
+                out = eng.field_unstage(stage)
                 if not to_host and not wait:
                     return PendingField(out)
         if not to_host:

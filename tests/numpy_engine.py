@@ -145,6 +145,10 @@ class NumpyEngine:
         return torch.from_numpy(np.ascontiguousarray(x.T))
 
     # K6
+    def field_unstage(self, stage, out=None):
+        world, n_p, n_loc = stage.shape
+        return stage.permute(1, 0, 2).reshape(n_p, world * n_loc).contiguous()
+
     def mask_rows(self, Ur, mask_u8):
         Ur[mask_u8 == 0, :] = 0.0
 

@@ -1546,3 +1546,44 @@ def test_predict_failure_modes_on_the_device(eng, r, s_extra):
     # the object is still usable afterwards
     a_again, _ = spr.predict(y)
     np.testing.assert_array_equal(a_again, a_ok)
+
+
+@pytest.mark.parametrize('n,r,n_p', [(9_000_123, 8, 1), (3_100_001, 16, 3)])
+def test_reconstruct_to_host_in_chunks(eng, n, r, n_p):
+    """The reference's output contract (:371-375: a host (n, n_p) ndarray) for fields above 64 MiB: row chunks whose D2H
+    copies overlap the next chunk's kernel, landing in page-locked memory -- bit for bit the field the one-launch path
+    leaves in HBM, features straddling the chunk boundaries."""
+    import torch
+    from openmeasure_amd.sparse_sensing import SPR
+    g = torch.Generator(device='cuda').manual_seed(n)
+    F = 3
+    n_points = n // F
+    n = n_points * F
+    Ur = torch.randn((n, r), generator=g, dtype=torch.float64, device='cuda')
+    rowmean = torch.randn((n,), generator=g, dtype=torch.float64, device='cuda')
+    scale = eng.to_device(np.array([1.5, 0.25, 3.0]))
+    A = eng.to_device(np.random.default_rng(r).standard_normal((n_p, r)))
+    dev = eng.reconstruct(Ur, 0, n_points, F, rowmean, scale, A)
+    host = eng.reconstruct_to_host(Ur, 0, n_points, F, rowmean, scale, A, chunks=5)
+    assert host is not None and host.shape == (n_p, n)
+    np.testing.assert_array_equal(host, dev.cpu().numpy())
+    # through the class: reconstruct() returns the (n, n_p) array of the reference
+    spr = SPR(np.zeros((F * 4, 2)), F, None, engine=eng)
+    spr.__dict__.update(_n_global=n, n_points=n_points, r=r)
+    spr._d.update(Ur=Ur, rowmean=rowmean, scale=scale)
+    out = spr.reconstruct(eng.to_host(A))
+    assert out.shape == (n, n_p)
+    np.testing.assert_array_equal(out, host.T)
+    # small results keep the one-launch path
+    assert eng.reconstruct_to_host(Ur[:1000], 0, n_points, F, rowmean[:1000], scale, A) is None
+
+
+def test_field_unstage_kernel(eng):
+    """spr_field_unstage_f64: the staged blocks of a sharded multi-vector reconstruct() -> the vectors side by side."""
+    import torch
+    for world, n_p, n_loc in ((2, 3, 1001), (4, 2, 4096), (3, 5, 7)):
+        st = torch.randn((world, n_p, n_loc), dtype=torch.float64, device='cuda')
+        out = eng.field_unstage(st)
+        assert torch.equal(out, st.permute(1, 0, 2).reshape(n_p, world * n_loc))
+        host = eng.stage_to_host(st)
+        np.testing.assert_array_equal(host, out.cpu().numpy())

@@ -267,6 +267,11 @@ class PendingField:
     def shape(self):
         return tuple(self._tensor.shape)
 
+    @property
+    def pending(self):
+        """True while the gather has not been joined."""
+        return bool(self._works)
+
     def wait(self):
         if self._works and self._on_wait is not None:
             done = self._on_wait()
@@ -382,6 +387,7 @@ def _eigvecs_top(fac, lam, r):
     isplit = np.zeros(m, dtype=np.int32)
     isplit[0] = m
     with _one_blas_thread():
+        # (splitting the eigenvalue list over a few threads gained nothing on the GPU host: 1.02 -> 1.09 ms, round 4)
         z, info = lapack.dstein(d, e, w, iblock, isplit)
         if info != 0:
             return None
@@ -878,13 +884,19 @@ class ROM:
         ev = self.__dict__.pop('_gram_events', None)
         rate = self.__dict__.get('_gram_rows_per_ms')
         self._gap_fill_rows = 0
+        self._gram_events_pending = ev
+        # A field all-gather left in flight by the previous reconstruct(wait=False) cannot run NEXT TO the Gram or projection
+        # workgroups (RCCL's kernel wants 261-280 VGPRs per wave and 19.7 KB of LDS; two Gram waves hold 448 of a SIMD's 512
+        # registers, two projection waves all of them): its window is this very gap, so it stays empty
+        pf = self.__dict__.get('_pending_field')
+        if pf is not None and pf.pending:
+            return
         if hist and rate:
             rows = int(self._GAP_FILL_FRACTION * min(hist) * rate) // 4096 * 4096
             rows = min(rows, Xd.shape[0])
             if rows >= 65536:
                 eng.gram_filler(Xd, rows, self._row0, self.n_points, self.n_features)
                 self._gap_fill_rows = rows
-        self._gram_events_pending = ev
 
     def _close_gap(self):
         """The projection is about to be launched: record the host gap this fit() had, and the rate of its Gram pass."""
@@ -1446,8 +1458,10 @@ class ROM:
             if n_p == 1:
                 out = stage.view(1, world * n_loc)
                 if not to_host and not wait:
-                    return PendingField(out, [work], keep=(loc, stage),
-                                        on_wait=lambda: self._comm_bracket('gather_exposed'))
+                    pf = PendingField(out, [work], keep=(loc, stage),
+                                      on_wait=lambda: self._comm_bracket('gather_exposed'))
+                    self._pending_field = pf                  # fit() leaves its host gap free while this is in flight
+                    return pf
                 work.wait()
                 close()
             else:

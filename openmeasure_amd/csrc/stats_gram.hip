@@ -304,6 +304,8 @@ __device__ inline void gram_wave_own(const TX *__restrict__ X, int64_t ldx, int6
     const bool nfull = nrow0 + R <= hi;                    // wave-uniform
     if (GRAM_ABLATE != 4) __syncthreads();               // GRAM_ABLATE=4 (diagnostic, wrong results): what the panel barrier costs
     const double *p = cur + frag;
+    // (Round 4 measured a staggered slot for the SIMD partners -- units >= 4 staging half a panel later, same barrier: 9.53
+    // vs 9.56 ms per 18.4 GB and 48.24 vs 48.21 ms per 92 GB, i.e. nothing: profiles/r04_gram_stage_stagger_ab.txt.)
     auto stage = [&](auto full_tag, int k) {
       constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll

@@ -93,9 +93,31 @@ def _synth_worker(rank, world, port, cells, F, m, s_, out_dir):
         spr.fit(select_modes='number', n_modes=s_)
         spr.optimal_placement()
         x = spr.reconstruct(spr.Ar[:1], to_host=False, wait=False).wait()
+        first = eng.to_host(x)[0].copy()
+        # round 4: the step loop of bench.py in both forms, with the collective brackets on -- gather left in flight (the gap
+        # filler of fit() must stay out of the gap the gather needs) and joined inside the step (the filler runs)
+        spr.comm_timing = {}
+        a_d = eng.to_device(spr.Ar[:1].copy())
+        fills = {}
+        for sync in (False, True):
+            prev, rows = None, []
+            for _ in range(4):
+                spr.fit(select_modes='number', n_modes=s_)
+                rows.append(int(spr._gap_fill_rows))
+                if prev is not None and hasattr(prev, 'wait'):
+                    prev.wait()
+                prev = spr.reconstruct(a_d, to_host=False, wait=sync)
+            last = prev.wait() if hasattr(prev, 'wait') else prev
+            fills['sync' if sync else 'pipelined'] = rows
+        torch.cuda.synchronize()
+        comm = {k: [eng.elapsed_ms(e0, e1) for e0, e1 in v] for k, v in spr.comm_timing.items()}
         if rank == 0:
-            np.savez(os.path.join(out_dir, 'dist.npz'), piv=spr.sensors_, S=spr.S_, field=eng.to_host(x)[0], a=spr.Ar[0],
-                     sign=np.sign(spr.Ar[0]), pool_sweeps=spr.pivot_pool_sweeps_, sweeps=spr.pivot_sweeps_)
+            np.savez(os.path.join(out_dir, 'dist.npz'), piv=spr.sensors_, S=spr.S_, field=first, a=spr.Ar[0],
+                     sign=np.sign(spr.Ar[0]), pool_sweeps=spr.pivot_pool_sweeps_, sweeps=spr.pivot_sweeps_,
+                     fills_pipelined=fills['pipelined'], fills_sync=fills['sync'], field_last=eng.to_host(last)[0],
+                     n_allreduce=len(comm['allreduce']), n_gather=len(comm.get('gather', [])),
+                     n_exposed=len(comm.get('gather_exposed', [])),
+                     min_ms=min(min(v) for v in comm.values()))
     finally:
         dist.destroy_process_group()
 
@@ -126,5 +148,13 @@ def test_config4_shaped_shards_four_ranks_one_gpu(tmp_path):
     ref = eng.to_host(one.reconstruct(one.Ar[:1] * 1.0, to_host=False))[0]
     # the same coefficient vector in each run's own sign convention reconstructs the same field
     assert np.linalg.norm(d['field'] - ref) <= 1e-12 * np.linalg.norm(ref)
+    # the refits of the step loops (gap filler on or off, gather pending or joined) reproduce the same field ...
+    assert np.linalg.norm(d['field_last'] - ref) <= 1e-12 * np.linalg.norm(ref)
+    # ... the filler stays out of the host gap while a gather is in flight (every fit of the pipelined loop but the first
+    # had a PendingField behind it) and fills it in the sync loop once there is a gap history
+    assert list(d['fills_pipelined'][1:]) == [0, 0, 0], d['fills_pipelined']
+    assert d['fills_sync'][-1] >= 65536, d['fills_sync']
+    # ... and every collective was bracketed: one all-reduce per fit, the gather where it was joined
+    assert int(d['n_allreduce']) == 8 and int(d['n_gather']) == 4 and int(d['n_exposed']) == 4 and float(d['min_ms']) >= 0.0
     del Xd, one
     torch.cuda.empty_cache()

@@ -31,7 +31,8 @@
  *   SPR_QR_DIRECT=0           spr_qr_init_* / spr_qr_refresh_*: LDS-panel sweeps only
  *   SPR_QR_FUSED_STEPS=0      spr_qr_steps_f64: three launches per candidate step instead of the fused one
  * and by the Python layer (openmeasure_amd/): SPR_PROJECT_STREAM=1 (streamed-W projection for every shape),
- * SPR_GAP_FILLER=0 (no filler launch in fit()'s host gap, ROM.gap_filler), SPR_TRACE=1 (per-phase wall clock of fit(),
+ * SPR_GAP_FILLER=0 (no filler launch in fit()'s host gap, ROM.gap_filler), SPR_PINNED_RESULT_GB=<g> (budget of page-locked
+ * memory for host results still alive, default 8; 0 = pageable copies only), SPR_TRACE=1 (per-phase wall clock of fit(),
  * synchronising), SPR_HIP_LIBRARY=<path> (another build of this library).  None of them is needed in production.
  */
 #ifndef SPR_HIP_H

@@ -116,20 +116,42 @@ class HipEngine:
         self._dstage_ev.synchronize()
         return buf.numpy().copy()
 
-    _PINNED_RESULT_BYTES = 8 << 30
+    _PINNED_RESULT_BYTES = 8 << 30      # page-locked memory handed out as results and still alive, at most (SPR_PINNED_RESULT_GB)
 
     def _pinned_result(self, shape, dtype):
         """A page-locked host tensor for a big result, or None when it cannot be had (then the pageable copy runs).
         PyTorch caches page-locked blocks: the first result of a size pays the pinning (59 ms for 720 MB), later ones
-        reuse the blocks earlier results have returned."""
+        reuse the blocks earlier results have returned.  Page-locked memory is a machine-wide resource: the results
+        still referenced by the caller are counted (weak references to the ndarrays handed out, _export_pinned) and a new
+        one is only pinned while the total stays under the budget."""
+        import os
         torch = self.torch
         nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-        if nbytes > self._PINNED_RESULT_BYTES:
+        budget = self._PINNED_RESULT_BYTES
+        env = os.environ.get('SPR_PINNED_RESULT_GB')
+        if env is not None:
+            try:
+                budget = int(float(env) * (1 << 30))
+            except ValueError:
+                pass
+        live = getattr(self, '_pinned_live', None)
+        if live is None:
+            live = self._pinned_live = []
+        live[:] = [(w, b) for w, b in live if w() is not None]
+        if nbytes + sum(b for _, b in live) > budget:
             return None
         try:
             return torch.empty(shape, dtype=dtype, pin_memory=True)
         except RuntimeError:
             return None
+
+    def _export_pinned(self, h):
+        """The ndarray view of a page-locked result tensor, registered with the budget of _pinned_result: the array (and
+        every view the caller takes of it) keeps the memory alive, so its own life is what is counted."""
+        import weakref
+        arr = h.numpy()
+        self._pinned_live.append((weakref.ref(arr), h.numel() * h.element_size()))
+        return arr
 
     def _to_host_big(self, t):
         """Results above 64 MiB -- the (n, n_p) field reconstruct() returns to the caller, sparse_sensing.py:371-375 -- land in
@@ -143,7 +165,7 @@ class HipEngine:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         ev.synchronize()
-        return h.numpy()
+        return self._export_pinned(h)
 
     def reconstruct_to_host(self, Ur, row0, n_points, n_features, rowmean, scale, A, chunks=8):
         """reconstruct() with the reference's output contract: the field as a HOST array.  -> ndarray (n_p, n) in
@@ -175,7 +197,7 @@ class HipEngine:
                     host[v, i0:i1].copy_(out[v, i0:i1], non_blocking=True)
         out.record_stream(self._side)
         self._side.synchronize()
-        return host.numpy()
+        return self._export_pinned(host)
 
     def field_unstage(self, stage, out=None):
         """stage (world, n_p, n_loc) as the all-gather left it -> (n_p, world * n_loc), the vectors side by side
@@ -201,7 +223,7 @@ class HipEngine:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         ev.synchronize()
-        return host.numpy()
+        return self._export_pinned(host)
 
     def timing_event(self):
         """An event recorded NOW on the current stream; pairs are read with elapsed_ms() after a synchronisation."""

@@ -1587,3 +1587,25 @@ def test_field_unstage_kernel(eng):
         assert torch.equal(out, st.permute(1, 0, 2).reshape(n_p, world * n_loc))
         host = eng.stage_to_host(st)
         np.testing.assert_array_equal(host, out.cpu().numpy())
+
+
+def test_pinned_result_budget(eng, monkeypatch):
+    """Host results above 64 MiB are page-locked memory; the ones the caller still holds are counted against a budget and a
+    result beyond it falls back to the pageable copy -- same values either way."""
+    import torch
+    t = torch.arange(10_000_000, dtype=torch.float64, device='cuda')          # 80 MB
+    monkeypatch.setenv('SPR_PINNED_RESULT_GB', '0.1')
+    a = eng.to_host(t)
+    assert len([1 for w, _ in eng._pinned_live if w() is not None]) >= 1
+    b = eng.to_host(t)                                                        # 160 MB alive > 0.1 GiB: pageable
+    n_live = len([1 for w, _ in eng._pinned_live if w() is not None])
+    np.testing.assert_array_equal(a, b)
+    del a
+    c = eng.to_host(t)                                                        # the first one was released: pinned again
+    assert len([1 for w, _ in eng._pinned_live if w() is not None]) == n_live
+    np.testing.assert_array_equal(b, c)
+    monkeypatch.setenv('SPR_PINNED_RESULT_GB', '0')
+    before = len(eng._pinned_live)
+    d = eng.to_host(t)
+    assert len([1 for w, _ in eng._pinned_live if w() is not None]) <= before
+    np.testing.assert_array_equal(d, c)

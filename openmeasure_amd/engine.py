@@ -160,12 +160,59 @@ class HipEngine:
         torch = self.torch
         h = self._pinned_result(tuple(t.shape), t.dtype)
         if h is None:
-            return t.cpu().numpy()
+            return self._to_host_staged(t)
         h.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         ev.synchronize()
         return self._export_pinned(h)
+
+    _STAGED_CHUNK = 64 << 20
+
+    def _to_host_staged(self, t, out=None):
+        """A result that may not be page-locked as a whole (the 46 GB basis of config 3 read as `spr.Ur`, a field beyond the
+        budget): into an ordinary ndarray through two page-locked 64 MiB buffers -- DMA into one on a side stream while
+        four threads copy the other out (28 GB/s against the 10 GB/s of a pageable tensor.cpu(), tools/transfer_probe.py).
+        ``out``: a C-contiguous ndarray of t's shape and dtype to fill (e.g. a block of a larger result)."""
+        torch = self.torch
+        from concurrent.futures import ThreadPoolExecutor
+        t = t.contiguous()
+        flat = t.view(-1)
+        n = flat.numel()
+        res = np.empty(tuple(t.shape), dtype=torch.empty((), dtype=t.dtype).numpy().dtype) if out is None else out
+        dst = res.reshape(-1)
+        if getattr(self, '_dstage2', None) is None:
+            self._dstage2 = [torch.empty(self._STAGED_CHUNK, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._copy_pool = ThreadPoolExecutor(4, thread_name_prefix='spr-d2h')
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        ch = self._STAGED_CHUNK // flat.element_size()
+        pend = [[], []]
+        k = 0
+        for i0 in range(0, n, ch):
+            i1 = min(n, i0 + ch)
+            for f in pend[k & 1]:                             # the slot's previous contents have been copied out
+                f.result()
+            stage = self._dstage2[k & 1][:(i1 - i0) * flat.element_size()].view(t.dtype)
+            with torch.cuda.stream(self._side):
+                stage.copy_(flat[i0:i1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            ev.synchronize()
+            src = stage.numpy()
+            q = -(-(i1 - i0) // 4)
+            pend[k & 1] = [self._copy_pool.submit(np.copyto, dst[i0 + j * q:min(i1, i0 + (j + 1) * q)],
+                                                  src[j * q:min(i1 - i0, (j + 1) * q)]) for j in range(4) if j * q < i1 - i0]
+            k += 1
+        for fs in pend:
+            for f in fs:
+                f.result()
+        t.record_stream(self._side)
+        return res
 
     def reconstruct_to_host(self, Ur, row0, n_points, n_features, rowmean, scale, A, chunks=8):
         """reconstruct() with the reference's output contract: the field as a HOST array.  -> ndarray (n_p, n) in

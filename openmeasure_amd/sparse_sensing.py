@@ -737,10 +737,23 @@ class ROM:
         """(n_local, m) centred/scaled matrix (:169, :492); built on first access only."""
         def make():
             eng = self._engine()
-            t = eng.scale_rows(self._Xd(), self._row0, self.n_points, self.n_features, self._fitted('rowmean', 'X0'),
-                               self._d['inv_scale'])
-            return eng.to_host(t)
+            Xd, rowmean = self._Xd(), self._fitted('rowmean', 'X0')
+            n, m = Xd.shape
+            block = max(1, self._X0_BLOCK_BYTES // (8 * m))
+            if n <= block or not hasattr(eng, '_to_host_staged'):
+                return eng.to_host(eng.scale_rows(Xd, self._row0, self.n_points, self.n_features, rowmean, self._d['inv_scale']))
+            # a scaled copy of a big X does not fit next to it in HBM (184 + 184 GB at BASELINE config 3): row blocks, each
+            # scaled into a scratch block and streamed to its place in the host array
+            out = np.empty((n, m), dtype=np.float64)
+            for i0 in range(0, n, block):
+                i1 = min(n, i0 + block)
+                t = eng.scale_rows(Xd[i0:i1], self._row0 + i0, self.n_points, self.n_features, rowmean[i0:i1],
+                                   self._d['inv_scale'])
+                eng._to_host_staged(t, out=out[i0:i1])
+            return out
         return self._lazy('X0', make)
+
+    _X0_BLOCK_BYTES = 1 << 30      # X0 is materialised through device blocks of this size above it
 
     @X0.setter
     def X0(self, value):

@@ -1609,3 +1609,26 @@ def test_pinned_result_budget(eng, monkeypatch):
     d = eng.to_host(t)
     assert len([1 for w, _ in eng._pinned_live if w() is not None]) <= before
     np.testing.assert_array_equal(d, c)
+
+
+def test_big_attributes_stream_to_the_host(eng, monkeypatch):
+    """t1: `spr.Ur` / `spr.X0` stay obtainable as host ndarrays at sizes that can neither be page-locked as a whole nor be
+    materialised next to X in HBM: staged D2H through two pinned buffers, X0 by row blocks -- same values as the one-shot paths."""
+    import torch
+    from openmeasure_amd.sparse_sensing import SPR
+    t = torch.randn((3_000_017, 7), dtype=torch.float64, device='cuda')       # 168 MB, ragged against the 64 MiB chunks
+    ref = t.cpu().numpy()
+    np.testing.assert_array_equal(eng._to_host_staged(t), ref)
+    monkeypatch.setenv('SPR_PINNED_RESULT_GB', '0')                            # beyond the budget: to_host() takes the staged path
+    np.testing.assert_array_equal(eng.to_host(t), ref)
+    t32 = t[:1_000_003].float()
+    np.testing.assert_array_equal(eng._to_host_staged(t32), t32.cpu().numpy())
+    X = synth_host(40_000, 3, 24, 8, 0.8, 1e-3, 9)
+    a = SPR(X, 3, None, engine=eng)
+    a.fit(select_modes='number', n_modes=4)
+    whole = a.X0
+    b = SPR(X, 3, None, engine=eng)
+    monkeypatch.setattr(SPR, '_X0_BLOCK_BYTES', 24 * 8 * 10_007)               # blocks that end inside features
+    b.fit(select_modes='number', n_modes=4)
+    np.testing.assert_array_equal(b.X0, whole)
+    np.testing.assert_allclose(whole, orc.scale_data_std(X, 3)[2], rtol=0, atol=1e-12)

@@ -55,6 +55,8 @@ extern "C" {
 #define SPR_MAX_M_WIDE 512   /* ... and the two-slice Gram path that forms the row means itself (spr_gram_cross, centre 1);
                                 wider matrices go as slice pairs (spr_gram_cross_pair), any m                       */
 #define SPR_MAX_R 128        /* retained modes / sensors ONE launch handles; callers go in column groups beyond      */
+#define SPR_MAX_R_STREAM 256 /* ... columns ONE spr_project_stream_f64 / _x32_f64out launch takes (float64 output, 16-byte-aligned rows,
+                                m % 4 == 0, no row norms): all m columns of fit()'s refinement pass at m <= 256 with X read once */
 #define SPR_MAX_R_WIDE 1024  /* ... the widest basis the placement / solve kernels accept (r <= m in the reference, :336) */
 
 /* Bumped whenever an entry point changes its argument list or meaning (round 3 -> 4: spr_qr_steps_f64 gained

@@ -23,6 +23,7 @@ SPR_ABI_VERSION = 2          # include/spr_hip.h: the value these prototypes wer
 SPR_MAX_M = 256
 SPR_MAX_M_WIDE = 512
 SPR_MAX_R = 128
+SPR_MAX_R_STREAM = 256
 SPR_MAX_R_WIDE = 1024
 
 _i32, _i64, _u64, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_size_t

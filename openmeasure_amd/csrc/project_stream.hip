@@ -32,8 +32,10 @@ namespace {
 
 constexpr int PS_WAVES = 8;
 constexpr int PS_THREADS = PS_WAVES * 64;
-constexpr int PS_NB = 2;                                // 16-row blocks per wave
-constexpr int PS_ROWS = 16 * PS_WAVES * PS_NB;          // rows a workgroup finishes per pass over W
+// 16-row blocks per wave: NB = 2 with up to 8 column tiles (r <= 128: the B fragments of a k-step serve both blocks), NB = 1 with
+// 16 column tiles (r <= 256, round 4: ALL m columns of the refinement pass of fit() in one launch -- X read once per pass);
+// 2 x 8 or 1 x 16 accumulator tiles, 128 VGPRs either way
+constexpr int ps_rows(int nb) { return 16 * PS_WAVES * nb; }   // rows a workgroup finishes per pass over W
 
 template <typename TX> struct PsK;                       // k-rows of W per chunk: a chunk of A pieces must fit the registers
 template <> struct PsK<double> { static constexpr int KC = 32; };
@@ -97,12 +99,12 @@ __global__ void ps_image_kernel(const double *__restrict__ W, int m, int r, int 
 }
 
 // NRM: the squared norms of the rows of Ur AS STORED (rounded to TU first) also go to nrm2[] (spr_qr_init_norms_*)
-template <int RT, int VEC, bool FULLK, bool PRE, typename TX, typename TU, bool NRM>
+template <int RT, int NB, int VEC, bool FULLK, bool PRE, typename TX, typename TU, bool NRM>
 __global__ __launch_bounds__(PS_THREADS) void project_stream_kernel(
     const TX *__restrict__ X, int64_t ldx, int m, int center_i, SegPlan plan, const double *__restrict__ inv_scale,
     const double *__restrict__ rowmean, const double *__restrict__ img, const double *__restrict__ wbar_g, int nch,
     int r, TU *__restrict__ Ur, int64_t ldu, double *__restrict__ nrm2) {
-  constexpr int KC = PsK<TX>::KC, NJ = KC / 16, NB = PS_NB;
+  constexpr int KC = PsK<TX>::KC, NJ = KC / 16, PS_ROWS = ps_rows(NB);
   constexpr int LDW = 16 * RT;                               // doubles per k-row of the image (a multiple of 32: see project_ws.hip)
   constexpr int CHUNK = KC * LDW;                            // doubles per chunk
   constexpr int NST = CHUNK / (2 * PS_THREADS);              // 16-byte pieces per thread and chunk
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(PS_THREADS) void project_stream_kernel(
   }
 }
 
-template <int RT, typename TX, typename TU>
+template <int RT, int NB, typename TX, typename TU>
 int ps_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0, int64_t n_points, int32_t n_features,
               int center, const double *inv_scale, const double *rowmean, const double *W, int32_t r, TU *Ur, int64_t ldu,
               double *ws, double *nrm2, hipStream_t st) {
@@ -290,18 +292,26 @@ int ps_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
   SegPlan plan;
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
   plan.total_wg = cus > 0 ? cus : 256;                     // registers allow two waves per SIMD: one workgroup per CU
-  plan.chunk_rows = PS_ROWS;
+  plan.chunk_rows = ps_rows(NB);
   const int grid = seg_total_wgs(plan);
   const bool vec = (m % 4 == 0) && ((sizeof(TX) * ldx) % 16 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   const bool fullk = vec && (m % KC == 0);
   const bool pre = center == 2;
 #define PSKN(V, FK, PR, NR)                                                                                                  \
-  hipLaunchKernelGGL((project_stream_kernel<RT, V, FK, PR, TX, TU, NR>), dim3(grid), dim3(PS_THREADS), 0, st, X, ldx, (int)m, \
+  hipLaunchKernelGGL((project_stream_kernel<RT, NB, V, FK, PR, TX, TU, NR>), dim3(grid), dim3(PS_THREADS), 0, st, X, ldx, (int)m, \
                      center, plan, inv_scale, rowmean, img, wbar, nch, (int)r, Ur, ldu, nrm2)
 #define PSK(V, FK, PR) do { if (nrm2) PSKN(V, FK, PR, true); else PSKN(V, FK, PR, false); } while (0)
-  if (fullk) { if (pre) PSK(1, true, true); else PSK(1, true, false); }
-  else if (vec) { if (pre) PSK(1, false, true); else PSK(1, false, false); }
-  else { if (pre) PSK(0, false, true); else PSK(0, false, false); }
+  if constexpr (RT > 8) {
+    // the 16-tile form is only built for aligned rows and without the row-norm epilogue (its one user, the refinement
+    // pass, needs neither); anything else goes in two column groups through the 8-tile form
+    if (!vec || nrm2) return SPR_E_UNSUPPORTED;
+    if (fullk) { if (pre) PSKN(1, true, true, false); else PSKN(1, true, false, false); }
+    else { if (pre) PSKN(1, false, true, false); else PSKN(1, false, false, false); }
+  } else {
+    if (fullk) { if (pre) PSK(1, true, true); else PSK(1, true, false); }
+    else if (vec) { if (pre) PSK(1, false, true); else PSK(1, false, false); }
+    else { if (pre) PSK(0, false, true); else PSK(0, false, false); }
+  }
 #undef PSK
 #undef PSKN
   SPR_LAUNCH_CHECK();
@@ -310,9 +320,9 @@ int ps_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
 
 template <typename TX>
 size_t ps_workspace(int32_t m, int32_t r) {
-  if (m <= 0 || r <= 0 || r > SPR_MAX_R) return 0;
+  if (m <= 0 || r <= 0 || r > SPR_MAX_R_STREAM) return 0;
   constexpr int KC = PsK<TX>::KC;
-  const int rt = (r <= 64) ? 4 : 8;
+  const int rt = (r <= 64) ? 4 : (r <= SPR_MAX_R) ? 8 : 16;
   const size_t nch = (size_t)(m + KC - 1) / KC;
   return sizeof(double) * (nch * KC * 16 * rt + 16 * rt);
 }
@@ -328,18 +338,27 @@ int ps_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int64_t 
   SPR_REQUIRE(center >= 0 && center <= 2, SPR_E_INVALID, "%s: centre mode must be 0, 1 (epilogue) or 2 (registers)", who);
   SPR_REQUIRE(n_points > 0 && n_features > 0 && row0 >= 0 && row0 + n_rows <= n_points * (int64_t)n_features,
               SPR_E_INVALID, "%s: bad feature layout", who);
-  SPR_REQUIRE(r <= SPR_MAX_R, SPR_E_UNSUPPORTED, "%s: r=%d > %d per call (project wider bases in column groups)", who, r,
-              SPR_MAX_R);
+  constexpr bool wide_ok = std::is_same<TU, double>::value;      // 129..256 columns per launch: float64 output only
+  SPR_REQUIRE(r <= (wide_ok ? SPR_MAX_R_STREAM : SPR_MAX_R), SPR_E_UNSUPPORTED,
+              "%s: r=%d > %d per call (project wider bases in column groups)", who, r, wide_ok ? SPR_MAX_R_STREAM : SPR_MAX_R);
   SPR_REQUIRE(workspace_bytes >= ps_workspace<TX>(m, r), SPR_E_WORKSPACE, "%s: workspace %zu < %zu", who, workspace_bytes,
               ps_workspace<TX>(m, r));
   SPR_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 15) == 0, SPR_E_INVALID, "%s: workspace must be 16-byte aligned", who);
   hipStream_t st = static_cast<hipStream_t>(stream);
   double *ws = static_cast<double *>(d_workspace);
   if (r <= 64)
-    return ps_launch<4, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r,
-                                d_Ur, ldu, ws, d_rownorm2, st);
-  return ps_launch<8, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r,
-                              d_Ur, ldu, ws, d_rownorm2, st);
+    return ps_launch<4, 2, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r,
+                                   d_Ur, ldu, ws, d_rownorm2, st);
+  if (r <= SPR_MAX_R)
+    return ps_launch<8, 2, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r,
+                                   d_Ur, ldu, ws, d_rownorm2, st);
+  if constexpr (wide_ok) {
+    const int rc = ps_launch<16, 1, TX, TU>(d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean,
+                                            d_W, r, d_Ur, ldu, ws, d_rownorm2, st);
+    if (rc == SPR_E_UNSUPPORTED) spr_set_error("%s: r=%d in one launch needs 16-byte-aligned rows, m %% 4 == 0 and no row norms", who, r);
+    return rc;
+  }
+  return SPR_E_UNSUPPORTED;
 }
 
 }  // namespace

@@ -487,7 +487,7 @@ class HipEngine:
 
     # ---- K4 --------------------------------------------------------------------------------
     def _project_group(self, X, i0, rows, row0, n_points, n_features, inv_scale, Wg, rowmean, center, out_ptr, ldu,
-                       out_f64, precenter, norms=None):
+                       out_f64, precenter, norms=None, force_stream=False):
         """One column group (q <= SPR_MAX_R columns of W, packed m x q) of the projection of rows [i0, i0+rows) of X,
         written at out_ptr with row stride ldu.  m <= 256: W-stationary / register-resident kernels (spr_project_*);
         wider X, or row means that must be removed before the multiplication: the streamed-W kernel, one launch over
@@ -501,7 +501,7 @@ class HipEngine:
         mean_p = rowmean.data_ptr() + i0 * rowmean.element_size() if center else None
         st = self._stream()
         sfx = '_f64' if not f32 else ('_x32_f64out' if out_f64 else '_x32')
-        stream = m > _lib.SPR_MAX_M or (precenter and center) or self._force_stream
+        stream = m > _lib.SPR_MAX_M or (precenter and center) or self._force_stream or force_stream
         if norms is not None and not stream:
             stream = not self.lib.spr_project_norms_supported(m, q, rows, ld, xp, int(f32))
         if stream:
@@ -582,12 +582,16 @@ class HipEngine:
                 and out.shape[0] >= rows and out.stride(0) % 2 == 0):
             raise ValueError('project_f64: out must be a float64 matrix with an even row stride')
         Wc = W.contiguous()
-        G = _lib.SPR_MAX_R
+        # up to 256 columns per launch in the streamed-W kernel's 16-tile form (float64 output, aligned rows, m % 4 == 0):
+        # the refinement pass of fit() at m <= 256 then reads X ONCE per pass instead of once per 128-column group
+        esz = X.element_size()
+        wide = (m % 4 == 0 and (ld * esz) % 16 == 0 and (X.data_ptr() + i0 * ld * esz) % 16 == 0 and q > _lib.SPR_MAX_R)
+        G = _lib.SPR_MAX_R_STREAM if wide else _lib.SPR_MAX_R
         for g0 in range(0, q, G):
             qg = min(G, q - g0)
             Wg = Wc if qg == q else Wc[:, g0:g0 + qg].contiguous()
             self._project_group(X, i0, rows, row0, n_points, n_features, inv_scale, Wg, rowmean, center,
-                                out.data_ptr() + g0 * 8, out.stride(0), True, precenter)
+                                out.data_ptr() + g0 * 8, out.stride(0), True, precenter, force_stream=qg > _lib.SPR_MAX_R)
         return out
 
     def feature_minmax(self, X, row0, n_points, n_features):

@@ -1632,3 +1632,34 @@ def test_big_attributes_stream_to_the_host(eng, monkeypatch):
     b.fit(select_modes='number', n_modes=4)
     np.testing.assert_array_equal(b.X0, whole)
     np.testing.assert_allclose(whole, orc.scale_data_std(X, 3)[2], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('n_points,F,m,q,f32,pre,i0', [(5000, 3, 256, 256, False, False, 0), (3333, 2, 256, 200, False, True, 128),
+                                                       (4000, 1, 512, 256, True, False, 0), (2000, 2, 300, 300, False, False, 16),
+                                                       (2500, 3, 130, 129, False, True, 0), (1800, 2, 256, 256, True, True, 64)])
+def test_project_f64_sixteen_tile_form(eng, n_points, F, m, q, f32, pre, i0):
+    """engine.project_f64 (what fit()'s refinement pass projects with): up to 256 columns in ONE launch of the streamed-W kernel's
+    16-tile form (round 4: X read once per pass), wider W in groups of 256, unaligned / m % 4 != 0 shapes in groups of 128 --
+    against ((X - mean) W) / X_scl in NumPy, row blocks starting inside a feature."""
+    import torch
+    rng = np.random.default_rng(m + q + i0)
+    n = n_points * F
+    X = rng.standard_normal((n, m)) * 2.0 + rng.standard_normal((n, 1)) * 5.0
+    if f32:
+        X = X.astype(np.float32).astype(np.float64)
+    mu = X.mean(axis=1)
+    scl = 0.5 + rng.random(F)
+    W = rng.standard_normal((m, q))
+    Xd = eng.to_device(X.astype(np.float32), dtype=torch.float32) if f32 else eng.to_device(X)
+    rows = n - i0 - 7
+    out = eng.empty((rows, q + (q & 1)))
+    eng.project_f64(Xd, i0, rows, 0, n_points, F, eng.to_device(1.0 / scl), eng.to_device(W), eng.to_device(mu), out, center=True,
+                    precenter=pre)
+    feat = np.arange(i0, i0 + rows) // n_points
+    ref = ((X[i0:i0 + rows] - mu[i0:i0 + rows, None]) @ W) / scl[feat][:, None]
+    got = eng.to_host(out)[:, :q]
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    out0 = eng.empty((rows, q + (q & 1)))
+    eng.project_f64(Xd, i0, rows, 0, n_points, F, eng.to_device(np.ones(F)), eng.to_device(W), None, out0, center=False)
+    ref0 = X[i0:i0 + rows] @ W
+    assert np.abs(eng.to_host(out0)[:, :q] - ref0).max() <= 1e-12 * np.abs(ref0).max()

@@ -563,11 +563,17 @@ class HipEngine:
         G = _lib.SPR_MAX_R
         if norms is not None and (r > G or tuple(norms.shape) != (n,) or norms.dtype != t.float64):
             raise ValueError('project(norms=...): a float64 vector with one entry per row, r <= 128')
+        # a float64 basis wider than 128 columns: groups of 256 through the streamed-W kernel's 16-tile form where the rows are
+        # aligned (half the reads of X); everything else in groups of 128
+        esz = X.element_size()
+        if r > G and dt == t.float64 and m % 4 == 0 and (ld * esz) % 16 == 0 and X.data_ptr() % 16 == 0:
+            G = _lib.SPR_MAX_R_STREAM
         for g0 in range(0, r, G):
             qg = min(G, r - g0)
             Wg = Wc if qg == r else Wc[:, g0:g0 + qg].contiguous()
             self._project_group(X, 0, n, row0, n_points, n_features, inv_scale, Wg, rowmean, center,
-                                buf.data_ptr() + g0 * buf.element_size(), ldu, dt == t.float64, precenter, norms)
+                                buf.data_ptr() + g0 * buf.element_size(), ldu, dt == t.float64, precenter, norms,
+                                force_stream=qg > _lib.SPR_MAX_R)
         toc()
         return buf[:, :r] if buf.shape[1] != r else buf
 

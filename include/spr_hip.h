@@ -30,6 +30,8 @@
  *                             f64 bases wider than 96 columns (default) | register-direct everywhere
  *   SPR_QR_DIRECT=0           spr_qr_init_* / spr_qr_refresh_*: LDS-panel sweeps only
  *   SPR_QR_FUSED_STEPS=0      spr_qr_steps_f64: three launches per candidate step instead of the fused one
+ *   SPR_RESERVE_CUS=k         every persistent grid is sized for k compute units fewer (multi-GPU diagnostic: leaves CUs to
+ *                             RCCL's kernel, which cannot share one with the Gram / projection workgroups)
  * and by the Python layer (openmeasure_amd/): SPR_PROJECT_STREAM=1 (streamed-W projection for every shape),
  * SPR_GAP_FILLER=0 (no filler launch in fit()'s host gap, ROM.gap_filler), SPR_PINNED_RESULT_GB=<g> (budget of page-locked
  * memory for host results still alive, default 8; 0 = pageable copies only), SPR_TRACE=1 (per-phase wall clock of fit(),

@@ -1,5 +1,6 @@
 // Error text, ABI version and device queries of libspr_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -22,6 +23,13 @@ int spr_cached_cus() {
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   cus = prop.multiProcessorCount;
+  // SPR_RESERVE_CUS=k: size every persistent grid for k compute units fewer.  A diagnostic for multi-GPU runs: RCCL's device
+  // kernel (261-280 VGPRs per wave, 19.7 KB of LDS) cannot share a CU with the Gram or projection workgroups, so a field
+  // gather left in flight only runs beside them on CUs they do not occupy.
+  if (const char *e = getenv("SPR_RESERVE_CUS")) {
+    const int k = atoi(e);
+    if (k > 0 && k < cus) cus -= k;
+  }
   return cus;
 }
 

@@ -76,6 +76,13 @@ int spr_device_cus(int *out_cus);
  * (sparse_sensing.py:272-279), X_scl per feature (:115), the coefficient vectors of reconstruct (:371) -- to
  * the device.  The source may be rewritten once work queued after this call on the stream has completed. */
 int spr_upload_bytes(void *d_dst, const void *h_pinned_src, int64_t n_bytes, void *stream);
+/* HOST-side helper (host pointers, no device work): unit eigenvectors of the symmetric tridiagonal matrix (h_d[m], h_e[m-1]) for
+ * the r eigenvalues h_lam, all at once -- the inverse iterations of LAPACK's dstein (dlagtf / dlagts) with the eigenvalue index
+ * as the vectorised dimension, without dstein's re-orthogonalisation inside clusters (check the result; fit() falls back to
+ * dstein).  h_Z: m x r row-major, column j belongs to h_lam[j].  Part of the host eigen-solve of the m x m Gram matrix between
+ * the two passes of fit() -- the reference's np.linalg.svd call site (sparse_sensing.py:272), of which :336 keeps r vectors. */
+int spr_host_tridiag_vectors(const double *h_d, const double *h_e, int32_t m, const double *h_lam, int32_t r, double *h_Z,
+                             int32_t iterations);
 
 /* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
  * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised

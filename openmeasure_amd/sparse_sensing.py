@@ -372,6 +372,29 @@ def _eigh_tridiagonal(G):
     return lam, (c, d, e, tau)
 
 
+def _tridiag_vectors_batched(d, e, w):
+    """Eigenvectors of the tridiagonal matrix (d, e) for the eigenvalues w, all inverse iterations side by side
+    (spr_host_tridiag_vectors, csrc/host_eig.hip: the recurrences of dstein vectorised over the eigenvalue index -- 0.2 instead of
+    0.77 ms for 64 of 256 on the GPU host).  It does not re-orthogonalise inside clusters: the vectors are accepted when they are
+    orthonormal to 1e-8 as they come (separated eigenvalues) and then made so to rounding by one symmetric correction
+    Z (I - (Z^T Z - I) / 2); otherwise None, and the caller takes dstein.  -> (m, r) Fortran-ordered array or None."""
+    try:
+        from . import _lib
+        lib = _lib.load()
+    except (RuntimeError, OSError, AttributeError):
+        return None
+    m, r = d.shape[0], w.shape[0]
+    d, e, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (d, e, w))
+    Z = np.empty((m, r))
+    if lib.spr_host_tridiag_vectors(d.ctypes.data, e.ctypes.data, m, w.ctypes.data, r, Z.ctypes.data, 4) != 0:
+        return None
+    E = Z.T @ Z
+    E[np.diag_indices(r)] -= 1.0
+    if not np.all(np.isfinite(E)) or np.abs(E).max() > 1e-8:
+        return None
+    return np.asfortranarray(Z - 0.5 * (Z @ E))
+
+
 def _eigvecs_top(fac, lam, r):
     """Second half: eigenvectors of the r LARGEST eigenvalues only -- inverse iteration on the tridiagonal matrix (dstein,
     with its re-orthogonalisation inside clusters) and back-transformation of those r vectors (dormqr on the reflectors
@@ -387,11 +410,14 @@ def _eigvecs_top(fac, lam, r):
     isplit = np.zeros(m, dtype=np.int32)
     isplit[0] = m
     with _one_blas_thread():
-        # (splitting the eigenvalue list over a few threads gained nothing on the GPU host: 1.02 -> 1.09 ms, round 4)
-        z, info = lapack.dstein(d, e, w, iblock, isplit)
-        if info != 0:
-            return None
-        Z = np.asfortranarray(z[:, :r])
+        Z = _tridiag_vectors_batched(d, e, w)
+        if Z is None:
+            # LAPACK's dstein: one eigenvalue after the other, with re-orthogonalisation inside clusters (splitting its list
+            # over a few threads gained nothing on the GPU host: 1.02 -> 1.09 ms, round 4)
+            z, info = lapack.dstein(d, e, w, iblock, isplit)
+            if info != 0:
+                return None
+            Z = np.asfortranarray(z[:, :r])
         cq = np.asfortranarray(c[1:, :m - 1])
         lw = _LWORK.get(('mqr', m, r))
         if lw is None:

@@ -526,3 +526,69 @@ def test_one_hot_rows_scalar_index_out_of_range():
             dense[1, j]
         with pytest.raises(IndexError):
             C[1, j]
+
+
+def _tridiag_case(kind, m, rng):
+    if kind == 'random':
+        return rng.standard_normal(m), rng.standard_normal(m - 1)
+    if kind == 'decaying':                                  # the spectrum of a Gram matrix: eigenvalues over twelve decades
+        lam = 10.0 ** (-12.0 * np.arange(m) / m)
+        Q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+        from scipy.linalg import lapack
+        c, d, e, tau, info = lapack.dsytrd(np.asfortranarray((Q * lam) @ Q.T), lower=1)
+        return d, e
+    if kind == 'split':                                     # exact zeros on the off-diagonal: the matrix decouples
+        d, e = rng.standard_normal(m), rng.standard_normal(m - 1)
+        e[m // 3] = 0.0
+        e[m // 2] = 0.0
+        return d, e
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize('kind,m,r', [('random', 40, 40), ('random', 257, 64), ('decaying', 128, 48), ('split', 90, 30),
+                                      ('random', 2, 2), ('random', 1, 1), ('random', 300, 7)])
+def test_host_tridiagonal_vectors_vs_lapack(kind, m, r):
+    """spr_host_tridiag_vectors (csrc/host_eig.hip): the inverse iterations of dstein for all requested eigenvalues side by
+    side.  Residual and orthogonality against the tridiagonal matrix itself; vectors against numpy's eigh of it."""
+    from openmeasure_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(m * 7 + r)
+    d, e = _tridiag_case(kind, m, rng)
+    d, e = np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(e, dtype=np.float64)
+    T = np.diag(d) + (np.diag(e, 1) + np.diag(e, -1) if m > 1 else 0.0)
+    lam, V = np.linalg.eigh(T)
+    w = np.ascontiguousarray(lam[m - r:])
+    Z = np.empty((m, r))
+    assert lib.spr_host_tridiag_vectors(d.ctypes.data, e.ctypes.data if m > 1 else None, m, w.ctypes.data, r, Z.ctypes.data, 4) == 0
+    scale = max(np.abs(lam).max(), 1e-300)
+    assert np.abs(T @ Z - Z * w).max() <= 50 * np.finfo(float).eps * scale * np.sqrt(m)
+    np.testing.assert_allclose(np.linalg.norm(Z, axis=0), 1.0, rtol=1e-14)
+    gaps = np.diff(lam)
+    if kind != 'split' and (m < 3 or gaps.min() > 1e-6 * scale):            # separated eigenvalues: the vectors themselves
+        ref = V[:, m - r:]
+        assert np.abs(np.abs(Z.T @ ref) - np.eye(r)).max() <= 1e-9
+    # argument validation: no work on bad input
+    assert lib.spr_host_tridiag_vectors(None, None, m, w.ctypes.data, r, Z.ctypes.data, 4) == -1
+    assert lib.spr_host_tridiag_vectors(d.ctypes.data, e.ctypes.data if m > 1 else None, m, w.ctypes.data, m + 1, Z.ctypes.data, 4) == -1
+
+
+def test_clustered_spectrum_takes_dstein(monkeypatch):
+    """A Gram matrix with a (numerically) multiple retained eigenvalue: the batched inverse iteration cannot separate the
+    cluster, _tridiag_vectors_batched declines (or its result fails the final check) and dstein / dsyevd take over --
+    fit() still returns an orthonormal basis with the right spectrum."""
+    import openmeasure_amd.sparse_sensing as ss
+    rng = np.random.default_rng(8)
+    m, n = 128, 3000
+    Q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    sig = np.r_[np.full(6, 5.0), 3.0, 3.0 * (1 + 1e-13), np.full(4, 1.0), 10.0 ** -np.linspace(1, 6, m - 12)]
+    U, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    X = (U * sig) @ Q.T
+    calls = []
+    real = ss._tridiag_vectors_batched
+    monkeypatch.setattr(ss, '_tridiag_vectors_batched', lambda d, e, w: calls.append(real(d, e, w)) or calls[-1])
+    rom = SPR(np.ascontiguousarray(X), 1, None, engine=NumpyEngine())
+    rom.fit(scale_type='none', select_modes='number', n_modes=12)
+    assert calls and calls[-1] is None                       # multiple eigenvalues: declined
+    assert np.abs(rom.Ur.T @ rom.Ur - np.eye(12)).max() < 1e-9
+    Xc = X - X.mean(axis=1, keepdims=True)
+    np.testing.assert_allclose(rom.Sigma_r, np.linalg.svd(Xc, compute_uv=False)[:12], rtol=1e-9)

@@ -603,10 +603,15 @@ class ROM:
     #: With the filler on, fit() queues the Gram kernel ONCE MORE over the first rows of X, sized to 85 % of the shortest
     #: host gap of the last fits, before it blocks on the download; the results are discarded.  It costs energy, not time:
     #: the device has nothing else to do, and the projection never waits for more than the filler overshoots.  Only for
-    #: m >= 128 (shorter eigen-solves leave no gap worth filling); SPR_GAP_FILLER=0 or ``rom.gap_filler = False`` turns it off.
+    #: m >= 128 and host gaps of at least _GAP_FILL_MIN_MS (shorter ones leave no clock drop worth filling); SPR_GAP_FILLER=0 or
+    #: ``rom.gap_filler = False`` turns it off.
     gap_filler = True
     _GAP_FILL_FRACTION = 0.85
     _GAP_FILL_MIN_M = 128
+    #: ... and only when the host gap is long enough for the clock to matter: behind a 2.8 ms gap the filler took 0.7 ms off a
+    #: 23 ms step, behind the 1.8 ms gap the batched eigen-solve leaves at m = 256 it changes nothing (same-box A/B, three
+    #: repetitions: 21.98-22.37 vs 22.09-22.13 ms).  Hosts whose eigen-solve takes longer (other CPUs, loaded machines) fill.
+    _GAP_FILL_MIN_MS = 2.2
 
     #: Collective timing (bench.py): set to a dict and every collective of fit() / reconstruct() appends a pair of
     #: engine timing events (recorded on the stream the collective is ordered on) under 'allreduce' (the ONE all-reduce
@@ -930,7 +935,7 @@ class ROM:
         pf = self.__dict__.get('_pending_field')
         if pf is not None and pf.pending:
             return
-        if hist and rate:
+        if hist and rate and min(hist) >= self._GAP_FILL_MIN_MS:
             rows = int(self._GAP_FILL_FRACTION * min(hist) * rate) // 4096 * 4096
             rows = min(rows, Xd.shape[0])
             if rows >= 65536:

@@ -97,6 +97,7 @@ def _synth_worker(rank, world, port, cells, F, m, s_, out_dir):
         # round 4: the step loop of bench.py in both forms, with the collective brackets on -- gather left in flight (the gap
         # filler of fit() must stay out of the gap the gather needs) and joined inside the step (the filler runs)
         spr.comm_timing = {}
+        spr._GAP_FILL_MIN_MS = 0.0                            # fill whatever gap this host leaves
         a_d = eng.to_device(spr.Ar[:1].copy())
         fills = {}
         for sync in (False, True):

@@ -26,6 +26,7 @@ class HipEngine:
     name = 'hip-gfx950'
 
     supports_row_norms = True      # project(norms=...) / qr_begin(norms=...): see ROM.placement_norms
+    supports_gram_out = True       # stats_gram(gram_out=, fstats_out=): results written into the caller's buffers
 
     def __init__(self, device=None):
         import torch
@@ -320,15 +321,25 @@ class HipEngine:
         return (lambda: ev[0].record(st)), (lambda: ev[1].record(st))
 
     # ---- K1 + K3a ------------------------------------------------------------------------
-    def stats_gram(self, X, row0, n_points, n_features, center=True):
+    def stats_gram(self, X, row0, n_points, n_features, center=True, gram_out=None, fstats_out=None):
         """-> rowmean (n,), fstats (F,3) = (count, mean, M2) of the local row means,
-        gram (F,m,m) = per-feature sum of centred outer products over the local rows."""
+        gram (F,m,m) = per-feature sum of centred outer products over the local rows.
+        ``gram_out`` / ``fstats_out``: contiguous float64 tensors of those shapes to write into (fit() hands over views of
+        its collective buffer, so nothing is copied between the finalize kernel and the all-reduce); m <= 256 only."""
         n, m, ld = self._check_matrix(X)
         if m > _lib.SPR_MAX_M:
-            return self._stats_gram_wide(X, row0, n_points, n_features, center)
+            rowmean, fstats, gram = self._stats_gram_wide(X, row0, n_points, n_features, center)
+            if gram_out is not None:
+                gram_out.copy_(gram)
+                fstats_out.copy_(fstats)
+                return rowmean, fstats_out, gram_out
+            return rowmean, fstats, gram
         rowmean = self.empty((n,))
-        fstats = self.empty((n_features, 3))
-        gram = self.empty((n_features, m, m))
+        fstats = fstats_out if fstats_out is not None else self.empty((n_features, 3))
+        gram = gram_out if gram_out is not None else self.empty((n_features, m, m))
+        if gram_out is not None and not (gram.is_contiguous() and fstats.is_contiguous() and gram.dtype == self.torch.float64
+                                         and tuple(gram.shape) == (n_features, m, m) and tuple(fstats.shape) == (n_features, 3)):
+            raise ValueError('stats_gram(gram_out, fstats_out): contiguous float64 (F, m, m) and (F, 3) tensors')
         nbytes = self.lib.spr_stats_gram_workspace(m, n_features)
         ws = self._workspace('gram', nbytes)
         tic, toc = self._timed('stats_gram')

@@ -902,12 +902,18 @@ class ROM:
             return rowmean, gram, fstats[None]
         world, rank = self._world(), self._shard.rank
         buf = eng.zeros((F * m * m + world * F * 3,))
-        rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+        g_view = buf[:F * m * m].view(F, m, m)
+        f_view = buf[F * m * m + rank * F * 3:F * m * m + (rank + 1) * F * 3].view(F, 3)
+        if getattr(eng, 'supports_gram_out', False):          # the finalize kernel writes straight into the collective buffer
+            rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True, gram_out=g_view,
+                                                   fstats_out=f_view)
+        else:                                                 # an engine without the output arguments (the NumPy test double)
+            rowmean, fstats, gram = eng.stats_gram(Xd, self._row0, self.n_points, F, center=True)
+            g_view.copy_(gram)
+            f_view.copy_(fstats)
         if fill:
             self._gram_events = (e0, eng.timing_event())
         self._trace.mark('stats_gram')
-        buf[:F * m * m].copy_(gram.reshape(-1))
-        buf[F * m * m + rank * F * 3:F * m * m + (rank + 1) * F * 3].copy_(fstats.reshape(-1))
         close = self._comm_bracket('allreduce')
         self._all_reduce(buf)
         close()

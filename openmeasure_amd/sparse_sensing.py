@@ -396,12 +396,13 @@ def _tridiag_vectors_batched(d, e, w):
 
 
 def _eigvecs_top(fac, lam, r):
-    """Second half: eigenvectors of the r LARGEST eigenvalues only -- inverse iteration on the tridiagonal matrix (dstein,
-    with its re-orthogonalisation inside clusters) and back-transformation of those r vectors (dormqr on the reflectors
-    dsytrd left below the sub-diagonal).  O(m^2 r) instead of dsyevd's O(m^3): 0.6 + 0.4 + ~0.5 + 0.2 ms against 2.65 ms
-    at m = 256, r = 64 on the GPU host (tools/eigh_pieces_probe.py).  -> V (m, r), columns in DESCENDING order of
-    eigenvalue, or None when dstein reports a failure or the vectors are not orthonormal to 1e-12 (the caller then
-    takes dsyevd)."""
+    """Second half: eigenvectors of the r LARGEST eigenvalues only -- inverse iteration on the tridiagonal matrix (all r at
+    once in spr_host_tridiag_vectors; LAPACK's dstein, with its re-orthogonalisation inside clusters, when those fail their
+    check) and back-transformation of the r vectors (dormqr on the reflectors dsytrd left below the sub-diagonal).  O(m^2 r)
+    instead of dsyevd's O(m^3): dsytrd 0.61 + dsterf 0.36 + vectors and dormqr 0.57 = 1.6 ms against 2.65 ms at m = 256,
+    r = 64 on the GPU host (tools/eigh_pieces_probe.py, profiles/r04_eigh_pieces_probe.txt).  -> V (m, r), columns in
+    DESCENDING order of eigenvalue, or None when dstein reports a failure or the vectors are not orthonormal to 1e-12 (the
+    caller then takes dsyevd)."""
     from scipy.linalg import lapack
     c, d, e, tau = fac
     m = d.shape[0]

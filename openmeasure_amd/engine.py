@@ -454,11 +454,12 @@ class HipEngine:
         scratch vector for the row means."""
         n, m, ld = self._check_matrix(X)
         rows = int(min(rows, n))
-        if rows <= 0 or m > _lib.SPR_MAX_M:
+        if rows <= 0:
             return
+        w = min(m, _lib.SPR_MAX_M)                            # a wide X: its first 256-column slice (row stride = full row)
         scratch = self._workspace('fillmean', rows * 8)
-        ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(m, n_features))
-        _lib.check(self._x('spr_stats_gram', X)(_ptr(X), rows, m, ld, row0, n_points, n_features, 1, scratch.data_ptr(),
+        ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(w, n_features))
+        _lib.check(self._x('spr_stats_gram', X)(_ptr(X), rows, w, ld, row0, n_points, n_features, 1, scratch.data_ptr(),
                                                _ptr(ws), ws.numel(), self._stream()), 'spr_stats_gram_f64')
 
     # ---- K3b: device-side spectrum (m <= 64) ------------------------------------------------------

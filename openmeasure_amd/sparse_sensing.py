@@ -611,7 +611,8 @@ class ROM:
     _GAP_FILL_MIN_M = 128
     #: ... and only when the host gap is long enough for the clock to matter: behind a 2.8 ms gap the filler took 0.7 ms off a
     #: 23 ms step, behind the 1.8 ms gap the batched eigen-solve leaves at m = 256 it changes nothing (same-box A/B, three
-    #: repetitions: 21.98-22.37 vs 22.09-22.13 ms).  Hosts whose eigen-solve takes longer (other CPUs, loaded machines) fill.
+    #: repetitions: 21.98-22.37 vs 22.09-22.13 ms).  Hosts whose eigen-solve takes longer (other CPUs, loaded machines) fill, and so
+    #: do wide matrices: behind the 7.6 ms eigen-solve of m = 512 the filler takes 1.6 ms off a 35 ms projection (c5s 114.0 -> 112.4 ms).
     _GAP_FILL_MIN_MS = 2.2
 
     #: Collective timing (bench.py): set to a dict and every collective of fit() / reconstruct() appends a pair of
@@ -924,7 +925,7 @@ class ROM:
         import os
         eng = self._engine()
         tr = self.__dict__.get('_trace')
-        return bool(self.gap_filler and hasattr(eng, 'gram_filler') and self._GAP_FILL_MIN_M <= Xd.shape[1] <= 256
+        return bool(self.gap_filler and hasattr(eng, 'gram_filler') and self._GAP_FILL_MIN_M <= Xd.shape[1]
                     and os.environ.get('SPR_GAP_FILLER', '1') != '0'
                     and not (tr is not None and tr.on))        # SPR_TRACE synchronises at every mark: its gaps are not fit()'s
 
@@ -943,7 +944,11 @@ class ROM:
         if pf is not None and pf.pending:
             return
         if hist and rate and min(hist) >= self._GAP_FILL_MIN_MS:
-            rows = int(self._GAP_FILL_FRACTION * min(hist) * rate) // 4096 * 4096
+            # a wide X (m > 256) is filled with the 256-column kernel on its first slice, whose rows cost (256 / m)^2 of what the
+            # rows of the whole wide pass -- the rate measured -- cost
+            m = Xd.shape[1]
+            speed = (m / 256.0) ** 2 if m > 256 else 1.0
+            rows = int(self._GAP_FILL_FRACTION * min(hist) * rate * speed) // 4096 * 4096
             rows = min(rows, Xd.shape[0])
             if rows >= 65536:
                 eng.gram_filler(Xd, rows, self._row0, self.n_points, self.n_features)

@@ -1586,6 +1586,7 @@ class SPR(ROM):
                             stats=stats)
         self.pivot_sweeps_ = sweeps - int(self.placement_from_norms_)   # passes over the basis (the start read none)
         self.pivot_pool_sweeps_ = stats.get('pool_sweeps', 0)           # refreshes that visited the pool only
+        self.pivot_log_ = stats.get('log', [])                          # batches and refreshes of the pooled driver, in order
         piv = eng.to_host(st['piv']).astype(np.int64)
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])

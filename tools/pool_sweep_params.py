@@ -35,5 +35,7 @@ for frac, margin in ((1 / 16, 1.15), (1 / 14, 1.15), (1 / 12, 1.15), (1 / 11, 1.
         torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
     if ref is None:
         ref = spr.sensors_.copy()
+        for e in spr.pivot_log_:      # ('batch', first step, certified, tried, level, tau, theta, pool rows) / ('pool sweep' | 'full sweep', epoch start, step)
+            print('   ', e, flush=True)
     print(f'pool fraction 1/{round(1 / frac)}, margin {margin}: {sorted(ts)[1]:7.2f} ms, full sweeps {spr.pivot_sweeps_}, '
           f'pool sweeps {spr.pivot_pool_sweeps_}, same sensors {np.array_equal(ref, spr.sensors_)}', flush=True)

@@ -24,9 +24,13 @@ spr = SPR(DeviceMatrix(Xd, basis='f32' if f32 else None), F, None, engine=eng)
 spr.fit(select_modes='number', n_modes=s)
 del Xd
 ref = None
+ROWS = int(os.environ.get('POOL_SWEEP_ROWS', '99'))
 for frac, margin in ((1 / 16, 1.15), (1 / 14, 1.15), (1 / 12, 1.15), (1 / 11, 1.15), (1 / 10, 1.15), (1 / 9, 1.15), (1 / 8, 1.15),
                      (1 / 16, 1.25), (1 / 10, 1.25)):
     ss._POOL_FRACTION, ss._POOL_MARGIN = frac, margin
+    ROWS -= 1
+    if ROWS < 0:
+        break
     spr.optimal_placement(); spr.optimal_placement()
     ts = []
     for _ in range(3):

@@ -245,6 +245,9 @@ def parse_args(argv=None):
     ap.add_argument('--extra', action='store_true',
                     help='more lines: A/B of the row norms fit() leaves for the placement, reconstruct() with its '
                          "reference output contract (host ndarray), upload rate of a host ndarray X")
+    ap.add_argument('--placement-norms', choices=('auto', 'on', 'off'), default='auto',
+                    help="developer aid (A/B): SPR.placement_norms -- whether fit()'s projection also leaves the squared row "
+                         "norms optimal_placement starts from (default: the class default, 'auto')")
     ap.add_argument('--sync-gather', action='store_true',
                     help='the headline loop joins the field all-gather at the end of every step (default: it overlaps the '
                          'next Gram pass; both forms are timed in every N > 1 run)')
@@ -341,6 +344,8 @@ def run_rank(args):
         shard = RowShard(row0, n_glob, force_collectives=force_dist) if (world > 1 or force_dist) else None
     # f32-stored workloads (config 5) also store the basis in f32 -- the explicit storage option; the default would be f64
     spr = SPR(DeviceMatrix(Xd, basis='f32' if f32 else None), F, None, shard=shard, engine=eng)
+    if args.placement_norms != 'auto':
+        spr.placement_norms = args.placement_norms == 'on'
 
     def barrier():
         if world > 1 or force_dist:
@@ -632,7 +637,8 @@ def run_rank(args):
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': plan['scaling'],
             'vs_baseline': None, 'dtype': 'f64' if not f32 else 'f64 arithmetic on f32-stored data', 'data': 'synthetic',
             'config': {'workload': what, 'rows_per_gpu': n_loc, 'rows_total': n_job,
-                       'snapshot_GB_per_gpu': round(n_loc * m * B / 1e9, 3), 'storage': 'f32' if f32 else 'f64'},
+                       'snapshot_GB_per_gpu': round(n_loc * m * B / 1e9, 3), 'storage': 'f32' if f32 else 'f64',
+                       **({'placement_norms': args.placement_norms} if args.placement_norms != 'auto' else {})},
             'hbm_roofline_frac_step': round(hbm_frac, 4),
             # the same K steps with the field all-gather joined inside every step (N > 1; at N = 1 there is no gather)
             'ms_per_step_sync_gather': (round(1e3 * dt_sync / args.steps, 4) if dt_sync is not None

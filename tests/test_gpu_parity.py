@@ -493,6 +493,31 @@ def test_end_to_end_vs_oracle(eng, n_points, F, m, r):
     assert np.abs(spr.Ur * sg - ref['Ur']).max() <= 1e-9
 
 
+@pytest.mark.parametrize('seed', range(48))
+def test_random_shapes_end_to_end(eng, seed):
+    """48 seeded random shapes -- 3 ... 4 000 cells, 1 ... 6 features, 2 ... 330 snapshots (narrow, 256-wide and wide Gram
+    routes; every projection, placement and solve template the widths select), 1 ... 70 modes -- through fit -> placement ->
+    train -> predict -> reconstruct against the oracle: spectrum to 1e-8, retained subspace to 1e-8, ordered sensors exact
+    wherever the oracle's own pivot margin is above rounding, field within 1e-6 rel-Frobenius (north_star)."""
+    rng = np.random.default_rng(1000 + seed)
+    F = int(rng.integers(1, 7))
+    m = int(rng.integers(2, 40)) if seed % 3 == 0 else int(rng.integers(40, 331))
+    n_points = max(int(rng.integers(3, 4001)), (m + 2 + F - 1) // F)       # tall matrix: n >= m + 2
+    r = int(rng.integers(1, min(m - 1, 70) + 1))
+    rho = 10 ** (-3 / (r - 1)) if r > 1 else 0.5
+    X = synth_host(n_points, F, m, min(m, 2 * r), rho, 1e-3, 5000 + seed)
+    spr, ref, xr = _full_path(eng, X, F, r)
+    assert spr.r == r == ref['Ur'].shape[1]
+    np.testing.assert_allclose(spr.Sigma_r, ref['Sigma_r'], rtol=1e-8)
+    Q = spr.Ur.T @ ref['Ur']                                                # same subspace <=> Q orthogonal
+    assert np.abs(Q.T @ Q - np.eye(r)).max() <= 1e-8, (n_points, F, m, r)
+    gaps = spr.pivot_gap_
+    safe = len(gaps) if gaps.min() > 1e-9 else int(np.argmax(gaps <= 1e-9))  # steps before the first near-tie
+    np.testing.assert_array_equal(spr.sensors_[:safe], ref['piv'][:safe], err_msg=str((n_points, F, m, r)))
+    if safe == len(gaps):
+        assert rel_fro(xr, ref['X_rec']) <= REL_FRO, (n_points, F, m, r)
+
+
 def test_masked_placement_vs_oracle(eng):
     from openmeasure_amd.sparse_sensing import SPR
     X = synth_host(3000, 3, 24, 24, 0.75, 1e-3, 77)

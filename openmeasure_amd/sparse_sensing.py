@@ -66,7 +66,9 @@ class RowShard:
     n_global  total rows (= n_points * n_features) over all ranks
     group     torch.distributed process group (None = default group); world size 1 if
               torch.distributed is not initialised.
-    Every rank must hold the same number of rows (the field all-gather needs it).
+    The ranks' blocks are contiguous, in rank order, and together cover all n_global rows (checked at the first gather);
+    equal blocks (n_global / world rows each) take the zero-copy field all-gather, unequal ones are padded to the
+    largest block for the gather and packed afterwards.
     broadcast_basis  every rank eigen-solves the same all-reduced Gram matrix (RCCL leaves identical bits on all
               ranks) with the same single-threaded LAPACK, so on one node the factors agree bit for bit and nothing
               is exchanged; set True when the ranks' hosts may differ (CPU type, LAPACK build): rank 0's
@@ -580,8 +582,6 @@ class ROM:
         self._row0 = shard.row0 if shard is not None else 0
         if self._row0 + X.shape[0] > n:
             raise ValueError('The local row block does not fit in the global matrix.')
-        if shard is not None and X.shape[0] * shard.world != n and not getattr(shard, 'partial', False):
-            raise ValueError('Every rank must hold n / world rows (the field all-gather needs equal shards).')
         self._eng = engine
         self._d = {}            # device-resident state
         self._host = {}         # lazily downloaded copies
@@ -675,6 +675,29 @@ class ROM:
     def _dist(self):
         """True when collectives have to be issued (more than one rank, or forced for testing)."""
         return self._shard is not None and (self._shard.world > 1 or self._shard.force_collectives)
+
+    def _shard_layout(self, n_loc):
+        """(first row, rows) of every rank's block, rank order, cached.  Blocks that do not tile the global rows raise
+        ValueError -- unless the shard is a declared slice of a larger job (partial)."""
+        lay = self.__dict__.get('_layout')
+        if lay is None:
+            eng = self._engine()
+            src = self.__dict__.pop('_layout_src', None)
+            if src is not None:
+                # fit()'s ONE all-reduce already carried every rank's row count per feature (the statistics slots) and
+                # its first row: no collective here, and every rank sees the same table (they raise together)
+                rows = np.rint(eng.to_host(src[0].sum(1))).astype(np.int64)
+                lay = np.stack([np.rint(eng.to_host(src[1])).astype(np.int64), rows], axis=1)
+            else:                                             # a fit route without those slots: ask (two integers per rank)
+                mine = eng.to_device(np.array([self._row0, n_loc], dtype=np.float64))  # exact below 2^53
+                lay = eng.to_host(self._all_gather(mine)).astype(np.int64)
+            self._layout = lay
+            if not self._shard.partial:
+                ends = lay[:, 0] + lay[:, 1]
+                if lay[0, 0] != 0 or ends[-1] != self._n_global or np.any(lay[1:, 0] != ends[:-1]):
+                    raise ValueError('The row blocks of the ranks are not contiguous in rank order or do not cover the '
+                                     f'{self._n_global} global rows: (first row, rows) per rank = {lay.tolist()}')
+        return lay
 
     def _Xd(self):
         if 'X' not in self._d:
@@ -888,9 +911,10 @@ class ROM:
 
     def _gram_collective(self, Xd):
         """The fused stats + Gram pass over the local rows and the ONE collective of fit(): an all-reduce (sum) of a
-        buffer [F m m Gram doubles | world x F x 3 statistics], every rank writing its (count, mean, M2) triples into
-        its own slot and zeros elsewhere, so the sum hands every rank all ranks' statistics in rank order (adding
-        zeros is exact) -- north_star: a single RCCL all-reduce for the Gram matrix.
+        buffer [F m m Gram doubles | world x F x 3 statistics | world first rows], every rank writing its (count, mean, M2)
+        triples and its first global row into its own slots and zeros elsewhere, so the sum hands every rank all ranks'
+        statistics and row blocks in rank order (adding zeros is exact) -- north_star: a single RCCL all-reduce for the
+        Gram matrix.
         Returns rowmean (n_local,), gram (F, m, m) summed over ranks, fstats_all (world, F, 3)."""
         eng = self._engine()
         F, m = self.n_features, Xd.shape[1]
@@ -903,7 +927,8 @@ class ROM:
             self._trace.mark('stats_gram')
             return rowmean, gram, fstats[None]
         world, rank = self._world(), self._shard.rank
-        buf = eng.zeros((F * m * m + world * F * 3,))
+        buf = eng.zeros((F * m * m + world * F * 3 + world,))
+        buf[F * m * m + world * F * 3 + rank] = float(self._row0)     # this rank's first row (exact below 2^53), see _shard_layout
         g_view = buf[:F * m * m].view(F, m, m)
         f_view = buf[F * m * m + rank * F * 3:F * m * m + (rank + 1) * F * 3].view(F, 3)
         if getattr(eng, 'supports_gram_out', False):          # the finalize kernel writes straight into the collective buffer
@@ -919,7 +944,11 @@ class ROM:
         close = self._comm_bracket('allreduce')
         self._all_reduce(buf)
         close()
-        return rowmean, buf[:F * m * m].view(F, m, m), buf[F * m * m:].view(world, F, 3)
+        fstats_all = buf[F * m * m:F * m * m + world * F * 3].view(world, F, 3)
+        if '_layout' not in self.__dict__:
+            # rows per (rank, feature) and first rows: the ranks' blocks, carried by the one all-reduce for free
+            self._layout_src = (fstats_all[:, :, 0], buf[F * m * m + world * F * 3:])
+        return rowmean, buf[:F * m * m].view(F, m, m), fstats_all
 
     def _filler_wanted(self, Xd):
         import os
@@ -1507,6 +1536,9 @@ class ROM:
             # the field itself, for several the columns are put side by side afterwards -- on the way to the host when
             # the caller wants a host array (block copies, no pass over the field on the device), by
             # spr_field_unstage_f64 when the field stays in HBM
+            lay = self._shard_layout(n_loc)
+            if np.any(lay[:, 1] != n_loc):
+                return self._gather_unequal(loc, lay, to_host, wait)
             stage = eng.empty((world, n_p, n_loc))
             close = self._comm_bracket('gather')              # issue -> join, when the join happens inside this call
             work = dist.all_gather_into_tensor(stage.view(-1), loc.contiguous().view(-1), group=self._shard.group,
@@ -1533,6 +1565,36 @@ class ROM:
         if not to_host:
             return out if wait else PendingField(out)
         return eng.to_host(out).T                             # (n, n_p), Fortran-ordered view
+
+
+    def _gather_unequal(self, loc, lay, to_host, wait):
+        """Field all-gather for row blocks of different sizes: every rank contributes its (n_p, n_loc) block padded to the
+        largest block (RCCL's all-gather wants equal counts), and the blocks are packed side by side afterwards -- block
+        copies on the way to the host, or one pass over the field on the device (n n_p 8 bytes; the equal-shard path
+        needs neither)."""
+        import torch.distributed as dist
+        eng = self._engine()
+        n_p, n_loc = loc.shape
+        world, n_max = lay.shape[0], int(lay[:, 1].max())
+        mine = eng.zeros((n_p, n_max))
+        mine[:, :n_loc].copy_(loc)
+        stage = eng.empty((world, n_p, n_max))
+        close = self._comm_bracket('gather')
+        dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self._shard.group)
+        close()
+        first = int(lay[0, 0])                                # 0 unless the group holds a slice of a larger job (partial)
+        total = int(lay[:, 1].sum())
+        if to_host:
+            host = np.empty((n_p, total))
+            for q in range(world):
+                o, k = int(lay[q, 0]) - first, int(lay[q, 1])
+                host[:, o:o + k] = eng.to_host(stage[q, :, :k])
+            return host.T
+        out = eng.empty((n_p, total))
+        for q in range(world):
+            o, k = int(lay[q, 0]) - first, int(lay[q, 1])
+            out[:, o:o + k].copy_(stage[q, :, :k])
+        return out if wait else PendingField(out)
 
 
 class SPR(ROM):

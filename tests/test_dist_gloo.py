@@ -25,7 +25,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, fixture, out_dir, bcast=False, candidates=False):
+def _cuts(n, world, uneven):
+    """first rows of the ranks' blocks (+ n at the end): equal blocks, or seeded unequal ones that cut through features"""
+    if not uneven:
+        return [r * (n // world) for r in range(world)] + [n]
+    rng = np.random.default_rng(n + world)
+    inner = np.sort(rng.choice(np.arange(1, n), size=world - 1, replace=False))
+    return [0] + inner.tolist() + [n]
+
+
+def _worker(rank, world, port, fixture, out_dir, bcast=False, candidates=False, uneven=False):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -37,9 +46,9 @@ def _worker(rank, world, port, fixture, out_dir, bcast=False, candidates=False):
         g = load_golden(fixture)
         X = g['X']
         n = X.shape[0]
-        n_loc = n // world
-        assert n_loc * world == n
-        row0 = rank * n_loc
+        cuts = _cuts(n, world, uneven)
+        row0, n_loc = cuts[rank], cuts[rank + 1] - cuts[rank]
+        assert uneven or n_loc * world == n
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None,
                   shard=RowShard(row0, n, broadcast_basis=bcast), engine=CandidateEngine() if candidates else NumpyEngine())
         spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'],
@@ -77,23 +86,67 @@ def test_sharded_path_on_the_candidate_model(tmp_path, fixture, world):
     _run_sharded(tmp_path, fixture, world, False, candidates=True)
 
 
-def _run_sharded(tmp_path, fixture, world, bcast, candidates=False):
+@pytest.mark.parametrize('fixture,world', [('g2_num4', 2), ('g2_num4', 3), ('g3_num8', 3), ('g1_num4', 2), ('g4_num5', 4),
+                                           ('g6_axisnone', 3), ('g5_median', 2), ('cond_1e5', 2)])
+def test_sharded_path_with_unequal_blocks(tmp_path, fixture, world):
+    """row blocks of different sizes (seeded cuts anywhere, also inside a feature; g4's 999 rows do not divide by 4): same
+    sensors, basis and fields; the field all-gather pads to the largest block and packs afterwards, the blocks' layout
+    rides on fit()'s one all-reduce (no extra collective: test_one_collective_per_fit_and_per_reconstruct)"""
+    _run_sharded(tmp_path, fixture, world, False, uneven=True)
+
+
+def _gap_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden
+        from tests.numpy_engine import NumpyEngine
+        g = load_golden('g1_num4')
+        X = g['X']
+        n = X.shape[0]
+        row0, n_loc = (0, 10) if rank == 0 else (11, 9)              # row 10 belongs to nobody
+        spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
+                  engine=NumpyEngine())
+        spr.fit(select_modes='number', n_modes=3)
+        try:
+            spr.reconstruct(spr.Ar[:1])
+            msg = ''
+        except ValueError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, f'gap{rank}.txt'), 'w') as fh:
+            fh.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_blocks_that_do_not_cover_the_rows_are_refused_on_every_rank(tmp_path):
+    """a hole between two ranks' blocks: reconstruct() raises the same ValueError on ALL ranks (the table of blocks comes out
+    of fit()'s all-reduce, identical everywhere), so nobody is left waiting in the gather"""
+    mp.spawn(_gap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(tmp_path / f'gap{r}.txt').read() for r in range(2)]
+    assert msgs[0] == msgs[1] and 'do not cover' in msgs[0] and '[[0, 10], [11, 9]]' in msgs[0]
+
+
+def _run_sharded(tmp_path, fixture, world, bcast, candidates=False, uneven=False):
     from tests.conftest import load_golden
     from tests.parity import REL_FRO, align_signs, rel_fro
     g = load_golden(fixture)
     n = g['X'].shape[0]
-    if n % world:
+    if n % world and not uneven:
         pytest.skip('rows do not divide')
-    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path), bcast, candidates), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path), bcast, candidates, uneven), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
-    n_loc = n // world
+    cuts = _cuts(n, world, uneven)
     for r, o in enumerate(outs):
         # replicated results identical on every rank
         np.testing.assert_array_equal(o['piv'], outs[0]['piv'])
         np.testing.assert_array_equal(o['X3'], outs[0]['X3'])
         np.testing.assert_array_equal(o['Theta'], outs[0]['Theta'])
         # sharded attributes are the local rows
-        sl = slice(r * n_loc, (r + 1) * n_loc)
+        sl = slice(cuts[r], cuts[r + 1])
         np.testing.assert_allclose(o['X_cnt'], g['X_cnt'][sl], rtol=1e-13, atol=1e-13)
         np.testing.assert_allclose(o['X_scl'], g['X_scl'][sl], rtol=1e-12)
         sg = align_signs(o['Ar'], g['Ar'])

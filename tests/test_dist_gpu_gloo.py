@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, fixture, out_dir):
+def _worker(rank, world, port, fixture, out_dir, uneven=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -36,8 +36,9 @@ def _worker(rank, world, port, fixture, out_dir):
         g = load_golden(fixture)
         X = g['X']
         n = X.shape[0]
-        n_loc = n // world
-        row0 = rank * n_loc
+        from tests.test_dist_gloo import _cuts
+        cuts = _cuts(n, world, uneven)
+        row0, n_loc = cuts[rank], cuts[rank + 1] - cuts[rank]
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
                   engine=HipEngine('cuda:0'))
         spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'], n_modes=g['n_modes'])
@@ -45,21 +46,25 @@ def _worker(rank, world, port, fixture, out_dir):
         spr.train(C)
         A3, S3 = spr.predict(list(g['ys']))
         X3 = spr.reconstruct(A3)
+        x1 = spr.reconstruct(A3[:1], to_host=False, wait=False).wait()        # one vector, field kept in HBM
+        np.testing.assert_array_equal(x1.cpu().numpy()[0], X3[:, 0])
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, Sigma=spr.Sigma_r, X3=X3, A3=A3, Ar=spr.Ar,
                  passes=spr.gram_refine_passes_)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('fixture,world', [('g3_num8', 2), ('g2_num4', 3), ('cond_1e7', 2), ('g5_pareto', 2)])
-def test_sharded_hip_path_two_ranks_one_gpu(tmp_path, fixture, world):
+@pytest.mark.parametrize('fixture,world,uneven', [('g3_num8', 2, False), ('g2_num4', 3, False), ('cond_1e7', 2, False),
+                                                  ('g5_pareto', 2, False), ('g3_num8', 3, True), ('g4_num5', 2, True)])
+def test_sharded_hip_path_two_ranks_one_gpu(tmp_path, fixture, world, uneven):
+    """uneven: row blocks of different sizes, cut anywhere (g4's 999 rows do not divide): padded field gather + packing"""
     import torch.multiprocessing as mp
     from tests.conftest import load_golden
     from tests.parity import REL_FRO, align_signs, rel_fro
     g = load_golden(fixture)
     n = g['X'].shape[0]
-    assert n % world == 0
-    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path)), nprocs=world, join=True)
+    assert uneven or n % world == 0
+    mp.spawn(_worker, args=(world, _free_port(), fixture, str(tmp_path), uneven), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
     for o in outs:
         np.testing.assert_array_equal(o['piv'], g['piv'])                   # global indices, exact, ordered

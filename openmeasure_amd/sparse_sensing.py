@@ -559,6 +559,45 @@ def _sign_fix(V):
     return V * sgn
 
 
+class _DeviceState(dict):
+    """The tensors an object keeps in HBM, by name.  An unpickled object starts with host copies only (``stash``): an
+    entry is uploaded when it is first asked for, so loading a pickle needs no GPU until the object is used."""
+
+    def __init__(self, stash=None, upload=None):
+        super().__init__()
+        self.stash = dict(stash or {})
+        self.upload = upload
+
+    def __missing__(self, key):
+        if key in self.stash:
+            t = self[key] = self.upload(self.stash.pop(key))
+            return t
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.stash
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def pop(self, key, *default):
+        if not dict.__contains__(self, key) and key in self.stash:
+            # every pop in this module either discards the entry or wants a BUFFER to overwrite: a host copy is neither
+            del self.stash[key]
+            if default:
+                return default[0]
+            raise KeyError(key)
+        return dict.pop(self, key, *default)
+
+
+#: attributes that never travel in a pickle: the engine, device state (downloaded instead), events, in-flight work
+_TRANSIENT = ('_eng', '_d', '_trace', '_pending', '_pending_field', '_gram_events', '_gram_events_pending', '_layout_src',
+              '_gap_t0', '_G', '_last_decomp', 'comm_timing')
+
+
 class ROM:
     """Reduced-order-model utilities (reference: ROM, sparse_sensing.py:18-511)."""
 
@@ -583,8 +622,45 @@ class ROM:
         if self._row0 + X.shape[0] > n:
             raise ValueError('The local row block does not fit in the global matrix.')
         self._eng = engine
-        self._d = {}            # device-resident state
+        self._d = _DeviceState()    # device-resident state
         self._host = {}         # lazily downloaded copies
+
+    # ------------------------------------------------------------------ pickling (the reference's objects are plain attributes)
+    def __getstate__(self):
+        """What the reference's object would pickle -- X, the fitted arrays, the trained operator -- with everything that
+        lives in HBM downloaded first (a DeviceMatrix becomes the host ndarray of its values; the basis comes down whole: a
+        pickle of a fitted config-3 object is 230 GB, as the reference's would be).  The engine, events and in-flight
+        work stay behind; a process group cannot travel either (the shard keeps its row block, group = default)."""
+        self._materialize()
+        pf = self.__dict__.get('_pending_field')
+        if pf is not None and pf.pending:
+            pf.wait()
+        eng = self._eng
+        state = {k: v for k, v in self.__dict__.items() if k not in _TRANSIENT and not hasattr(v, 'is_cuda')}
+        d_host = dict(self._d.stash)
+        for k, t in self._d.items():
+            if k == 'X' and not isinstance(self.X, DeviceMatrix):
+                continue                                       # the host ndarray X is in the state already
+            d_host[k] = eng.to_host(t)
+        if isinstance(self.X, DeviceMatrix):
+            state['X'] = d_host.pop('X') if 'X' in d_host else eng.to_host(self.X.tensor)
+            state['_basis_f32'] = self.X.basis == 'f32'
+        state['_d_host'] = d_host
+        if self._shard is not None:
+            sh = RowShard(self._shard.row0, self._shard.n_global, None, self._shard.force_collectives,
+                          self._shard.broadcast_basis, self._shard.partial)
+            state['_shard'] = sh
+        return state
+
+    def __setstate__(self, state):
+        d_host = state.pop('_d_host', {})
+        self.__dict__.update(state)
+        self._eng = None                                       # the default engine, created on first use (or assign ._eng)
+
+        def upload(a):
+            eng = self._engine()
+            return eng.to_device(a, dtype=eng.torch.float32 if a.dtype == np.float32 else None)
+        self._d = _DeviceState(d_host, upload)
 
     # ------------------------------------------------------------------ lazily fetched fit results
     _LAZY = ('Ar', 'Sigma_r', 'Vr', 'exp_variance_', 'S_', '_scl_f', '_var_f')
@@ -724,7 +800,8 @@ class ROM:
     def _basis_dtype(self):
         """storage type of Ur: float64 (the reference's, for any dtype of X) unless DeviceMatrix(basis='f32')"""
         t = self._engine().torch
-        return t.float32 if (isinstance(self.X, DeviceMatrix) and self.X.basis == 'f32') else t.float64
+        f32 = (isinstance(self.X, DeviceMatrix) and self.X.basis == 'f32') or self.__dict__.get('_basis_f32', False)
+        return t.float32 if f32 else t.float64
 
     def _all_reduce(self, t):
         if self._dist():

@@ -518,6 +518,41 @@ def test_random_shapes_end_to_end(eng, seed):
         assert rel_fro(xr, ref['X_rec']) <= REL_FRO, (n_points, F, m, r)
 
 
+@pytest.mark.parametrize('device_matrix,f32', [(False, False), (True, False), (True, True)])
+def test_pickle_round_trip_on_the_device(eng, device_matrix, f32):
+    """pickle.dumps of a fitted, trained object downloads what lives in HBM (a DeviceMatrix becomes a host ndarray of its
+    values, an f32 basis stays f32); the loaded object creates its engine and uploads its state on first use and gives the
+    same answers bit for bit -- also after a second fit."""
+    import pickle
+    import torch
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    X = synth_host(3000, 3, 48, 24, 0.7, 1e-3, 11)
+    if f32:
+        X = X.astype(np.float32)
+    Xin = DeviceMatrix(eng.to_device(X, dtype=torch.float32 if f32 else None), basis='f32' if f32 else None) if device_matrix else X
+    spr = SPR(Xin, 3, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=12)
+    C = spr.optimal_placement()
+    spr.train(C)
+    y = np.zeros((12, 3))
+    y[:, 0] = X[spr.sensors_, 5]
+    y[:, 2] = spr.sensors_ // 3000
+    a0, _ = spr.predict(y)
+    x0 = spr.reconstruct(a0)
+    clone = pickle.loads(pickle.dumps(spr))
+    assert clone._eng is None and len(clone._d) == 0 and isinstance(clone.X, np.ndarray) and clone.X.dtype == X.dtype
+    np.testing.assert_array_equal(clone.Ur, spr.Ur)
+    assert clone.Ur.dtype == spr.Ur.dtype
+    a1, _ = clone.predict(y)
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(clone.reconstruct(a1), x0)
+    clone.fit(select_modes='number', n_modes=12)
+    clone.optimal_placement()
+    np.testing.assert_array_equal(clone.sensors_, spr.sensors_)
+    np.testing.assert_array_equal(clone.Sigma_r, spr.Sigma_r)
+    assert clone.Ur.dtype == spr.Ur.dtype
+
+
 def test_masked_placement_vs_oracle(eng):
     from openmeasure_amd.sparse_sensing import SPR
     X = synth_host(3000, 3, 24, 24, 0.75, 1e-3, 77)

@@ -215,6 +215,46 @@ def test_reference_unit_tests_on_class(small):         # tests/test_rom.py, test
     np.testing.assert_allclose(spr.reconstruct(a), X[:, [0]])                          # test_spr.py:48-60
 
 
+@pytest.mark.parametrize('stage', ['constructed', 'fitted', 'trained'])
+def test_pickle_and_deepcopy_round_trip(small, stage):
+    """The reference's objects are plain attributes and pickle as they are; here the state lives behind an engine: the pickle
+    carries host copies of it (no engine, no device handles) and the loaded object uploads them on first use -- same
+    attributes, same predictions, and it can be fitted again."""
+    import copy
+    import pickle
+    from openmeasure_amd.sparse_sensing import _DeviceState
+    X, F, xyz = small
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    if stage != 'constructed':
+        spr.fit(select_modes='number', n_modes=4)
+    if stage == 'trained':
+        C = spr.optimal_placement()
+        spr.train(C)
+    for clone in (pickle.loads(pickle.dumps(spr)), copy.deepcopy(spr)):
+        assert clone._eng is None and isinstance(clone._d, _DeviceState) and len(clone._d) == 0     # nothing uploaded yet
+        clone._eng = NumpyEngine()
+        np.testing.assert_array_equal(clone.X, X)
+        if stage == 'constructed':
+            with pytest.raises(AttributeError):
+                clone.Ur
+        else:
+            for name in ('Ur', 'Ar', 'Vr', 'Sigma_r', 'X_cnt', 'X_scl'):
+                np.testing.assert_array_equal(getattr(clone, name), getattr(spr, name), err_msg=name)
+            assert clone.r == spr.r == 4
+            np.testing.assert_array_equal(clone.reconstruct(clone.Ar[0, :]), spr.reconstruct(spr.Ar[0, :]))
+        if stage == 'trained':
+            np.testing.assert_array_equal(clone.sensors_, spr.sensors_)
+            y = np.zeros((4, 3))
+            y[:, 0] = X[spr.sensors_, 1]
+            y[:, 2] = spr.sensors_ // 10
+            a0, s0 = spr.predict(y)
+            a1, s1 = clone.predict(y)
+            np.testing.assert_array_equal(a1, a0)
+            np.testing.assert_array_equal(clone.reconstruct(a1), spr.reconstruct(a0))
+        clone.fit(select_modes='number', n_modes=3)                    # a loaded object is a full object
+        assert clone.r == 3 and clone.Ur.shape == (20, 3)
+
+
 def test_decomposition_public(small):
     X, F, xyz = small
     rom = ROM(X, F, xyz, engine=NumpyEngine())

@@ -1740,6 +1740,52 @@ class SPR(ROM):
         C = OneHotRows(piv, n)
         return C.toarray() if len(piv) * n * 8 <= _DENSE_C_LIMIT else C
 
+    def gem(self, Ur, n_sensors, mask, d_min, verbose=False):
+        """Reference :586-698, the method optimal_placement(calc_type='gem') calls with the fitted basis: greedy entropy
+        placement on the rows of ``Ur`` (n_local, r) -> the ordered sensor rows (global indices).  ``Ur`` may be the fitted
+        basis (``self.Ur``: the copy in HBM is used) or any other array of that many rows, which is uploaded for the call and
+        leaves the fitted state as it was.  ``verbose`` is accepted and prints nothing (the reference prints its entropy
+        table)."""
+        fitted = self._host.get('Ur')
+        if Ur is fitted and 'Ur' in self._d:
+            self._placement_gem(n_sensors, mask, d_min)
+            return self.sensors_.copy()
+        Ur = np.asarray(Ur)
+        if Ur.ndim != 2 or Ur.shape[0] != self.X.shape[0]:
+            raise ValueError(f'gem: Ur must have one row per (local) row of X, ({self.X.shape[0]}, r); got {Ur.shape}')
+        eng = self._engine()
+        t = eng.torch
+        missing = object()
+        keep_d = {k: (dict.get(self._d, k, missing), self._d.stash.get(k, missing)) for k in ('Ur', 'rowmean')}
+        keep_r, keep_host = self.__dict__.get('r', missing), self._host.pop('Ur', missing)
+        keep_attrs = {k: self.__dict__.get(k, missing) for k in ('_placed', 'sensors_', 'pivot_gap_', 'pivot_sweeps_')}
+        try:
+            self._d.stash.pop('Ur', None)
+            self._d['Ur'] = eng.to_device(Ur, dtype=t.float32 if Ur.dtype == np.float32 else None)
+            if 'rowmean' not in self._d:
+                self._d['rowmean'] = eng.zeros((Ur.shape[0],))    # only its address is used (the measure kernel's centre output)
+            self.r = int(Ur.shape[1])
+            self._placement_gem(n_sensors, mask, d_min)
+            return self.sensors_.copy()
+        finally:
+            for k, v in keep_attrs.items():                    # a placement on a foreign basis is not this object's placement
+                if v is missing:
+                    self.__dict__.pop(k, None)
+                else:
+                    self.__dict__[k] = v
+            for k, (dev, host) in keep_d.items():
+                dict.pop(self._d, k, None)
+                if dev is not missing:
+                    self._d[k] = dev
+                if host is not missing:
+                    self._d.stash[k] = host
+            if keep_r is missing:
+                self.__dict__.pop('r', None)
+            else:
+                self.r = keep_r
+            if keep_host is not missing:
+                self._host['Ur'] = keep_host
+
     def _placement_gem(self, n_sensors, mask, d_min):
         """calc_type='gem' (reference :586-698, :745-751): greedy maximisation of the conditional variance
         sigma_y^2 - S_ya S_aa^-1 S_ay of a row of Ur (its r entries as samples) given the rows picked so far,

@@ -553,6 +553,26 @@ def test_pickle_round_trip_on_the_device(eng, device_matrix, f32):
     assert clone.Ur.dtype == spr.Ur.dtype
 
 
+def test_public_gem_method_on_the_device(eng):
+    """SPR.gem(Ur, ...) (reference :586-698) with the fitted basis and with a foreign one, on the HIP engine"""
+    from openmeasure_amd.sparse_sensing import SPR
+    rng = np.random.default_rng(4)
+    n_points, F, r = 2500, 2, 8
+    X = synth_host(n_points, F, 20, 16, 0.8, 1e-3, 9)
+    xyz = rng.random((n_points, 3))
+    spr = SPR(X, F, xyz, engine=eng)
+    spr.fit(select_modes='number', n_modes=r)
+    C = spr.optimal_placement(calc_type='gem', n_sensors=6)
+    np.testing.assert_array_equal(spr.gem(spr.Ur, 6, None, 0.0, False), np.argmax(np.asarray(C), axis=1))
+    U = rng.standard_normal((n_points * F, 5))
+    want, _ = orc.gem_pivots(U, 4, xyz, F, None, 0.02)
+    Ur0 = spr.Ur.copy()
+    np.testing.assert_array_equal(spr.gem(U, 4, None, 0.02, False), want)
+    assert spr.r == r
+    np.testing.assert_array_equal(spr.Ur, Ur0)
+    np.testing.assert_array_equal(spr.reconstruct(spr.Ar[0, :])[:, 0], spr.reconstruct(spr.Ar[:1])[:, 0])
+
+
 def test_masked_placement_vs_oracle(eng):
     from openmeasure_amd.sparse_sensing import SPR
     X = synth_host(3000, 3, 24, 24, 0.75, 1e-3, 77)

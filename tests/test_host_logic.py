@@ -255,6 +255,33 @@ def test_pickle_and_deepcopy_round_trip(small, stage):
         assert clone.r == 3 and clone.Ur.shape == (20, 3)
 
 
+def test_public_gem_method():
+    """SPR.gem(Ur, n_sensors, mask, d_min, verbose) -- the method optimal_placement('gem') calls (reference :586-698, :747) --
+    on the fitted basis, on a foreign basis (fitted state untouched) and on an object that was never fitted; against the
+    oracle's literal covariance formulas."""
+    from oracle import spr_oracle as orc
+    rng = np.random.default_rng(1)
+    n_points, F, r = 80, 2, 6
+    X, xyz = rng.standard_normal((n_points * F, 9)), rng.random((n_points, 2))
+    U = rng.standard_normal((n_points * F, r))
+    mask = rng.random(n_points * F) < 0.6
+    spr = SPR(X, F, xyz, engine=NumpyEngine())
+    want, _ = orc.gem_pivots(U, 4, xyz, F, None, 0.0)
+    np.testing.assert_array_equal(spr.gem(U, 4, None, 0.0, False), want)            # never fitted: only Ur and xyz matter
+    assert not hasattr(spr, 'r') and not hasattr(spr, 'sensors_')
+    spr.fit(select_modes='number', n_modes=r)
+    C = spr.optimal_placement(calc_type='gem', n_sensors=4)
+    np.testing.assert_array_equal(spr.gem(spr.Ur, 4, None, 0.0, False), np.argmax(np.asarray(C), axis=1))
+    Ur0, sensors0 = spr.Ur.copy(), spr.sensors_.copy()
+    want, _ = orc.gem_pivots(U, 5, xyz, F, mask, 0.05)
+    np.testing.assert_array_equal(spr.gem(U, 5, mask, 0.05, True), want)
+    assert spr.r == r
+    np.testing.assert_array_equal(spr.Ur, Ur0)
+    np.testing.assert_array_equal(spr.sensors_, sensors0)
+    with pytest.raises(ValueError):
+        spr.gem(U[:-1], 4, None, 0.0, False)
+
+
 def test_decomposition_public(small):
     X, F, xyz = small
     rom = ROM(X, F, xyz, engine=NumpyEngine())

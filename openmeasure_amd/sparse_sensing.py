@@ -625,6 +625,19 @@ class ROM:
         self._d = _DeviceState()    # device-resident state
         self._host = {}         # lazily downloaded copies
 
+    # ------------------------------------------------------------------ reference methods outside the built path
+    def CPOD(self, problem_dict, **kwargs):
+        """Reference :434-461: the constrained POD solves one cvxpy problem per snapshot.  Not built (no conic solver on
+        the device, cvxpy not available to pin a result against): raises like every option without a device path."""
+        raise NotImplementedError('CPOD (constrained POD through cvxpy, reference :434-461) is not part of this implementation.')
+
+    def adaptive_sampling(self, P, scale_type='std'):
+        """Reference :377-432.  Not built: its snapshot weights contain Vt[k,:] @ V[k,:] (:401), which changes with the
+        arbitrary signs LAPACK gives the singular vectors, and its candidate points come from an unseeded Latin hypercube --
+        there is no result to reproduce."""
+        raise NotImplementedError('adaptive_sampling (reference :377-432) is not part of this implementation: its result '
+                                  'depends on the sign convention of the singular vectors and on an unseeded sampler.')
+
     # ------------------------------------------------------------------ pickling (the reference's objects are plain attributes)
     def __getstate__(self):
         """What the reference's object would pickle -- X, the fitted arrays, the trained operator -- with everything that
@@ -1740,7 +1753,7 @@ class SPR(ROM):
         C = OneHotRows(piv, n)
         return C.toarray() if len(piv) * n * 8 <= _DENSE_C_LIMIT else C
 
-    def gem(self, Ur, n_sensors, mask, d_min, verbose=False):
+    def gem(self, Ur, n_sensors, mask, d_min, verbose):
         """Reference :586-698, the method optimal_placement(calc_type='gem') calls with the fitted basis: greedy entropy
         placement on the rows of ``Ur`` (n_local, r) -> the ordered sensor rows (global indices).  ``Ur`` may be the fitted
         basis (``self.Ur``: the copy in HBM is used) or any other array of that many rows, which is uploaded for the call and

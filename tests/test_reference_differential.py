@@ -114,3 +114,28 @@ def test_every_attribute_of_a_used_reference_object_exists_here(sps):
         elif isinstance(a, (int, str, bool)) or a is None:
             assert a == b, name
     assert abs(ref.k - mine.k) <= 1e-12 * ref.k
+
+
+def test_every_public_method_of_the_reference_exists_with_its_signature(sps):
+    """names, parameter names, order and defaults of every public method of ROM and SPR (extra trailing keyword parameters
+    are allowed: shard=, engine=, to_host=, wait=); CPOD and adaptive_sampling exist and raise NotImplementedError."""
+    import inspect
+    import openmeasure_amd.sparse_sensing as mine
+    for cls in ('ROM', 'SPR'):
+        R, M = getattr(sps, cls), getattr(mine, cls)
+        for name, f in inspect.getmembers(R, inspect.isfunction):
+            if name.startswith('_') and name != '__init__':
+                continue
+            g = getattr(M, name)
+            pr, pm = list(inspect.signature(f).parameters.values()), list(inspect.signature(g).parameters.values())
+            assert len(pm) >= len(pr), (cls, name)
+            for a, b in zip(pr, pm):
+                assert a.name == b.name and a.default == b.default and a.kind == b.kind, (cls, name, a, b)
+            for extra in pm[len(pr):]:
+                assert extra.default is not inspect.Parameter.empty, (cls, name, extra)
+    from tests.numpy_engine import NumpyEngine
+    o = mine.SPR(np.zeros((4, 2)), 2, None, engine=NumpyEngine())
+    with pytest.raises(NotImplementedError):
+        o.CPOD({})
+    with pytest.raises(NotImplementedError):
+        o.adaptive_sampling(np.zeros((2, 1)))

@@ -2,7 +2,7 @@
 """Repeat the whole step (fit with the gap filler forced on, placement, train, predict, reconstruct) a few hundred times on
 the same resident matrix and count results that differ IN ANY BIT from the first round: spectrum, sensors, coefficients, field.
 A race -- the filler's re-queued Gram launch against the real one, the side-stream copies, the fused step kernel's tickets --
-would show up as a sporadic difference.  GPU box.   usage: python tools/step_stress.py [rounds]"""
+would show up as a sporadic difference.  GPU box.   usage: python tools/step_stress.py [rounds] [workload:cells ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,14 +14,16 @@ from openmeasure_amd.synth import make_R
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 eng = HipEngine('cuda:0')
-for name, cells in (('c3', 250_000), ('c2', 300_000), ('c5s', 60_000), ('c3', 1_250_000)):
+shapes = [(a.split(':')[0], int(a.split(':')[1])) for a in sys.argv[2:]] or [('c3', 250_000), ('c2', 300_000), ('c5s', 60_000),
+                                                                             ('c3', 1_250_000)]
+for name, cells in shapes:
     wl = bench.WORKLOADS[name]
     F, m, s = wl['features'], wl['m'], wl['s']
     Xd = eng.synth(cells * F, m, 0, cells, eng.to_device(make_R(m, s, seed=1234)), 1e-3, 1234)
     spr = SPR(DeviceMatrix(Xd), F, None, engine=eng)
     spr._GAP_FILL_MIN_MS = 0.0                      # fill whatever gap this host leaves
     ref, bad, fills = None, 0, 0
-    reps = rounds if cells < 1_000_000 else max(rounds // 4, 10)
+    reps = rounds if (cells < 1_000_000 or len(sys.argv) > 2) else max(rounds // 4, 10)
     t0 = time.time()
     for it in range(reps):
         spr.fit(select_modes='number', n_modes=s)

@@ -17,6 +17,9 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef PAIRS_MAX
 #define PAIRS_MAX 7          // slice pairs with s + t <= PAIRS_MAX (7: 36 pairs of 8 slices)
 #endif
+#ifndef MODEL_PIPE
+#define MODEL_PIPE 0       // n > 0: slicing of the next k step interleaved with the MFMAs, n vector instructions per MFMA
+#endif
 #ifndef MODEL_ABLATE
 #define MODEL_ABLATE 0       // 1: no MFMAs, 2: no slicing (digits = raw words), 3: neither (loads + stores only)
 #endif
@@ -65,10 +68,7 @@ __global__ __launch_bounds__(WAVES * 64) void proj_i8_model(const double *__rest
     for (int d = 0; d < NS; ++d)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) acc[d][ct] = (i32x4){0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      // ---- slicing: 16 values -> eight planes of 16 signed 7-bit digits (4 dwords each)
-      unsigned dig[NS][4];
+    auto slice = [&](int ks, unsigned (&dig)[NS][4]) {        // 16 values -> eight planes of 16 signed 7-bit digits
 #pragma unroll
       for (int g = 0; g < 4; ++g) {                           // four values per packed dword
         int d[4][NS];
@@ -96,11 +96,8 @@ __global__ __launch_bounds__(WAVES * 64) void proj_i8_model(const double *__rest
 #pragma unroll
         for (int s = 0; s < NS; ++s) dig[s][g] = pack4(d[0][s], d[1][s], d[2][s], d[3][s]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // the registers of this k step are free: request the next block's piece
-#pragma unroll
-      for (int q = 0; q < 8; ++q) x[ks][q] = *reinterpret_cast<const f64x2 *>(rpn + 64 * ks + 2 * q);
-      // ---- MFMAs: slice pairs (s, t), s + t <= PAIRS_MAX, against the four column tiles
+    };
+    auto mfmas = [&](int ks, const unsigned (&dig)[NS][4]) {  // slice pairs (s, t), s + t <= PAIRS_MAX, four column tiles
 #pragma unroll
       for (int t = 0; t < NS; ++t) {
         i32x4 bf[4];
@@ -119,8 +116,45 @@ __global__ __launch_bounds__(WAVES * 64) void proj_i8_model(const double *__rest
           }
         }
       }
+    };
+#if MODEL_PIPE
+    // software pipeline: the digits of k step ks + 1 are cut while the MFMAs of step ks run (one instruction stream: the
+    // scheduler is asked for {1 MFMA, MODEL_PIPE vector instructions} groups)
+    unsigned digA[NS][4], digB[NS][4];
+    slice(0, digA);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[0][q] = *reinterpret_cast<const f64x2 *>(rpn + 2 * q);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      unsigned (&cur)[NS][4] = (ks & 1) ? digB : digA;
+      unsigned (&nxt)[NS][4] = (ks & 1) ? digA : digB;
+      if (ks < 3) slice(ks + 1, nxt);
+      mfmas(ks, cur);
+      if (ks < 3) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[ks + 1][q] = *reinterpret_cast<const f64x2 *>(rpn + 64 * (ks + 1) + 2 * q);
+      }
+#pragma unroll
+      for (int rep = 0; rep < 144; ++rep) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, MODEL_PIPE, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
+#else
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      unsigned dig[NS][4];
+      slice(ks, dig);
+      __builtin_amdgcn_sched_barrier(0);
+      // the registers of this k step are free: request the next block's piece
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[ks][q] = *reinterpret_cast<const f64x2 *>(rpn + 64 * ks + 2 * q);
+      mfmas(ks, dig);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     // ---- combination of the digit groups in f64, row and column scales, store (result tile: row 4 (l >> 4) + reg, col l & 15)
     const double rscale = __longlong_as_double((long long)(emax ? emax : 1) << 52) * 0x1p-55;
     double *up = U + (b * 16 + 4 * kq) * R + li;
@@ -162,7 +196,7 @@ int main(int argc, char **argv) {
   }
   if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
   const double gb = (double)n * (M + R) * 8 / 1e9;
-  printf("proj_i8_model (pairs s+t <= %d, ablate %d): %lld rows: %.3f ms = %.2f TB/s of X + Ur  (f64 W-stationary kernel: 52.5 ms per 90M rows, 6.4-6.7 per 11.25M)\n",
-         PAIRS_MAX, MODEL_ABLATE, (long long)n, best, gb / best);
+  printf("proj_i8_model (pairs s+t <= %d, ablate %d, pipe %d): %lld rows: %.3f ms = %.2f TB/s of X + Ur  (f64 W-stationary kernel: 52.5 ms per 90M rows, 6.4-6.7 per 11.25M)\n",
+         PAIRS_MAX, MODEL_ABLATE, MODEL_PIPE, (long long)n, best, gb / best);
   return 0;
 }

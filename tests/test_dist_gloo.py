@@ -95,6 +95,12 @@ def test_sharded_path_with_unequal_blocks(tmp_path, fixture, world):
     _run_sharded(tmp_path, fixture, world, False, uneven=True)
 
 
+@pytest.mark.parametrize('fixture,world', [('g3_num8', 3), ('g2_num4_mask', 2)])
+def test_unequal_blocks_on_the_candidate_model(tmp_path, fixture, world):
+    """unequal row blocks under the candidate-set model of the placement (every rank keeps its own pool over ITS rows)"""
+    _run_sharded(tmp_path, fixture, world, False, candidates=True, uneven=True)
+
+
 def _gap_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'

@@ -215,7 +215,43 @@ def count_gpus(env=None):
     return k if lim is None else min(k, lim)
 
 
-def comm_summary(comm_main, comm_sync, dist_on, sync_gather, F, m, world, n_loc):
+class Watchdog:
+    """First-contact armour for multi-GPU runs: a rank that makes no progress for `timeout_s` seconds -- a collective its
+    peers never joined, a stream wait on a counter nobody raises -- says where it stands (phase label, step, the collective
+    brackets recorded so far, every thread's Python stack) and ends the PROCESS with a non-zero code; the launcher then stops
+    the other ranks.  It never re-executes anything.  `beat(label)` is called at every phase boundary of the run."""
+
+    def __init__(self, timeout_s, rank=0, describe=None, exit_code=3):
+        import threading
+        self.timeout_s, self.rank, self.describe, self.exit_code = float(timeout_s), rank, describe, exit_code
+        self.label, self.t, self.on = 'start', time.time(), self.timeout_s > 0
+        if self.on:
+            threading.Thread(target=self._run, daemon=True, name='spr-watchdog').start()
+
+    def beat(self, label):
+        self.label, self.t = label, time.time()
+
+    def stop(self):
+        self.on = False
+
+    def _run(self):
+        while self.on:
+            time.sleep(min(1.0, max(0.05, self.timeout_s / 4)))
+            idle = time.time() - self.t
+            if self.on and idle > self.timeout_s:
+                import faulthandler
+                log(f'[rank {self.rank}] WATCHDOG: no progress for {idle:.0f} s in phase {self.label!r}')
+                try:
+                    if self.describe is not None:
+                        log(f'[rank {self.rank}] WATCHDOG: {self.describe()}')
+                except Exception as exc:                       # noqa: BLE001 -- the dump must not stop the exit
+                    log(f'[rank {self.rank}] WATCHDOG: describe() failed: {exc}')
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                sys.stderr.flush()
+                os._exit(self.exit_code)
+
+
+def comm_summary(comm_main, comm_sync, dist_on, sync_gather, F, m, world, n_loc, gather_path=None, paths=None):
     """The `comm` object of the JSON line from the mean bracket times (ms) of the headline loop and of the sync-gather loop
     (ROM.comm_timing keys 'allreduce', 'gather', 'gather_exposed').  None = no such collective ran."""
     src = comm_sync if comm_sync else comm_main
@@ -229,6 +265,11 @@ def comm_summary(comm_main, comm_sync, dist_on, sync_gather, F, m, world, n_loc)
     for k_ in ('allreduce_ms', 'gather_ms', 'gather_exposed_ms'):
         if comm[k_] is not None:
             comm[k_] = round(comm[k_], 4)
+    if dist_on:
+        # which exchange carried the field in the headline loop ('p2p ...': SDMA pushes into peer-mapped buffers, no compute
+        # units; 'rccl ...': the all-gather kernel -- with the reason when p2p was not available), and both timed side by side
+        comm['gather_path'] = gather_path
+        comm['paths'] = paths
     return comm
 
 
@@ -255,6 +296,11 @@ def parse_args(argv=None):
                     help="developer aid: run ONE rank's shard of an N-rank job on this GPU (collectives in a 1-rank RCCL "
                          'group); the line says so and is not an N-GPU number')
     ap.add_argument('--share-rank', type=int, default=0, help='which rank of --share-of')
+    ap.add_argument('--gather', default=os.environ.get('SPR_BENCH_GATHER', 'auto'), choices=('auto', 'p2p', 'rccl'),
+                    help="field exchange of the headline loop (RowShard.gather); with 'auto' the other path is timed as well")
+    ap.add_argument('--gap-filler', action='store_true',
+                    help='switch ROM.gap_filler on (opt-in: fit() re-queues its Gram kernel on part of X into the host gap to '
+                         'hold the clock; the line then says so and counts the rows)')
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
@@ -339,13 +385,19 @@ def run_rank(args):
 
     if share:
         # one rank's block of an N-rank job, alone: the global row numbering (feature boundaries) of the N-rank job
-        shard = RowShard(row0, n_glob, force_collectives=True, partial=True)
+        shard = RowShard(row0, n_glob, force_collectives=True, partial=True, gather=args.gather)
     else:
-        shard = RowShard(row0, n_glob, force_collectives=force_dist) if (world > 1 or force_dist) else None
+        shard = (RowShard(row0, n_glob, force_collectives=force_dist, gather=args.gather)
+                 if (world > 1 or force_dist) else None)
     # f32-stored workloads (config 5) also store the basis in f32 -- the explicit storage option; the default would be f64
     spr = SPR(DeviceMatrix(Xd, basis='f32' if f32 else None), F, None, shard=shard, engine=eng)
     if args.placement_norms != 'auto':
         spr.placement_norms = args.placement_norms == 'on'
+    if args.gap_filler:
+        spr.gap_filler = True
+    wd = Watchdog(float(os.environ.get('SPR_BENCH_WATCHDOG_S', '300')), rank,
+                  lambda: dict(collective_brackets={k: len(v) for k, v in (spr.comm_timing or {}).items()},
+                               last_collective=getattr(spr, 'last_comm_', None), gather_path=getattr(spr, 'gather_path_', None)))
 
     def barrier():
         if world > 1 or force_dist:
@@ -353,6 +405,7 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     dist_on = world > 1 or force_dist
+    wd.beat('first fit')
     spr.fit(select_modes='number', n_modes=s)     # first call: allocations, RCCL warm-up
     a_d = eng.to_device(spr.Ar[:1].copy())        # (1, r) coefficient vector, resident
     if dist_on:
@@ -361,15 +414,22 @@ def run_rank(args):
     def done(f):
         return f.wait() if hasattr(f, 'wait') else f
 
+    fill_rows = []
+
     def timed_loop(sync_gather):
         """W warm-up steps, then K steps bracketed by barrier + device sync on both sides.  -> (seconds, max over ranks;
-        per-step kernel event triples; mean ms of every collective bracket; the last field)"""
+        this rank's own seconds; per-step kernel event triples; mean ms of every collective bracket; the last field)"""
         def step(prev=None, timers=None):
             if timers is not None:
                 timers.append((eng.time_next('stats_gram'), eng.time_next('project'), eng.time_next('reconstruct')))
+            wd.beat('fit')
             spr.fit(select_modes='number', n_modes=s)
-            done(prev)                            # the previous field's all-gather ran under this fit: join it now
-            # default: the gather is left in flight and overlaps the next step's (MFMA-bound) Gram pass
+            if timers is not None:
+                fill_rows.append(int(spr.__dict__.get('_gap_fill_rows', 0)) if spr.gap_filler else 0)
+            wd.beat('join of the previous field')
+            done(prev)                            # the previous field's exchange ran under this fit: join it now
+            wd.beat('reconstruct')
+            # default: the exchange is left in flight and overlaps the next step's (MFMA-bound) Gram pass
             return spr.reconstruct(a_d, to_host=False, wait=sync_gather)
 
         field = None
@@ -380,11 +440,16 @@ def run_rank(args):
         timers = []
         if dist_on:
             spr.comm_timing.clear()
+        wd.beat('barrier in front of the timed steps')
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             field = step(field, timers)
-        field = done(field)                       # the last gather joins the compute stream inside the timed region
+        wd.beat('last join')
+        field = done(field)                       # the last exchange joins the compute stream inside the timed region
+        torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0         # this rank's own time (before the others are waited for)
+        wd.beat('barrier behind the timed steps')
         barrier()
         dt = time.perf_counter() - t0
         if dist_on:
@@ -395,19 +460,59 @@ def run_rank(args):
         if dist_on:
             for key, pairs in spr.comm_timing.items():
                 comm[key] = float(np.mean([eng.elapsed_ms(e0, e1) for e0, e1 in pairs])) if pairs else None
-        return dt, timers, comm, field
+        return dt, dt_own, timers, comm, field
 
-    dt, timers, comm_main, field = timed_loop(args.sync_gather)
+    # N > 1: the field exchange of the headline loop is RowShard(gather=...) as resolved at the first sharded reconstruct()
+    # ('auto': p2p when its collective self-test passes); the OTHER path is then timed with the same loops, so one run says
+    # what each costs, pipelined and joined inside the step
+    path_results = {}
+    if dist_on:
+        wd.beat('first sharded reconstruct (gather path set-up)')
+        done(spr.reconstruct(a_d, to_host=False, wait=True))
+        head_path = 'p2p' if spr.gather_path_.startswith('p2p') else 'rccl'
+        head_why = spr.gather_path_
+        others = []
+        if args.gather == 'auto':
+            others = ['rccl'] if head_path == 'p2p' else []
+    else:
+        head_path, head_why, others = None, None, []
+
+    dt, dt_own, timers, comm_main, field = timed_loop(args.sync_gather)
     dt_sync, comm_sync = None, {}
     if dist_on and not args.sync_gather:
-        # the same K steps once more with the gather joined inside every step: what the pipelining hides, and the
-        # duration of the gather itself (its bracket closes behind the join)
-        dt_sync, _, comm_sync, _ = timed_loop(True)
+        # the same K steps once more with the exchange joined inside every step: what the pipelining hides, and the
+        # duration of the exchange itself (its bracket closes behind the join)
+        dt_sync, _, _, comm_sync, _ = timed_loop(True)
+    if dist_on:
+        path_results[head_path] = dict(ms_per_step=round(1e3 * dt / args.steps, 4),
+                                       ms_per_step_sync_gather=round(1e3 * (dt_sync if dt_sync is not None else dt) / args.steps, 4),
+                                       allreduce_ms=comm_main.get('allreduce'),
+                                       gather_ms=(comm_sync or comm_main).get('gather'),
+                                       gather_exposed_ms=comm_main.get('gather_exposed'), why=head_why)
+        for other in others:
+            wd.beat(f'switch to gather path {other}')
+            spr.use_gather(other)
+            done(spr.reconstruct(a_d, to_host=False, wait=True))
+            dt_o, _, _, comm_o, _ = timed_loop(False)
+            dt_os, _, _, comm_os, _ = timed_loop(True)
+            path_results[other] = dict(ms_per_step=round(1e3 * dt_o / args.steps, 4),
+                                       ms_per_step_sync_gather=round(1e3 * dt_os / args.steps, 4),
+                                       allreduce_ms=comm_o.get('allreduce'), gather_ms=comm_os.get('gather'),
+                                       gather_exposed_ms=comm_o.get('gather_exposed'), why=spr.gather_path_)
+        if others:
+            wd.beat('back to the headline gather path')
+            spr.use_gather(args.gather)
+            field = done(spr.reconstruct(a_d, to_host=False, wait=True))
+        for v in path_results.values():
+            for k_ in ('allreduce_ms', 'gather_ms', 'gather_exposed_ms'):
+                if v[k_] is not None:
+                    v[k_] = round(v[k_], 4)
     ms_per_step = 1e3 * dt / args.steps
     # collectives, from event pairs on the stream each one is ordered on (ROM.comm_timing): the ONE all-reduce of fit(), the
-    # field all-gather of reconstruct() timed where it is joined inside the step, and what of it stays exposed when it is
+    # field exchange of reconstruct() timed where it is joined inside the step, and what of it stays exposed when it is
     # left in flight under the next Gram pass (the wait of the join).  None = no such collective ran (N = 1).
-    comm = comm_summary(comm_main, comm_sync, dist_on, args.sync_gather, F, m, world, n_loc)
+    comm = comm_summary(comm_main, comm_sync, dist_on, args.sync_gather, F, m, world, n_loc, gather_path=head_why,
+                        paths=path_results or None)
     # never print a number for a run that computed garbage: spectrum, basis sample and field must be finite
     fld = field if torch.is_tensor(field) else None
     if not (np.all(np.isfinite(spr.S_[:s])) and bool(torch.isfinite(spr._d['Ur'][:4096].double()).all())
@@ -468,18 +573,36 @@ def run_rank(args):
                                       f"separate passes (round {ent.get('round', '?')})")
     except (OSError, ValueError):
         pass
+    # ONE line per rank that says why a run is slow (every rank logs its own; rank 0 also carries all of them in the JSON
+    # line and names the slowest): its own step time (before it waited for the others), the three kernels, the host
+    # eigen-solve and the collectives of the headline loop
+    nan = float('nan')
+    mine = dict(step_ms=1e3 * dt_own / args.steps, gram_ms=k_ms['stats_gram'], project_ms=k_ms['project'],
+                reconstruct_ms=k_ms['reconstruct'], eig_ms=float(getattr(spr, 'eig_ms_', nan)),
+                allreduce_ms=comm_main.get('allreduce') if comm_main.get('allreduce') is not None else nan,
+                gather_ms=(comm_sync or comm_main).get('gather') if (comm_sync or comm_main).get('gather') is not None else nan,
+                gather_exposed_ms=comm_main.get('gather_exposed') if comm_main.get('gather_exposed') is not None else nan)
+    log(f'[rank {rank}] ' + ' '.join(f'{k_}={v:.3f}' for k_, v in mine.items()))
     per_rank = None
+    slowest = None
     if world > 1:
-        kt = torch.tensor([k_ms['stats_gram'], k_ms['project'], k_ms['reconstruct']], dtype=torch.float64, device=eng.device)
+        keys = list(mine)
+        kt = torch.tensor([mine[k_] for k_ in keys], dtype=torch.float64, device=eng.device)
         allk = [torch.empty_like(kt) for _ in range(world)]
         dist.all_gather(allk, kt)
         per_rank = []
         for q, t in enumerate(allk):
-            v = t.tolist()
-            rf = roofline_of(dict(stats_gram=v[0], project=v[1], reconstruct=v[2]))
+            v = dict(zip(keys, t.tolist()))
+            rf = roofline_of(dict(stats_gram=v['gram_ms'], project=v['project_ms'], reconstruct=v['reconstruct_ms']))
             rf['rank'] = q
-            rf['kernels_ms'] = dict(stats_gram=round(v[0], 4), project=round(v[1], 4), reconstruct=round(v[2], 4))
+            rf['kernels_ms'] = dict(stats_gram=round(v['gram_ms'], 4), project=round(v['project_ms'], 4),
+                                    reconstruct=round(v['reconstruct_ms'], 4))
+            rf['timeline_ms'] = {k_: (None if x != x else round(x, 4)) for k_, x in v.items()}
             per_rank.append(rf)
+        q_slow = int(np.argmax([e['timeline_ms']['step_ms'] for e in per_rank]))
+        slowest = dict(rank=q_slow, **per_rank[q_slow]['timeline_ms'])
+        if rank == 0:
+            log(f'[rank 0] slowest rank: {q_slow} ({per_rank[q_slow]["timeline_ms"]})')
     # whole-step algorithmic bytes: (2m + 2r) n B for X and Ur + 8 n (field, f64) + 16 n (row means)
     step_bytes = (2 * m + 2 * r) * float(n_job) * B + 24.0 * n_job
     hbm_frac = step_bytes / (dt / args.steps) / (world * HBM_PEAK_GBS * 1e9)
@@ -496,6 +619,7 @@ def run_rank(args):
     # The rest of the path, in every run ("timed and reported as separate lines"): optimal_placement('qr'),
     # train, predict.  Two untimed calls first: code objects, allocator growth and the interpreter's first full GC pass
     # all land in the first two placements (tools/placement_probe.py: 180 / 105 / 55 / 55 / 55 ms at config 3)
+    wd.beat('placement / train / predict')
     spr.optimal_placement()
     piv_first = spr.sensors_.copy()
     spr.optimal_placement()
@@ -525,7 +649,9 @@ def run_rank(args):
         path['sensors_vs_f64_basis'] = 'inferred from min_pivot_gap at full size; checked exactly on the parity sample'
 
     extra = {}
+    wd.beat('extra')
     if args.extra:
+        wd.stop()
         extra = dict(optimal_placement_ms=path['optimal_placement_ms'], train_ms=path['train_ms'],
                      predict_ms=path['predict_ms'], min_pivot_gap=gap_min, pivot_sweeps=path['pivot_sweeps'],
                      timing='median of 3 calls after 2 warm-up calls')
@@ -572,11 +698,13 @@ def run_rank(args):
 
     cpu = None
     parity = None
+    wd.beat('cpu baseline / parity leg')
     if rank == 0 and world == 1 and not share and not args.no_cpu:
         from oracle import spr_oracle as orc
         cc = min(wl['cpu_cells'], n_points)
         idx = torch.cat([torch.arange(f * n_points, f * n_points + cc, device=eng.device) for f in range(F)])
         Xs = eng.to_host(Xd[idx])                   # first cc cells of every feature: a valid (cc*F) x m problem
+        wd.stop()                                   # the oracle runs for 10-30 s of host time; nothing below can hang on a peer
         t1 = time.perf_counter()
         # an f32-stored sample goes to the oracle widened: the reference itself would run in f32 on it
         Xo = Xs.astype(np.float64) if f32 else Xs
@@ -643,7 +771,8 @@ def run_rank(args):
             # the same K steps with the field all-gather joined inside every step (N > 1; at N = 1 there is no gather)
             'ms_per_step_sync_gather': (round(1e3 * dt_sync / args.steps, 4) if dt_sync is not None
                                         else round(ms_per_step, 4)),
-            'headline_loop': 'sync gather' if (args.sync_gather or not dist_on) else 'gather overlaps the next Gram pass',
+            'headline_loop': ('sync gather' if (args.sync_gather or not dist_on) else
+                              f'field exchange ({head_path}) left in flight under the next Gram pass'),
             'comm': comm,
             **({'refine': dict(gram_refine_passes=int(spr.gram_refine_passes_), refine_ms=round(float(spr.refine_ms_), 3),
                                refine_over_plain_gram=round(float(spr.refine_ms_) / k_ms['stats_gram'], 3),
@@ -661,8 +790,14 @@ def run_rank(args):
                if (backend != 'nccl' or os.environ.get('SPR_BENCH_ONE_GPU') == '1') else {}),
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
         }
+        out['rank_timeline_ms'] = {k_: (None if v != v else round(v, 4)) for k_, v in mine.items()}
+        out['gap_filler'] = dict(on=bool(spr.gap_filler), rows_per_fit=(int(np.mean(fill_rows)) if fill_rows else 0),
+                                 note='opt-in (--gap-filler): fit() re-queues its Gram kernel over this many rows of X into the '
+                                      'host gap and discards the result -- work inside the timed step that the GB/s model does '
+                                      'not count')
         if per_rank:
             out['roofline_per_rank'] = per_rank
+            out['slowest_rank'] = slowest
         if extra:
             out['extra'] = extra
         out['peak_hbm_GB'] = round(torch.cuda.max_memory_allocated() / 1e9, 2)

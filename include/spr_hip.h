@@ -11,7 +11,8 @@
  *
  * Conventions
  *   - every pointer named d_* is a DEVICE pointer (HBM) owned by the caller; the
- *     library allocates nothing and keeps no state between calls;
+ *     library allocates nothing (one exception: spr_p2p_alloc, whose interprocess handle needs
+ *     the base pointer of an allocation) and keeps no state between calls;
  *   - matrices are row-major float64; "ld*" is the row stride in elements;
  *   - rows of the snapshot matrix are feature-major (global row = f*n_points + cell,
  *     sparse_sensing.py:110); a rank holds the contiguous global rows
@@ -62,10 +63,11 @@ extern "C" {
 #define SPR_MAX_R_WIDE 1024  /* ... the widest basis the placement / solve kernels accept (r <= m in the reference, :336) */
 
 /* Bumped whenever an entry point changes its argument list or meaning (round 3 -> 4: spr_qr_steps_f64 gained
- * first_exact, new entry points arrived).  A binding written for another value must refuse to
+ * first_exact, new entry points arrived; 4 -> 5: the CU-free field exchange spr_p2p_* / spr_field_gather_p2p*,
+ * spr_field_unstage_blocks_f64).  A binding written for another value must refuse to
  * call into this library: openmeasure_amd/_lib.py compares spr_abi_version() with the value its prototypes were
  * written for. */
-#define SPR_ABI_VERSION 2
+#define SPR_ABI_VERSION 3
 int spr_abi_version(void);
 const char *spr_last_error(void);
 /* number of compute units of the current device (used to size persistent grids) */
@@ -295,6 +297,50 @@ int spr_reconstruct_f64(const double *d_Ur, int64_t n_rows, int32_t r, int64_t l
  * the field.) */
 int spr_field_unstage_f64(const double *d_stage, int32_t world, int32_t n_p, int64_t n_loc, double *d_out, int64_t ldo,
                           void *stream);
+/* ... and for row blocks of DIFFERENT sizes (the gather then carries blocks padded to n_max rows):
+ * d_out[v * ldo + off_q + i] = d_stage[q][v][i] for i < rows_q, with (off_q, rows_q) = d_layout[2q], d_layout[2q+1]
+ * (int64, on the device; off_q = first global row of rank q's block minus that of rank 0's). */
+int spr_field_unstage_blocks_f64(const double *d_stage, int32_t world, int32_t n_p, int64_t n_max, const int64_t *d_layout,
+                                 double *d_out, int64_t ldo, void *stream);
+
+/* ---- the same exchange WITHOUT compute units (csrc/p2p.hip, round 5) -------------------------------------------------
+ * RCCL's all-gather runs a device kernel that cannot share a compute unit with the Gram / projection workgroups, so a field
+ * gather left in flight under the next fit() only progresses where a CU is free.  On one node the ranks can instead map each
+ * other's copy of the field (interprocess handles) and WRITE their block into it with the SDMA engines.
+ *   spr_p2p_alloc / spr_p2p_free   a device buffer of n_bytes (multiple of 4096) from hipMalloc and its interprocess handle
+ *                                  (spr_p2p_handle_bytes() bytes at h_handle).  The ONE allocation this library makes: a
+ *                                  handle can only be taken of the base pointer of an allocation.
+ *   spr_p2p_open / spr_p2p_close   map / unmap a buffer exported by ANOTHER process of this node (peer access is enabled
+ *                                  lazily); the handle bytes travel through any channel the caller has (torch.distributed).
+ *   spr_p2p_signal / spr_p2p_wait  hipStreamWriteValue64 / hipStreamWaitValue64(>=) on a 64-bit counter inside such a
+ *                                  buffer (own or mapped): command-processor packets, no kernel.
+ *   spr_p2p_copy                   one device-to-device copy through the SDMA engines (hipMemcpyDeviceToDeviceNoCU).
+ *   spr_field_gather_p2p           this rank's block of the field -- columns [first, first + n_loc) of the n_p rows of its
+ *                                  own (n_p, ldo) copy d_field -- into the same place of every peer's copy: per peer p, on
+ *                                  streams[p]: wait until *d_release_flag[p] >= release_value (a counter in THIS rank's
+ *                                  buffer that peer p raises when it no longer reads what its copy held; 0 = no wait),
+ *                                  n_p copies of n_loc doubles, then *d_peer_arrive_flag[p] = arrive_value (a counter in
+ *                                  peer p's buffer).  The caller orders streams[p] behind the kernel that wrote the block.
+ *   spr_field_gather_p2p_join      `stream` waits until every *d_arrive_flag[p] >= arrive_value (counters in this rank's
+ *                                  own buffer, one per peer): the field is complete for whatever is enqueued next.
+ *   spr_field_gather_p2p_release   *d_peer_release_flag[p] = value for every peer, behind everything enqueued on `stream`
+ *                                  so far (the consumers of the previous field).
+ * All pointer tables are HOST arrays of device pointers.  Replaces the remote half of Ur @ Ar.T being whole on every caller
+ * (sparse_sensing.py:371-375) next to torch.distributed's all_gather; SPR_P2P_BLIT=1 swaps the SDMA copies for blit kernels
+ * (A/B only). */
+size_t spr_p2p_handle_bytes(void);
+int spr_p2p_alloc(size_t n_bytes, void **d_ptr, void *h_handle);
+int spr_p2p_free(void *d_ptr);
+int spr_p2p_open(const void *h_handle, void **d_mapped);
+int spr_p2p_close(void *d_mapped);
+int spr_p2p_signal(void *d_flag, uint64_t value, void *stream);
+int spr_p2p_wait(void *d_flag, uint64_t value, void *stream);
+int spr_p2p_copy(void *d_dst, const void *d_src, int64_t n_bytes, void *stream);
+int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc, int32_t n_peers,
+                         void *const *d_peer_field, void *const *d_release_flag, uint64_t release_value,
+                         void *const *d_peer_arrive_flag, uint64_t arrive_value, void *const *streams);
+int spr_field_gather_p2p_join(void *const *d_arrive_flag, int32_t n_peers, uint64_t arrive_value, void *stream);
+int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream);
 
 /* ---- K6 : QR column pivoting of Ur^T (sensor selection) -----------------------------
  * Replaces scipy.linalg.qr(Ur.T, pivoting=True) (:739) -- only the first s pivots are

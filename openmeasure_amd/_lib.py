@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SPR_HIP_LIBRARY: load another build of the same library (the ASan host build of `make asan`, tests only)
 LIB_PATH = os.environ.get('SPR_HIP_LIBRARY') or os.path.join(_HERE, 'libspr_hip.so')
 
-SPR_ABI_VERSION = 2          # include/spr_hip.h: the value these prototypes were written for
+SPR_ABI_VERSION = 3          # include/spr_hip.h: the value these prototypes were written for
 SPR_MAX_M = 256
 SPR_MAX_M_WIDE = 512
 SPR_MAX_R = 128
@@ -67,6 +67,18 @@ PROTOTYPES = {
     'spr_fill_feature_f64': (C.c_int, [_p, _i64, _i64, _i64, _i32, _p, _p]),
     'spr_reconstruct_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     'spr_field_unstage_f64': (C.c_int, [_p, _i32, _i32, _i64, _p, _i64, _p]),
+    'spr_field_unstage_blocks_f64': (C.c_int, [_p, _i32, _i32, _i64, _p, _p, _i64, _p]),
+    'spr_p2p_handle_bytes': (_sz, []),
+    'spr_p2p_alloc': (C.c_int, [_sz, _p, _p]),
+    'spr_p2p_free': (C.c_int, [_p]),
+    'spr_p2p_open': (C.c_int, [_p, _p]),
+    'spr_p2p_close': (C.c_int, [_p]),
+    'spr_p2p_signal': (C.c_int, [_p, _u64, _p]),
+    'spr_p2p_wait': (C.c_int, [_p, _u64, _p]),
+    'spr_p2p_copy': (C.c_int, [_p, _p, _i64, _p]),
+    'spr_field_gather_p2p': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p, _u64, _p, _u64, _p]),
+    'spr_field_gather_p2p_join': (C.c_int, [_p, _i32, _u64, _p]),
+    'spr_field_gather_p2p_release': (C.c_int, [_p, _i32, _u64, _p]),
     'spr_qr_workspace': (_sz, [_i64]),
     'spr_qr_workspace_r': (_sz, [_i64, _i32]),
     'spr_qr_batch': (_i32, []),

@@ -1,0 +1,141 @@
+// CU-free exchange of the reconstructed field between the ranks of one node (round 5).
+//
+// reconstruct() of a row-sharded SPR ends with every rank handing its (n_p, n_loc) block of the field to every other rank
+// (north_star: "a final all-gather for the reconstructed field"; reference: the (n, n_p) array Ur @ Ar.T of
+// sparse_sensing.py:371-375, whole on every caller).  RCCL's all-gather does that with a device kernel of 256 threads,
+// 261-280 VGPRs per wave and 19.7 KB of LDS, which cannot share a compute unit with the Gram or projection workgroups
+// (DESIGN.md 5c): left in flight under the next fit() it only progresses where a CU is free.  This file moves the same bytes
+// without a single wave:
+//
+//   * every rank owns one buffer from hipMalloc (the one allocation this library makes: an interprocess handle needs the
+//     BASE pointer of an allocation, which a sub-allocating caller cannot give) and exports it (hipIpcGetMemHandle); the
+//     other ranks of the node map it (hipIpcOpenMemHandle, peer access enabled lazily);
+//   * a rank's block goes straight from its own copy of the field into the same place of every peer's copy with
+//     hipMemcpyAsync(..., hipMemcpyDeviceToDeviceNoCU): the SDMA engines, one stream per peer so the copies to different
+//     peers use different engines / xGMI links;
+//   * arrival and buffer release are 64-bit counters in the exported buffers, written with hipStreamWriteValue64 behind the
+//     copies and awaited with hipStreamWaitValue64 in front of the consumer -- command-processor packets, no kernel.
+//
+// Measured on one MI355X, two processes (tools/lab/p2p_probe.hip, profiles/r05_p2p_probe.txt): a NoCU copy into the other
+// process's buffer runs at 61 GB/s and leaves a CU-filling kernel's time unchanged (24.87 ms with and without), the same
+// copy as a blit kernel takes 15 ms next to that kernel; write/wait values work on IPC-mapped device memory.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace {
+hipMemcpyKind p2p_kind() {
+  // SPR_P2P_BLIT=1: the default device-to-device copy (blit kernels on compute units) instead of the SDMA engines -- A/B only
+  static int blit = -1;
+  if (blit < 0) {
+    const char *e = getenv("SPR_P2P_BLIT");
+    blit = (e && atoi(e) == 1) ? 1 : 0;
+  }
+  return blit ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToDeviceNoCU;
+}
+}  // namespace
+
+extern "C" size_t spr_p2p_handle_bytes(void) { return sizeof(hipIpcMemHandle_t); }
+
+extern "C" int spr_p2p_alloc(size_t n_bytes, void **d_ptr, void *h_handle) {
+  SPR_REQUIRE(d_ptr && h_handle, SPR_E_INVALID, "spr_p2p_alloc: NULL output");
+  SPR_REQUIRE(n_bytes > 0 && n_bytes % 4096 == 0, SPR_E_INVALID, "spr_p2p_alloc: n_bytes=%zu must be a positive multiple of 4096",
+              n_bytes);
+  void *p = nullptr;
+  SPR_HIP_TRY(hipMalloc(&p, n_bytes));
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    spr_set_error("hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on hosts with dmabuf IPC only)",
+                  hipGetErrorString(e));
+    return SPR_E_HIP;
+  }
+  memcpy(h_handle, &h, sizeof h);
+  *d_ptr = p;
+  return SPR_OK;
+}
+
+extern "C" int spr_p2p_free(void *d_ptr) {
+  if (d_ptr) SPR_HIP_TRY(hipFree(d_ptr));
+  return SPR_OK;
+}
+
+extern "C" int spr_p2p_open(const void *h_handle, void **d_mapped) {
+  SPR_REQUIRE(h_handle && d_mapped, SPR_E_INVALID, "spr_p2p_open: NULL pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, h_handle, sizeof h);
+  void *p = nullptr;
+  SPR_HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  *d_mapped = p;
+  return SPR_OK;
+}
+
+extern "C" int spr_p2p_close(void *d_mapped) {
+  if (d_mapped) SPR_HIP_TRY(hipIpcCloseMemHandle(d_mapped));
+  return SPR_OK;
+}
+
+extern "C" int spr_p2p_signal(void *d_flag, uint64_t value, void *stream) {
+  SPR_REQUIRE(d_flag && (uintptr_t)d_flag % 8 == 0, SPR_E_INVALID, "spr_p2p_signal: NULL / unaligned flag");
+  SPR_HIP_TRY(hipStreamWriteValue64(static_cast<hipStream_t>(stream), d_flag, value, 0));
+  return SPR_OK;
+}
+
+extern "C" int spr_p2p_wait(void *d_flag, uint64_t value, void *stream) {
+  SPR_REQUIRE(d_flag && (uintptr_t)d_flag % 8 == 0, SPR_E_INVALID, "spr_p2p_wait: NULL / unaligned flag");
+  SPR_HIP_TRY(hipStreamWaitValue64(static_cast<hipStream_t>(stream), d_flag, value, hipStreamWaitValueGte, ~0ull));
+  return SPR_OK;
+}
+
+extern "C" int spr_p2p_copy(void *d_dst, const void *d_src, int64_t n_bytes, void *stream) {
+  SPR_REQUIRE(d_dst && d_src && n_bytes > 0, SPR_E_INVALID, "spr_p2p_copy: NULL pointer / empty copy");
+  SPR_HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)n_bytes, p2p_kind(), static_cast<hipStream_t>(stream)));
+  return SPR_OK;
+}
+
+extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc,
+                                    int32_t n_peers, void *const *d_peer_field, void *const *d_release_flag,
+                                    uint64_t release_value, void *const *d_peer_arrive_flag, uint64_t arrive_value,
+                                    void *const *streams) {
+  SPR_REQUIRE(d_field && n_p >= 1 && first >= 0 && n_loc >= 0 && ldo >= first + n_loc, SPR_E_INVALID,
+              "spr_field_gather_p2p: n_p=%d first=%lld n_loc=%lld ldo=%lld", n_p, (long long)first, (long long)n_loc,
+              (long long)ldo);
+  SPR_REQUIRE(n_peers >= 1 && d_peer_field && d_peer_arrive_flag && streams, SPR_E_INVALID,
+              "spr_field_gather_p2p: n_peers=%d (>= 1) / NULL peer table", n_peers);
+  SPR_REQUIRE(release_value == 0 || d_release_flag, SPR_E_INVALID, "spr_field_gather_p2p: release flags missing");
+  const hipMemcpyKind kind = p2p_kind();
+  for (int p = 0; p < n_peers; ++p) {
+    hipStream_t st = static_cast<hipStream_t>(streams[p]);
+    SPR_REQUIRE(d_peer_field[p] && d_peer_arrive_flag[p], SPR_E_INVALID, "spr_field_gather_p2p: peer %d has a NULL pointer", p);
+    if (release_value)   // the peer must have let go of what this buffer held (it writes the slot when it enters its own gather)
+      SPR_HIP_TRY(hipStreamWaitValue64(st, d_release_flag[p], release_value, hipStreamWaitValueGte, ~0ull));
+    if (n_loc > 0) {
+      double *dst = static_cast<double *>(d_peer_field[p]);
+      for (int v = 0; v < n_p; ++v)   // contiguous pieces: one row of the (n_p, ldo) field each
+        SPR_HIP_TRY(hipMemcpyAsync(dst + (int64_t)v * ldo + first, d_field + (int64_t)v * ldo + first, (size_t)n_loc * 8, kind, st));
+    }
+    SPR_HIP_TRY(hipStreamWriteValue64(st, d_peer_arrive_flag[p], arrive_value, 0));
+  }
+  return SPR_OK;
+}
+
+extern "C" int spr_field_gather_p2p_join(void *const *d_arrive_flag, int32_t n_peers, uint64_t arrive_value, void *stream) {
+  SPR_REQUIRE(n_peers >= 1 && d_arrive_flag, SPR_E_INVALID, "spr_field_gather_p2p_join: n_peers=%d (>= 1) / NULL flag table", n_peers);
+  for (int p = 0; p < n_peers; ++p) {
+    SPR_REQUIRE(d_arrive_flag[p], SPR_E_INVALID, "spr_field_gather_p2p_join: flag %d is NULL", p);
+    SPR_HIP_TRY(hipStreamWaitValue64(static_cast<hipStream_t>(stream), d_arrive_flag[p], arrive_value, hipStreamWaitValueGte, ~0ull));
+  }
+  return SPR_OK;
+}
+
+extern "C" int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream) {
+  SPR_REQUIRE(n_peers >= 1 && d_peer_release_flag, SPR_E_INVALID, "spr_field_gather_p2p_release: n_peers=%d (>= 1) / NULL flag table",
+              n_peers);
+  for (int p = 0; p < n_peers; ++p) {
+    SPR_REQUIRE(d_peer_release_flag[p], SPR_E_INVALID, "spr_field_gather_p2p_release: flag %d is NULL", p);
+    SPR_HIP_TRY(hipStreamWriteValue64(static_cast<hipStream_t>(stream), d_peer_release_flag[p], value, 0));
+  }
+  return SPR_OK;
+}

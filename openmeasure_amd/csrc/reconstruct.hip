@@ -413,6 +413,43 @@ extern "C" int spr_field_unstage_f64(const double *d_stage, int32_t world, int32
   return SPR_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void field_unstage_blocks_kernel(const double *__restrict__ stage, int n_p, int64_t n_max,
+                                                                   const int64_t *__restrict__ layout,
+                                                                   double *__restrict__ out, int64_t ldo) {
+  // one (q, v) block per blockIdx.y, rows_q of its n_max padded entries; same copy loop as field_unstage_kernel
+  const int q = blockIdx.y / n_p, v = blockIdx.y - q * n_p;
+  const int64_t off = layout[2 * q], rows = layout[2 * q + 1];
+  const double *src = stage + ((int64_t)q * n_p + v) * n_max;
+  double *dst = out + (int64_t)v * ldo + off;
+  const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    const int64_t n2 = rows / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride)
+      reinterpret_cast<f64x2 *>(dst)[i] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(src) + i);
+    if ((rows & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[rows - 1] = src[rows - 1];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += stride) dst[i] = src[i];
+  }
+}
+}  // namespace
+
+extern "C" int spr_field_unstage_blocks_f64(const double *d_stage, int32_t world, int32_t n_p, int64_t n_max,
+                                            const int64_t *d_layout, double *d_out, int64_t ldo, void *stream) {
+  SPR_REQUIRE(d_stage && d_out && d_layout, SPR_E_INVALID, "spr_field_unstage_blocks_f64: NULL pointer");
+  SPR_REQUIRE(world > 0 && n_p > 0 && n_max > 0 && ldo > 0 && (int64_t)world * n_p <= 65535, SPR_E_INVALID,
+              "spr_field_unstage_blocks_f64: bad shape world=%d n_p=%d n_max=%lld ldo=%lld", world, n_p, (long long)n_max,
+              (long long)ldo);
+  int64_t bx = (n_max / 2 + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(field_unstage_blocks_kernel, dim3((unsigned)bx, (unsigned)(world * n_p)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_stage, (int)n_p, n_max, d_layout, d_out, ldo);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
 // basis stored as f32 (the dtype of an f32 snapshot shard's U), arithmetic and output f64
 extern "C" int spr_reconstruct_u32(const float *d_Ur, int64_t n_rows, int32_t r, int64_t ldu, int64_t row0,
                                    int64_t n_points, int32_t n_features, const double *d_rowmean,

@@ -257,6 +257,22 @@ class HipEngine:
                                                   self._stream()), 'spr_field_unstage_f64')
         return out
 
+    def field_unstage_blocks(self, stage, table, total):
+        """stage (world, n_p, n_max) of blocks padded to n_max rows, table (world, 2) int64 = (offset in the result, rows) per
+        rank -> (n_p, total), the blocks side by side (spr_field_unstage_blocks_f64)."""
+        world, n_p, n_max = stage.shape
+        out = self.empty((n_p, int(total)))
+        lay = self.to_device(np.ascontiguousarray(table, dtype=np.int64).reshape(-1), dtype=self.torch.int64)
+        _lib.check(self.lib.spr_field_unstage_blocks_f64(_ptr(stage.contiguous()), world, n_p, n_max, _ptr(lay), _ptr(out),
+                                                         out.stride(0), self._stream()), 'spr_field_unstage_blocks_f64')
+        return out
+
+    def p2p_field_gather(self, world, rank, all_gather):
+        """The CU-free field exchange of a sharded reconstruct() (openmeasure_amd/p2p.py); buffers are made by ensure()."""
+        import os
+        from .p2p import P2PFieldGather
+        return P2PFieldGather(self, world, rank, all_gather, double_buffer=os.environ.get('SPR_P2P_BUFFERS') == '2')
+
     def stage_to_host(self, stage):
         """The same re-arrangement on the way to the host: block (q, v) of the staged field is copied straight to its place
         in a page-locked (n_p, world * n_loc) result -- no pass over the field on the device.  None: no pinned memory."""

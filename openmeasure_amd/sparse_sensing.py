@@ -76,15 +76,25 @@ class RowShard:
     partial   the ranks of the group together hold only a slice of the global rows (one rank's block of a larger job
               run on its own, bench.py --share-of): the global numbering still places the feature boundaries, the
               statistics, the basis and the gathered field are those of the rows the group holds.
+    gather    how reconstruct() brings every rank's block of the field to every rank: 'rccl' -- torch.distributed's
+              all-gather (a device kernel); 'p2p' -- the ranks of ONE node map each other's copy of the field and push
+              their block into it with the SDMA engines (openmeasure_amd/p2p.py: no compute unit, so a gather left in
+              flight really runs under the next fit(); any block sizes without padding); 'auto' (default) -- 'p2p' when
+              its collective self-test passes on every rank, else 'rccl', with the reason on stderr and in
+              ``rom.gather_path_``.  SPR_GATHER=rccl|p2p|auto overrides.
     """
 
-    def __init__(self, row0, n_global, group=None, force_collectives=False, broadcast_basis=False, partial=False):
+    def __init__(self, row0, n_global, group=None, force_collectives=False, broadcast_basis=False, partial=False,
+                 gather='auto'):
+        if gather not in ('auto', 'p2p', 'rccl'):
+            raise ValueError("gather must be 'auto', 'p2p' or 'rccl'")
         self.row0 = int(row0)
         self.n_global = int(n_global)
         self.group = group
         self.force_collectives = bool(force_collectives)   # issue the collectives even in a 1-rank group (tests)
         self.broadcast_basis = bool(broadcast_basis)
         self.partial = bool(partial)
+        self.gather = gather
 
     @property
     def world(self):
@@ -255,15 +265,18 @@ class OneHotRows:
 
 
 class PendingField:
-    """Result of ``reconstruct(..., to_host=False, wait=False)``: the (n_p, n) field in HBM whose all-gather over the
-    ranks may still be in flight on the communication stream.  ``wait()`` makes the current stream wait for it and
-    returns the tensor; nothing else may read the tensor before that."""
+    """Result of ``reconstruct(..., to_host=False, wait=False)``: the (n_p, n) field in HBM whose exchange between the
+    ranks may still be in flight (RCCL's all-gather on its communication stream, or the SDMA pushes of the p2p path).
+    ``wait()`` makes the current stream wait for it and returns the tensor; nothing else may read the tensor before that.
+    ``needs_cus``: the exchange runs a device kernel (RCCL) and competes with the caller's kernels for compute units."""
 
-    def __init__(self, tensor, works=(), keep=(), on_wait=None):
+    def __init__(self, tensor, works=(), keep=(), on_wait=None, join=None, needs_cus=True):
         self._tensor = tensor
         self._works = list(works)
+        self._join = join                      # p2p path: enqueues the stream waits on the arrival counters
         self._keep = keep                      # the gather's source buffers stay alive until it has been joined
         self._on_wait = on_wait                # ROM.comm_timing: brackets the join with two stream events
+        self.needs_cus = bool(needs_cus) and (bool(self._works) or join is not None)
 
     @property
     def shape(self):
@@ -271,19 +284,19 @@ class PendingField:
 
     @property
     def pending(self):
-        """True while the gather has not been joined."""
-        return bool(self._works)
+        """True while the exchange has not been joined."""
+        return bool(self._works) or self._join is not None
 
     def wait(self):
-        if self._works and self._on_wait is not None:
-            done = self._on_wait()
-            for w in self._works:
-                w.wait()
+        done = self._on_wait() if (self.pending and self._on_wait is not None) else None
+        for w in self._works:
+            w.wait()
+        if self._join is not None:
+            self._join()
+        if done is not None:
             done()
-        else:
-            for w in self._works:
-                w.wait()
         self._works = []
+        self._join = None
         self._keep = ()
         self._on_wait = None
         return self._tensor
@@ -595,7 +608,7 @@ class _DeviceState(dict):
 
 #: attributes that never travel in a pickle: the engine, device state (downloaded instead), events, in-flight work
 _TRANSIENT = ('_eng', '_d', '_trace', '_pending', '_pending_field', '_gram_events', '_gram_events_pending', '_layout_src',
-              '_gap_t0', '_G', '_last_decomp', 'comm_timing')
+              '_gap_t0', '_G', '_last_decomp', 'comm_timing', 'last_comm_', '_layout', '_p2p', '_gather_sel', '_basis_checked', '_basis_diverged')
 
 
 class ROM:
@@ -661,7 +674,7 @@ class ROM:
         state['_d_host'] = d_host
         if self._shard is not None:
             sh = RowShard(self._shard.row0, self._shard.n_global, None, self._shard.force_collectives,
-                          self._shard.broadcast_basis, self._shard.partial)
+                          self._shard.broadcast_basis, self._shard.partial, self._shard.gather)
             state['_shard'] = sh
         return state
 
@@ -686,16 +699,17 @@ class ROM:
     #: W-stationary kernel's range then run the streamed-W kernel); False (ROM, whose users never place sensors): never.
     placement_norms = False
 
-    #: Gap filler.  Between the Gram pass and the projection the device waits for the host (download of the m x m Gram
-    #: matrix, eigen-solve, upload of W: 3.6 ms at m = 256), and a chip that idles for a few milliseconds lowers its clock
-    #: and takes several more to raise it again: the kernels of a fit() + reconstruct() step on one rank's block of
-    #: BASELINE config 4 at N = 8 take 19.9 ms behind such a gap against 18.6 ms back to back (tools/keepalive_probe.py).
-    #: With the filler on, fit() queues the Gram kernel ONCE MORE over the first rows of X, sized to 85 % of the shortest
-    #: host gap of the last fits, before it blocks on the download; the results are discarded.  It costs energy, not time:
-    #: the device has nothing else to do, and the projection never waits for more than the filler overshoots.  Only for
-    #: m >= 128 and host gaps of at least _GAP_FILL_MIN_MS (shorter ones leave no clock drop worth filling); SPR_GAP_FILLER=0 or
-    #: ``rom.gap_filler = False`` turns it off.
-    gap_filler = True
+    #: Gap filler (OPT-IN: ``rom.gap_filler = True`` or SPR_GAP_FILLER=1).  Between the Gram pass and the projection the
+    #: device waits for the host (download of the m x m Gram matrix, eigen-solve, upload of W: 1.8 ms at m = 256, 8 ms at
+    #: m = 512), and a chip that idles for a few milliseconds lowers its clock and takes several more to raise it again: the
+    #: kernels of a fit() + reconstruct() step on one rank's block of BASELINE config 4 at N = 8 take 19.9 ms behind a 3 ms gap
+    #: against 18.6 ms back to back (tools/keepalive_probe.py).  With the filler on, fit() queues the Gram kernel ONCE MORE
+    #: over the first rows of X, sized to 85 % of the shortest host gap of the last fits, before it blocks on the download;
+    #: the results are discarded.  It costs energy (about 2.5 J per fit) and, on a GPU shared with other work, their time --
+    #: which is why a library must not do it unasked.  Only for m >= 128 and host gaps of at least _GAP_FILL_MIN_MS (shorter
+    #: ones leave no clock drop worth filling).  Sharded objects size it from their own host-gap history: ranks with different
+    #: histories queue fillers of different length in front of their projections (unmeasured on more than one GPU).
+    gap_filler = False
     _GAP_FILL_FRACTION = 0.85
     _GAP_FILL_MIN_M = 128
     #: ... and only when the host gap is long enough for the clock to matter: behind a 2.8 ms gap the filler took 0.7 ms off a
@@ -816,9 +830,14 @@ class ROM:
         f32 = (isinstance(self.X, DeviceMatrix) and self.X.basis == 'f32') or self.__dict__.get('_basis_f32', False)
         return t.float32 if f32 else t.float64
 
+    #: (name, shape, time.time()) of the last collective this object ENTERED -- what a watchdog prints when a rank hangs
+    last_comm_ = None
+
     def _all_reduce(self, t):
         if self._dist():
+            import time
             import torch.distributed as dist
+            self.last_comm_ = ('all_reduce', tuple(t.shape), time.time())
             dist.all_reduce(t, group=self._shard.group)
         return t
 
@@ -826,7 +845,9 @@ class ROM:
         """-> tensor (world, *t.shape)"""
         if not self._dist():
             return t[None]
+        import time
         import torch.distributed as dist
+        self.last_comm_ = ('all_gather', tuple(t.shape), time.time())
         flat = t.contiguous().view(-1)                       # concatenated layout: accepted by RCCL and gloo alike
         out = flat.new_empty((self._world() * flat.numel(),))
         dist.all_gather_into_tensor(out, flat, group=self._shard.group)
@@ -1044,8 +1065,9 @@ class ROM:
         import os
         eng = self._engine()
         tr = self.__dict__.get('_trace')
-        return bool(self.gap_filler and hasattr(eng, 'gram_filler') and self._GAP_FILL_MIN_M <= Xd.shape[1]
-                    and os.environ.get('SPR_GAP_FILLER', '1') != '0'
+        env = os.environ.get('SPR_GAP_FILLER')
+        on = (self.gap_filler or env == '1') and env != '0'
+        return bool(on and hasattr(eng, 'gram_filler') and self._GAP_FILL_MIN_M <= Xd.shape[1]
                     and not (tr is not None and tr.on))        # SPR_TRACE synchronises at every mark: its gaps are not fit()'s
 
     def _queue_gap_filler(self, Xd):
@@ -1060,7 +1082,7 @@ class ROM:
         # workgroups (RCCL's kernel wants 261-280 VGPRs per wave and 19.7 KB of LDS; two Gram waves hold 448 of a SIMD's 512
         # registers, two projection waves all of them): its window is this very gap, so it stays empty
         pf = self.__dict__.get('_pending_field')
-        if pf is not None and pf.pending:
+        if pf is not None and pf.pending and pf.needs_cus:     # (the p2p exchange runs on the SDMA engines: nothing to leave free)
             return
         if hist and rate and min(hist) >= self._GAP_FILL_MIN_MS:
             # a wide X (m > 256) is filled with the 256-column kernel on its first slice, whose rows cost (256 / m)^2 of what the
@@ -1291,16 +1313,25 @@ class ROM:
         return U[:, :r], A[:, :r]
 
     # ------------------------------------------------------------------ a3 decomposition
-    def _same_on_all_ranks(self, *arrays):
-        """RowShard(broadcast_basis=True): rank 0's host factors win (heterogeneous hosts)."""
-        if not (self._dist() and self._shard.broadcast_basis):
-            return arrays
+    def _broadcasts_basis(self):
+        """Do the ranks take rank 0's host factors instead of their own?  RowShard(broadcast_basis=True), or the check of
+        the first fit() found ranks whose eigen-solves differ (_factors_agree)."""
+        return self._dist() and (self._shard.broadcast_basis or self.__dict__.get('_basis_diverged', False))
+
+    def _bcast(self, pack):
+        """rank 0's float64 vector `pack` (same length on every rank) -> every rank"""
         import torch.distributed as dist
         eng = self._engine()
-        pack = eng.to_device(np.concatenate([np.ravel(a) for a in arrays]))
-        dist.broadcast(pack, src=dist.get_global_rank(self._shard.group, 0) if self._shard.group is not None else 0,
+        t = eng.to_device(pack)
+        dist.broadcast(t, src=dist.get_global_rank(self._shard.group, 0) if self._shard.group is not None else 0,
                        group=self._shard.group)
-        pack = eng.to_host(pack)
+        return eng.to_host(t)
+
+    def _same_on_all_ranks(self, *arrays):
+        """rank 0's host arrays win (shapes agree on all ranks); identity unless the basis is broadcast"""
+        if not self._broadcasts_basis():
+            return arrays
+        pack = self._bcast(np.concatenate([np.ravel(a) for a in arrays]))
         out, o = [], 0
         for a in arrays:
             out.append(pack[o:o + a.size].reshape(a.shape).copy())
@@ -1312,32 +1343,82 @@ class ROM:
         lam_pos = np.maximum(lam, 0.0)
         return 100 * np.cumsum(lam_pos) / np.sum(lam_pos)      # :274-275
 
+    def _eig_local(self, G, rank_of):
+        """This rank's eigen-solve of the (m, m) Gram matrix -> (lam descending (m,), V with r or m columns, unsigned).
+        The top-r route (dsytrd + dsterf + r inverse iterations + dormqr) for m >= 96 when the caller only needs r <= m/2
+        vectors and sigma_1/sigma_r is within the plain Gram route's range (the refinement pass needs all of V)."""
+        m = G.shape[0]
+        if rank_of is not None and m >= _EIGH_TOP_MIN_M:
+            lam_a, fac = _eigh_tridiagonal(G)
+            lam = lam_a[::-1].copy()
+            S = np.sqrt(np.maximum(lam, 0.0))
+            r = rank_of(self._expvar(lam))
+            if 2 * r <= m and np.isfinite(S[0]) and not S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
+                V = _eigvecs_top(fac, lam_a, r)
+                if V is not None:
+                    return lam, V
+        lam, V = _eigh_small(G)
+        return lam[::-1].copy(), np.ascontiguousarray(V[:, ::-1])
+
+    def _factors_agree(self, lam, V):
+        """First sharded fit(): every rank has eigen-solved the same all-reduced Gram matrix on its own host.  On one node
+        with one LAPACK the results agree bit for bit and nothing needs to be exchanged -- but a node whose sockets or
+        libraries differ would let the ranks project onto slightly different bases WITHOUT any error.  One all-gather of a
+        64-bit digest of (lam, V) per rank settles it; every rank sees the same table, hence the same verdict."""
+        import hashlib
+        eng = self._engine()
+        h = hashlib.blake2b(np.ascontiguousarray(lam).tobytes() + np.ascontiguousarray(V).tobytes(), digest_size=8).digest()
+        mine = np.array([int.from_bytes(h[:4], 'little'), int.from_bytes(h[4:], 'little'), V.shape[1]], dtype=np.float64)
+        table = eng.to_host(self._all_gather(eng.to_device(mine)))
+        return bool(np.all(table == table[0]))
+
     def _spectrum(self, G, rank_of=None):
         """Eigen-decomposition of the (m,m) Gram matrix -> S (desc), V, explained variance (:272-275).
         ``rank_of(exp_variance) -> r``: the caller only needs the r leading vectors -- V then has r columns whenever
-        the top-r route applies (m >= 96, r <= m/2, sigma_1/sigma_r within the plain Gram route's range: the
-        refinement pass needs all of V) and all m otherwise."""
+        the top-r route applies (_eig_local) and all m otherwise.
+        Sharded: every rank solves for itself (identical bits in, identical bits out on one node: no exchange), checked
+        ONCE per object by a digest all-gather at the first fit(); if the ranks differ -- or with
+        RowShard(broadcast_basis=True) -- only rank 0 solves and its factors are broadcast in one fixed-size message
+        [route, columns, lam (m), V (m x m, padded)], so that no rank-local decision (the route, r, a failed inverse
+        iteration) can change the size or the branch of a collective."""
         if not np.all(np.isfinite(G)):
             # a constant feature (X_scl = 0 -> X0 = nan/inf, :169) or a NaN/Inf in X: np.linalg.svd(X0) (:272) raises
             raise np.linalg.LinAlgError('SVD did not converge')
         m = G.shape[0]
-        if rank_of is not None and m >= _EIGH_TOP_MIN_M:
-            lam_a, fac = _eigh_tridiagonal(G)
-            lam = lam_a[::-1]
-            S = np.sqrt(np.maximum(lam, 0.0))
-            expv = self._expvar(lam)
-            r = rank_of(expv)
-            if 2 * r <= m and np.isfinite(S[0]) and not S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
-                V = _eigvecs_top(fac, lam_a, r)
-                if V is not None:
-                    lam, V = self._same_on_all_ranks(lam.copy(), V)
-                    return np.sqrt(np.maximum(lam, 0.0)), _sign_fix(V), self._expvar(lam)
-        lam, V = _eigh_small(G)
-        lam, V = self._same_on_all_ranks(lam, V)
-        lam = lam[::-1]
-        V = _sign_fix(V[:, ::-1])
-        S = np.sqrt(np.maximum(lam, 0.0))
-        return S, V, self._expvar(lam)
+        if self._broadcasts_basis():
+            lam, V = self._broadcast_factors(G, rank_of, None)
+        else:
+            lam, V = self._eig_local(G, rank_of)
+            if self._dist() and not self.__dict__.get('_basis_checked', False):
+                self._basis_checked = True
+                if not self._factors_agree(lam, V):
+                    import sys
+                    self._basis_diverged = True
+                    if self._shard.rank == 0:
+                        print('[openmeasure_amd] the ranks\' host eigen-solves of the same Gram matrix differ (hosts or LAPACK '
+                              'builds differ): rank 0\'s factors are broadcast from now on', file=sys.stderr)
+                    lam, V = self._broadcast_factors(G, rank_of, (lam, V))
+        self.basis_broadcast_ = bool(self._broadcasts_basis())
+        return np.sqrt(np.maximum(lam, 0.0)), _sign_fix(V), self._expvar(lam)
+
+    def _broadcast_factors(self, G, rank_of, have):
+        """Rank 0's (lam, V) on every rank; ``have``: what this rank has already computed (rank 0 re-uses it).  Rank 0's
+        LinAlgError travels in the header, so all ranks raise together."""
+        m = G.shape[0]
+        pack = np.zeros(2 + m + m * m)
+        if self._shard.rank == 0:
+            try:
+                lam, V = have if have is not None else self._eig_local(G, rank_of)
+                pack[0], pack[1] = 1.0, V.shape[1]
+                pack[2:2 + m] = lam
+                pack[2 + m:2 + m + m * V.shape[1]] = V.ravel()
+            except np.linalg.LinAlgError:
+                pack[0] = -1.0
+        pack = self._bcast(pack)
+        if pack[0] < 0:
+            raise np.linalg.LinAlgError('Eigenvalues did not converge')
+        k = int(pack[1])
+        return pack[2:2 + m].copy(), pack[2 + m:2 + m + m * k].reshape(m, k).copy()
 
     def _refine_spectrum(self, S, V, r, Xd, row0, n_points, n_features, inv_scale_d, rowmean_d, center):
         """Conditioning safeguard of the Gram route (hard part 1).
@@ -1415,7 +1496,10 @@ class ROM:
         eng = self._engine()
         Xd = self._Xd()
         m = Xd.shape[1]
+        import time
+        t_eig = time.perf_counter()
         S, V, exp_variance = self._spectrum(G, lambda ev: self._select_rank(ev, m, select_modes, n_modes))
+        self.eig_ms_ = 1e3 * (time.perf_counter() - t_eig)      # host wall time of the m x m eigen-solve (bench.py: per rank)
         self._trace.mark('eigh')
         r = self._select_rank(exp_variance, m, select_modes, n_modes)
         self.gram_refine_passes_ = 0
@@ -1620,17 +1704,21 @@ class ROM:
                                   self._d['scale'], A_d)
         else:
             import torch.distributed as dist
+            lay = self._shard_layout(n_loc)
+            if self._gather_select(n_p, lay) == 'p2p':
+                return self._reconstruct_p2p(Ur_d, A_d, lay, to_host, wait)
+            if np.any(lay[:, 1] != n_loc):
+                return self._gather_unequal(Ur_d, A_d, lay, to_host, wait)
             loc = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
                                   self._d['scale'], A_d)
             # ONE all-gather for all n_p columns: rank q's (n_p, n_loc) block lands at stage[q]; for one column that is
             # the field itself, for several the columns are put side by side afterwards -- on the way to the host when
             # the caller wants a host array (block copies, no pass over the field on the device), by
             # spr_field_unstage_f64 when the field stays in HBM
-            lay = self._shard_layout(n_loc)
-            if np.any(lay[:, 1] != n_loc):
-                return self._gather_unequal(loc, lay, to_host, wait)
             stage = eng.empty((world, n_p, n_loc))
             close = self._comm_bracket('gather')              # issue -> join, when the join happens inside this call
+            import time
+            self.last_comm_ = ('field all_gather (rccl)', (world, n_p, n_loc), time.time())
             work = dist.all_gather_into_tensor(stage.view(-1), loc.contiguous().view(-1), group=self._shard.group,
                                                async_op=True)
             if n_p == 1:
@@ -1656,34 +1744,111 @@ class ROM:
             return out if wait else PendingField(out)
         return eng.to_host(out).T                             # (n, n_p), Fortran-ordered view
 
+    # ------------------------------------------------------------------ the field exchange of sharded objects
+    def _gather_select(self, n_p, lay):
+        """'p2p' or 'rccl' for this object's field exchange (RowShard.gather / SPR_GATHER), decided at the first sharded
+        reconstruct() -- by all ranks together: the p2p set-up ends with a collective self-test whose verdict every rank
+        shares, so no rank can take one path while its peers take the other.  ``gather_path_`` says what was chosen and why."""
+        sel = self.__dict__.get('_gather_sel')
+        if sel is not None:
+            return sel
+        import os
+        import sys
+        eng = self._engine()
+        want = os.environ.get('SPR_GATHER') or self._shard.gather
+        if want not in ('auto', 'p2p', 'rccl'):
+            raise ValueError(f"SPR_GATHER={want!r}: 'auto', 'p2p' or 'rccl'")
+        if want == 'rccl':
+            sel, why = 'rccl', 'rccl (asked for)'
+        elif not hasattr(eng, 'p2p_field_gather'):
+            if want == 'p2p':
+                raise RuntimeError("RowShard(gather='p2p'): this engine has no p2p field exchange")
+            sel, why = 'rccl', 'rccl (engine without p2p exchange)'
+        else:
+            from .p2p import P2PUnavailable
+            px = self.__dict__.get('_p2p')
+            try:
+                if px is None:
+                    px = eng.p2p_field_gather(self._world(), self._shard.rank, self._all_gather)
+                px.ensure(n_p, int(lay[:, 1].sum()))
+                self._p2p = px
+                sel, why = 'p2p', 'p2p (SDMA pushes into peer-mapped buffers, no compute units)'
+            except P2PUnavailable as exc:
+                if want == 'p2p':
+                    raise
+                sel, why = 'rccl', f'rccl (p2p unavailable: {exc})'
+                if self._shard.rank == 0:
+                    print(f'[openmeasure_amd] field exchange falls back to the RCCL all-gather: {exc}', file=sys.stderr)
+        self._gather_sel = sel
+        self.gather_path_ = why
+        return sel
 
-    def _gather_unequal(self, loc, lay, to_host, wait):
-        """Field all-gather for row blocks of different sizes: every rank contributes its (n_p, n_loc) block padded to the
-        largest block (RCCL's all-gather wants equal counts), and the blocks are packed side by side afterwards -- block
-        copies on the way to the host, or one pass over the field on the device (n n_p 8 bytes; the equal-shard path
-        needs neither)."""
+    def use_gather(self, path):
+        """Switch the field exchange of later reconstruct() calls ('auto' | 'p2p' | 'rccl'; COLLECTIVE like the calls
+        themselves: every rank must switch at the same point).  A pending field is joined first."""
+        if path not in ('auto', 'p2p', 'rccl'):
+            raise ValueError("path must be 'auto', 'p2p' or 'rccl'")
+        pf = self.__dict__.get('_pending_field')
+        if pf is not None and pf.pending:
+            pf.wait()
+        self._shard.gather = path
+        self.__dict__.pop('_gather_sel', None)
+
+    def _reconstruct_p2p(self, Ur_d, A_d, lay, to_host, wait):
+        """reconstruct() over the p2p exchange: the kernel writes this rank's block straight into its persistent copy of
+        the (n_p, n) field, the SDMA engines push the block into every peer's copy (any block sizes, no padding, no pass
+        over the field afterwards).  The tensor returned is a view of that copy: valid until the next sharded
+        reconstruct() of this object."""
+        eng = self._engine()
+        px = self._p2p
+        n_loc, n_p = Ur_d.shape[0], A_d.shape[0]
+        first, total = int(lay[0, 0]), int(lay[:, 1].sum())
+        px.ensure(n_p, total)                                 # a larger field than before: new buffers (collective)
+        out = px.begin()
+        off = self._row0 - first
+        eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'], self._d['scale'], A_d,
+                        out=out[:, off:off + n_loc])
+        close = self._comm_bracket('gather')                  # issue -> join, when the join happens inside this call
+        import time
+        self.last_comm_ = ('field exchange (p2p)', (n_p, total), time.time())
+        k = px.push(off, n_loc)
+        if not to_host and not wait:
+            pf = PendingField(out, join=lambda: px.join(k), needs_cus=False,
+                              on_wait=lambda: self._comm_bracket('gather_exposed'))
+            self._pending_field = pf
+            return pf
+        px.join(k)
+        close()
+        return out if not to_host else eng.to_host(out).T
+
+    def _gather_unequal(self, Ur_d, A_d, lay, to_host, wait):
+        """RCCL field all-gather for row blocks of different sizes: every rank contributes its (n_p, n_loc) block padded to
+        the largest block (the all-gather wants equal counts; the reconstruct kernel writes into the padded block directly),
+        and spr_field_unstage_blocks_f64 packs the blocks side by side afterwards -- one pass over the field, which the
+        equal-shard path and the p2p exchange do not need."""
         import torch.distributed as dist
         eng = self._engine()
-        n_p, n_loc = loc.shape
+        n_p, n_loc = A_d.shape[0], Ur_d.shape[0]
         world, n_max = lay.shape[0], int(lay[:, 1].max())
         mine = eng.zeros((n_p, n_max))
-        mine[:, :n_loc].copy_(loc)
+        eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'], self._d['scale'], A_d,
+                        out=mine[:, :n_loc])
         stage = eng.empty((world, n_p, n_max))
         close = self._comm_bracket('gather')
         dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self._shard.group)
         close()
         first = int(lay[0, 0])                                # 0 unless the group holds a slice of a larger job (partial)
         total = int(lay[:, 1].sum())
-        if to_host:
-            host = np.empty((n_p, total))
+        table = np.stack([lay[:, 0] - first, lay[:, 1]], axis=1).astype(np.int64)
+        if hasattr(eng, 'field_unstage_blocks'):
+            out = eng.field_unstage_blocks(stage, table, total)
+        else:                                                 # the NumPy test double
+            out = eng.empty((n_p, total))
             for q in range(world):
-                o, k = int(lay[q, 0]) - first, int(lay[q, 1])
-                host[:, o:o + k] = eng.to_host(stage[q, :, :k])
-            return host.T
-        out = eng.empty((n_p, total))
-        for q in range(world):
-            o, k = int(lay[q, 0]) - first, int(lay[q, 1])
-            out[:, o:o + k].copy_(stage[q, :, :k])
+                o, k = int(table[q, 0]), int(table[q, 1])
+                out[:, o:o + k] = stage[q, :, :k]
+        if to_host:
+            return eng.to_host(out).T
         return out if wait else PendingField(out)
 
 

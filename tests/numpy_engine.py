@@ -142,7 +142,11 @@ class NumpyEngine:
         feat = self._feat(Ur.shape[0], row0, n_points, n_features)
         sc = scale.numpy()[feat] if rowscale is None else rowscale.numpy()
         x = (self._w(Ur) @ A.numpy().T) * sc[:, None] + rowmean.numpy()[:, None]
-        return torch.from_numpy(np.ascontiguousarray(x.T))
+        res = torch.from_numpy(np.ascontiguousarray(x.T))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     # K6
     def field_unstage(self, stage, out=None):

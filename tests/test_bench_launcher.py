@@ -116,3 +116,23 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--no-cpu'], env=env,
                        capture_output=True, text=True, timeout=240)
     assert p.returncode != 0 and 'WORLD_SIZE=2' in p.stderr
+
+
+def test_watchdog_ends_a_rank_that_makes_no_progress():
+    """bench.Watchdog (round 5): a rank stuck in a collective says where it stands -- phase label, the collective brackets
+    recorded so far, every thread's stack -- and ends its process with a non-zero code; a rank that keeps beating is left
+    alone."""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "wd = bench.Watchdog(0.6, rank=5, describe=lambda: dict(collective_brackets={'allreduce': 7}))\n"
+            "for _ in range(8):\n    time.sleep(0.2); wd.beat('warm-up')\n"
+            "wd.beat('join of the previous field')\ntime.sleep(30)\n" % ROOT)
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3, (p.returncode, p.stderr[-400:])
+    assert "WATCHDOG: no progress" in p.stderr and "'join of the previous field'" in p.stderr
+    assert "'allreduce': 7" in p.stderr and 'time.sleep(30)' not in p.stdout and 'File "<string>"' in p.stderr
+    # stop(): the host-only legs of the run (CPU oracle) are not watched
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "wd = bench.Watchdog(0.3); wd.stop(); time.sleep(1.2); print('alive')\n" % ROOT)
+    p2 = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=60)
+    assert p2.returncode == 0 and 'alive' in p2.stdout

@@ -365,6 +365,9 @@ def _count_worker(rank, world, port, fixture, out_dir):
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
                   engine=NumpyEngine())
         spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        fit0_calls = list(calls)
+        del calls[:]
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
         fit_calls = list(calls)
         del calls[:]
         X3 = spr.reconstruct(spr.Ar[:3])
@@ -374,7 +377,7 @@ def _count_worker(rank, world, port, fixture, out_dir):
         rec1_calls = list(calls)
         for k, fn in real.items():
             setattr(dist, k, fn)
-        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), fit=np.array(fit_calls), rec=np.array(rec_calls),
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), fit=np.array(fit_calls), fit0=np.array(fit0_calls), rec=np.array(rec_calls),
                  rec1=np.array(rec1_calls), X3=X3, x1=x1.numpy())
     finally:
         dist.destroy_process_group()
@@ -384,7 +387,8 @@ def _count_worker(rank, world, port, fixture, out_dir):
 def test_one_collective_per_fit_and_per_reconstruct(tmp_path, world):
     """north_star: 'a single RCCL all-reduce over xGMI for the Gram matrix and a final all-gather for the reconstructed
     field' -- fit() issues exactly ONE collective (the per-rank statistics ride in rank-indexed slots of the Gram
-    buffer), reconstruct() exactly ONE all-gather whatever the number of coefficient vectors."""
+    buffer), reconstruct() exactly ONE all-gather whatever the number of coefficient vectors (the NumPy engine double has
+    no p2p exchange: RowShard(gather='auto') resolves to the collective)."""
     from tests.conftest import load_golden
     fixture = 'g3_num8'
     g = load_golden(fixture)
@@ -393,9 +397,77 @@ def test_one_collective_per_fit_and_per_reconstruct(tmp_path, world):
     for r in range(world):
         o = np.load(tmp_path / f'rank{r}.npz')
         assert o['fit'].tolist() == ['all_reduce'], o['fit']
+        # the object's FIRST fit also all-gathers a 24-byte digest of every rank's host factors (do the ranks' eigen-solves
+        # agree? -- ROM._factors_agree), once
+        assert o['fit0'].tolist() == ['all_reduce', 'all_gather_into_tensor'], o['fit0']
         assert o['rec'].tolist() == ['all_gather_into_tensor'] and o['rec1'].tolist() == ['all_gather_into_tensor']
         assert np.linalg.norm(o['X3'] - ref) <= 1e-6 * np.linalg.norm(ref)
         np.testing.assert_allclose(o['x1'][0], o['X3'][:, 0], rtol=1e-12, atol=1e-12)
+
+
+def _wide_worker(rank, world, port, out_dir, bcast, perturb):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import openmeasure_amd.sparse_sensing as ss
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.numpy_engine import NumpyEngine
+        rng = np.random.default_rng(5)
+        n_points, F, m, r = 300, 3, 128, 16                     # m >= 96: the top-r eigen route (dsytrd + dsterf + r vectors)
+        n = n_points * F
+        X = rng.standard_normal((n, 40)) @ ((0.8 ** np.arange(40))[:, None] * rng.standard_normal((40, m)))
+        X += 1e-3 * rng.standard_normal((n, m))
+        n_loc = n // world
+        row0 = rank * n_loc
+        if perturb and rank == world - 1:
+            real = ss._eigvecs_top
+            if perturb == 'ulp':                                # another LAPACK: the same vectors up to the last bit
+                def other(fac, lam, r_):
+                    V = real(fac, lam, r_)
+                    V[0, 0] = np.nextafter(V[0, 0], np.inf)
+                    return V
+            else:                                               # 'route': this host's inverse iterations "fail" -> dsyevd, m columns
+                def other(fac, lam, r_):
+                    return None
+            ss._eigvecs_top = other
+        spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), F, None, shard=RowShard(row0, n, broadcast_basis=bcast),
+                  engine=NumpyEngine())
+        fields = []
+        for _ in range(2):                                      # the verdict of the first fit holds for the second
+            spr.fit(select_modes='number', n_modes=r)
+            spr.optimal_placement()
+            fields.append(spr.reconstruct(spr.Ar[:2]))
+        np.savez(os.path.join(out_dir, f'wide{rank}.npz'), X=X, piv=spr.sensors_, Vr=spr.Vr, S=spr.Sigma_r, f0=fields[0],
+                 f1=fields[1], bc=bool(spr.basis_broadcast_), Ar=spr.Ar)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,bcast,perturb', [(2, True, None), (3, True, 'route'), (2, False, None), (2, False, 'ulp'),
+                                                 (3, False, 'route')])
+def test_host_factors_agree_or_rank0_wins(tmp_path, world, bcast, perturb):
+    """Every rank eigen-solves the all-reduced Gram matrix on its own host.  (i) RowShard(broadcast_basis=True) at m >= 96
+    (ADVICE r04): rank 0 alone decides the route and r, one fixed-size broadcast -- also when another rank's route would
+    have differed; (ii) without the option, the first fit() all-gathers a digest of the factors and switches to rank 0's
+    when a rank differs by one ulp or by its route (round 5) -- silently diverging bases are not possible."""
+    from oracle import spr_oracle as orc
+    mp.spawn(_wide_worker, args=(world, _free_port(), str(tmp_path), bcast, perturb), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f'wide{r}.npz') for r in range(world)]
+    X = outs[0]['X']
+    st = orc.fit(X, 3, select_modes='number', n_modes=16)
+    piv, _ = orc.qr_pivots(st['Ur'])
+    for o in outs:
+        assert bool(o['bc']) == (bcast or perturb is not None)
+        np.testing.assert_array_equal(o['piv'], piv)
+        np.testing.assert_array_equal(o['Vr'], outs[0]['Vr'])           # the SAME bits on every rank
+        np.testing.assert_array_equal(o['f0'], outs[0]['f0'])
+        np.testing.assert_array_equal(o['f1'], o['f0'])
+        np.testing.assert_allclose(o['S'], st['Sigma_r'], rtol=1e-8)
+    sg = np.sign(np.sum(outs[0]['Ar'] * st['Ar'], axis=0))
+    ref = (st['Ur'] @ (outs[0]['Ar'][:2] * sg).T) * st['X_scl'] + st['X_cnt']
+    assert np.linalg.norm(outs[0]['f0'] - ref) <= 1e-6 * np.linalg.norm(ref)
 
 
 def _pool_worker(rank, world, port, out_dir, heavy):

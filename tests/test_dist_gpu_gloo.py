@@ -48,6 +48,27 @@ def _worker(rank, world, port, fixture, out_dir, uneven=False):
         X3 = spr.reconstruct(A3)
         x1 = spr.reconstruct(A3[:1], to_host=False, wait=False).wait()        # one vector, field kept in HBM
         np.testing.assert_array_equal(x1.cpu().numpy()[0], X3[:, 0])
+        # round 5: the CU-free exchange (IPC peer-mapped copies of the field, SDMA pushes) against the collective one, bit for bit
+        assert spr.gather_path_.startswith('p2p'), spr.gather_path_            # 'auto' took it: the self-test passed on all ranks
+        spr.use_gather('rccl')
+        X3_c = spr.reconstruct(A3)
+        assert spr.gather_path_.startswith('rccl')
+        np.testing.assert_array_equal(X3_c, X3)
+        # six gathers, each left in flight and joined the way bench.py's step loop does it -- behind the next fit(), in front of
+        # the next reconstruct() --, one and three vectors alternating (the three-vector field re-uses the buffers)
+        As = [(A3 * (1.0 + 0.25 * it))[: (1 if it % 2 else 3)] for it in range(6)]
+        wants = [spr.reconstruct(A).T.copy() for A in As]                   # collective path
+        spr.use_gather('p2p')
+        prev = None
+        for it, A in enumerate(As):
+            if it < 3:
+                spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'], n_modes=g['n_modes'])
+            if prev is not None:
+                np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[it - 1])
+            prev = spr.reconstruct(A, to_host=False, wait=False)
+            assert prev.pending and not prev.needs_cus
+        np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[-1])
+        np.testing.assert_array_equal(spr.reconstruct(A3), X3)             # ... and with the host contract
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, Sigma=spr.Sigma_r, X3=X3, A3=A3, Ar=spr.Ar,
                  passes=spr.gram_refine_passes_)
     finally:
@@ -102,10 +123,12 @@ def _synth_worker(rank, world, port, cells, F, m, s_, out_dir):
         # round 4: the step loop of bench.py in both forms, with the collective brackets on -- gather left in flight (the gap
         # filler of fit() must stay out of the gap the gather needs) and joined inside the step (the filler runs)
         spr.comm_timing = {}
+        spr.gap_filler = True                                 # opt-in since round 5
         spr._GAP_FILL_MIN_MS = 0.0                            # fill whatever gap this host leaves
         a_d = eng.to_device(spr.Ar[:1].copy())
         fills = {}
-        for sync in (False, True):
+        for path, sync in (('rccl', False), ('rccl', True), ('p2p', False)):
+            spr.use_gather(path)
             prev, rows = None, []
             for _ in range(4):
                 spr.fit(select_modes='number', n_modes=s_)
@@ -114,13 +137,14 @@ def _synth_worker(rank, world, port, cells, F, m, s_, out_dir):
                     prev.wait()
                 prev = spr.reconstruct(a_d, to_host=False, wait=sync)
             last = prev.wait() if hasattr(prev, 'wait') else prev
-            fills['sync' if sync else 'pipelined'] = rows
+            fills[path + ('_sync' if sync else '_pipelined')] = rows
         torch.cuda.synchronize()
         comm = {k: [eng.elapsed_ms(e0, e1) for e0, e1 in v] for k, v in spr.comm_timing.items()}
         if rank == 0:
             np.savez(os.path.join(out_dir, 'dist.npz'), piv=spr.sensors_, S=spr.S_, field=first, a=spr.Ar[0],
                      sign=np.sign(spr.Ar[0]), pool_sweeps=spr.pivot_pool_sweeps_, sweeps=spr.pivot_sweeps_,
-                     fills_pipelined=fills['pipelined'], fills_sync=fills['sync'], field_last=eng.to_host(last)[0],
+                     fills_pipelined=fills['rccl_pipelined'], fills_sync=fills['rccl_sync'], fills_p2p=fills['p2p_pipelined'],
+                     field_last=eng.to_host(last)[0], gather_path=str(spr.gather_path_),
                      n_allreduce=len(comm['allreduce']), n_gather=len(comm.get('gather', [])),
                      n_exposed=len(comm.get('gather_exposed', [])),
                      min_ms=min(min(v) for v in comm.values()))
@@ -160,7 +184,9 @@ def test_config4_shaped_shards_four_ranks_one_gpu(tmp_path):
     # had a PendingField behind it) and fills it in the sync loop once there is a gap history
     assert list(d['fills_pipelined'][1:]) == [0, 0, 0], d['fills_pipelined']
     assert d['fills_sync'][-1] >= 65536, d['fills_sync']
+    # ... while the p2p exchange needs no compute unit, so the filler runs under it (round 5)
+    assert str(d['gather_path']).startswith('p2p') and d['fills_p2p'][-1] >= 65536, (d['gather_path'], d['fills_p2p'])
     # ... and every collective was bracketed: one all-reduce per fit, the gather where it was joined
-    assert int(d['n_allreduce']) == 8 and int(d['n_gather']) == 4 and int(d['n_exposed']) == 4 and float(d['min_ms']) >= 0.0
+    assert int(d['n_allreduce']) == 12 and int(d['n_gather']) == 4 and int(d['n_exposed']) == 8 and float(d['min_ms']) >= 0.0
     del Xd, one
     torch.cuda.empty_cache()

@@ -36,7 +36,7 @@ def test_native_library_is_loaded(eng):
     maps = open(f'/proc/{os.getpid()}/maps').read()
     assert 'libspr_hip.so' in maps
     from openmeasure_amd import _lib
-    assert eng.lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 2
+    assert eng.lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 3
 
 
 def test_golden_fixture(golden, eng):
@@ -1534,16 +1534,21 @@ def test_gap_filler_changes_nothing_but_the_clock(eng, monkeypatch, m, r):
     n_points, F = (30_000 if m == 256 else 24_000), 3          # (a wide X is filled with the 256-column kernel on its first slice)
     X = synth_host(n_points, F, m, 100, 0.93, 1e-3, 11)
     monkeypatch.setattr(SPR, '_GAP_FILL_MIN_MS', 0.0)          # whatever this host's eigen-solve takes, fill its gap
+    assert SPR.gap_filler is False                             # opt-in (round 5): a plain fit() queues no discarded work
     a = SPR(X, F, None, engine=eng)
+    a.gap_filler = True
     fills = []
     for _ in range(4):
         a.fit(select_modes='number', n_modes=r)
         fills.append(a._gap_fill_rows)
     assert fills[0] == 0 and fills[-1] >= 65536, fills      # no history in the first call; later ones fill the gap
-    monkeypatch.setenv('SPR_GAP_FILLER', '0')
     b = SPR(X, F, None, engine=eng)
-    b.fit(select_modes='number', n_modes=r)
+    for _ in range(2):
+        b.fit(select_modes='number', n_modes=r)
     assert not hasattr(b, '_gap_fill_rows')
+    monkeypatch.setenv('SPR_GAP_FILLER', '0')                  # the environment switch overrides the attribute
+    a.fit(select_modes='number', n_modes=r)
+    monkeypatch.delenv('SPR_GAP_FILLER')
     for name in ('Ur', 'X_cnt', 'Sigma_r', 'Ar'):
         np.testing.assert_array_equal(getattr(a, name), getattr(b, name))
     a.optimal_placement(); b.optimal_placement()

@@ -21,6 +21,7 @@ for name, cells in shapes:
     F, m, s = wl['features'], wl['m'], wl['s']
     Xd = eng.synth(cells * F, m, 0, cells, eng.to_device(make_R(m, s, seed=1234)), 1e-3, 1234)
     spr = SPR(DeviceMatrix(Xd), F, None, engine=eng)
+    spr.gap_filler = True
     spr._GAP_FILL_MIN_MS = 0.0                      # fill whatever gap this host leaves
     ref, bad, fills = None, 0, 0
     reps = rounds if (cells < 1_000_000 or len(sys.argv) > 2) else max(rounds // 4, 10)

@@ -298,6 +298,10 @@ def parse_args(argv=None):
     ap.add_argument('--share-rank', type=int, default=0, help='which rank of --share-of')
     ap.add_argument('--gather', default=os.environ.get('SPR_BENCH_GATHER', 'auto'), choices=('auto', 'p2p', 'rccl'),
                     help="field exchange of the headline loop (RowShard.gather); with 'auto' the other path is timed as well")
+    ap.add_argument('--p2p-loopback', type=int, default=0, metavar='L',
+                    help='developer aid, with --share-of: the p2p field exchange with L imaginary peers inside this GPU (the '
+                         "rank issues the L pushes of its block an (L+1)-rank exchange would, both ends in its own HBM); the "
+                         'line says so')
     ap.add_argument('--gap-filler', action='store_true',
                     help='switch ROM.gap_filler on (opt-in: fit() re-queues its Gram kernel on part of X into the host gap to '
                          'hold the clock; the line then says so and counts the rows)')
@@ -329,6 +333,12 @@ def run_rank(args):
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.gpus > 1 or args.share_of > 1:
+        # Sharded runs use a compute stream, three copy streams (p2p field exchange), RCCL's own stream and a host-transfer
+        # stream; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one are
+        # served in submission order -- a copy stream's wait for its SDMA engine then sits in front of a kernel of the compute
+        # stream.  Read by the runtime when it initialises, i.e. below (measured: profiles/r05_p2p_gap_experiments.txt).
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     import torch
     import torch.distributed as dist
     from openmeasure_amd.engine import HipEngine
@@ -375,6 +385,11 @@ def run_rank(args):
     n_points, n_glob, n_loc, row0 = plan['n_points'], plan['n_glob'], plan['n_loc'], plan['row0']
     seed, eps = 1234, wl.get('eps', 1e-3)
 
+    if args.p2p_loopback:
+        if not share:
+            raise SystemExit('bench.py: --p2p-loopback is a diagnostic of --share-of runs')
+        os.environ['SPR_P2P_LOOPBACK'] = str(args.p2p_loopback)
+        args.gather = 'p2p'
     eng = HipEngine(f'cuda:{local_rank}')
     R = eng.to_device(make_R(m, s, seed=seed, ratio=wl.get('ratio', 1e3)))
     t0 = time.time()
@@ -405,6 +420,14 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     dist_on = world > 1 or force_dist
+    own_stream = dist_on and os.environ.get('SPR_BENCH_STREAM', '1') != '0'
+    if own_stream:
+        # Sharded runs put the whole step on a stream of their own: on the DEFAULT (null) stream a kernel launched while SDMA
+        # pushes of the p2p field exchange are in flight on other streams only starts when they end -- 0.9 ms per step on one
+        # rank's block of config 4 (profiles/r05_p2p_gap_experiments.txt: reconstruct -> next Gram pass 0.92 ms on the null
+        # stream, 0.05 ms on any other).  SPR_BENCH_STREAM=0 keeps the default stream (A/B).
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(eng.device))
     wd.beat('first fit')
     spr.fit(select_modes='number', n_modes=s)     # first call: allocations, RCCL warm-up
     a_d = eng.to_device(spr.Ar[:1].copy())        # (1, r) coefficient vector, resident
@@ -513,6 +536,10 @@ def run_rank(args):
     # left in flight under the next Gram pass (the wait of the join).  None = no such collective ran (N = 1).
     comm = comm_summary(comm_main, comm_sync, dist_on, args.sync_gather, F, m, world, n_loc, gather_path=head_why,
                         paths=path_results or None)
+    px = spr.__dict__.get('_p2p')
+    if dist_on and px is not None and px.host_ms['calls']:
+        comm['p2p_host_ms_per_gather'] = {k_: round(v / px.host_ms['calls'], 4) for k_, v in px.host_ms.items() if k_ != 'calls'}
+        comm['p2p_copy_streams'] = len(px._pool)
     # never print a number for a run that computed garbage: spectrum, basis sample and field must be finite
     fld = field if torch.is_tensor(field) else None
     if not (np.all(np.isfinite(spr.S_[:s])) and bool(torch.isfinite(spr._d['Ur'][:4096].double()).all())
@@ -524,6 +551,12 @@ def run_rank(args):
 
     k_ms = {k: float(np.mean([tm[i][0].elapsed_time(tm[i][1]) for tm in timers]))
             for i, k in enumerate(('stats_gram', 'project', 'reconstruct'))}
+    # what lies BETWEEN the three kernels on the compute stream (same events): the host gap of fit() (download, eigen-solve,
+    # upload), the join / release of the field exchange in front of reconstruct, and reconstruct -> the next step's Gram pass
+    gaps_ms = dict(gram_to_project=float(np.mean([tm[0][1].elapsed_time(tm[1][0]) for tm in timers])),
+                   project_to_reconstruct=float(np.mean([tm[1][1].elapsed_time(tm[2][0]) for tm in timers])),
+                   reconstruct_to_next_gram=(float(np.mean([a[2][1].elapsed_time(b[0][0]) for a, b in zip(timers, timers[1:])]))
+                                             if len(timers) > 1 else None))
     r = spr.r
     # per-launch algorithmic work of each kernel on THIS rank's shard
     alg = {
@@ -786,11 +819,17 @@ def run_rank(args):
                if getattr(spr, 'gram_refine_passes_', 0) else {}),
             'placement_ms': path['optimal_placement_ms'], 'train_ms': path['train_ms'], 'predict_ms': path['predict_ms'],
             'pivot_sweeps': path['pivot_sweeps'], 'min_pivot_gap': path['min_pivot_gap'], 'path': path,
+            **({'p2p_loopback': f'{args.p2p_loopback} imaginary peers inside this GPU: the pushes, counters and waits of a '
+                                f'{args.p2p_loopback + 1}-rank p2p field exchange with both ends in this HBM -- NOT an N-GPU number'}
+               if args.p2p_loopback else {}),
             **({'rehearsal': f'{backend} backend, all ranks on one GPU: exercises the code path, measures nothing'}
                if (backend != 'nccl' or os.environ.get('SPR_BENCH_ONE_GPU') == '1') else {}),
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
         }
         out['rank_timeline_ms'] = {k_: (None if v != v else round(v, 4)) for k_, v in mine.items()}
+        out['gaps_ms'] = {k_: (None if v is None else round(v, 4)) for k_, v in gaps_ms.items()}
+        out['compute_stream'] = 'own (non-default) stream' if own_stream else 'default stream'
+        out['hw_queues'] = os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)')
         out['gap_filler'] = dict(on=bool(spr.gap_filler), rows_per_fit=(int(np.mean(fill_rows)) if fill_rows else 0),
                                  note='opt-in (--gap-filler): fit() re-queues its Gram kernel over this many rows of X into the '
                                       'host gap and discards the result -- work inside the timed step that the GB/s model does '

@@ -307,39 +307,50 @@ int spr_field_unstage_blocks_f64(const double *d_stage, int32_t world, int32_t n
  * RCCL's all-gather runs a device kernel that cannot share a compute unit with the Gram / projection workgroups, so a field
  * gather left in flight under the next fit() only progresses where a CU is free.  On one node the ranks can instead map each
  * other's copy of the field (interprocess handles) and WRITE their block into it with the SDMA engines.
- *   spr_p2p_alloc / spr_p2p_free   a device buffer of n_bytes (multiple of 4096) from hipMalloc and its interprocess handle
- *                                  (spr_p2p_handle_bytes() bytes at h_handle).  The ONE allocation this library makes: a
+ *   spr_p2p_alloc / spr_p2p_free   a device buffer of n_bytes (multiple of 4096) and its interprocess handle
+ *                                  (spr_p2p_handle_bytes() bytes at h_handle).  kind 0: hipMalloc (coarse-grained: coherent
+ *                                  between GPUs at kernel boundaries); 1: fine-grained (coherent at system scope while
+ *                                  kernels run: the counters); 2: uncached.  The ONE allocation this library makes: a
  *                                  handle can only be taken of the base pointer of an allocation.
  *   spr_p2p_open / spr_p2p_close   map / unmap a buffer exported by ANOTHER process of this node (peer access is enabled
  *                                  lazily); the handle bytes travel through any channel the caller has (torch.distributed).
  *   spr_p2p_signal / spr_p2p_wait  hipStreamWriteValue64 / hipStreamWaitValue64(>=) on a 64-bit counter inside such a
- *                                  buffer (own or mapped): command-processor packets, no kernel.
+ *                                  buffer (own or mapped); used on the copy streams.
+ *   spr_p2p_flags_set / _wait      ONE single-wave kernel that raises / awaits n <= 128 counters (host table of device
+ *                                  pointers, passed to the kernel by value): what the compute stream uses.  The wait gives
+ *                                  up after timeout_s seconds of the device's wall clock and leaves (index + 1, value seen)
+ *                                  in the two words at d_status (NULL: nowhere) -- every wave reaches its exit.
  *   spr_p2p_copy                   one device-to-device copy through the SDMA engines (hipMemcpyDeviceToDeviceNoCU).
  *   spr_field_gather_p2p           this rank's block of the field -- columns [first, first + n_loc) of the n_p rows of its
  *                                  own (n_p, ldo) copy d_field -- into the same place of every peer's copy: per peer p, on
- *                                  streams[p]: wait until *d_release_flag[p] >= release_value (a counter in THIS rank's
- *                                  buffer that peer p raises when it no longer reads what its copy held; 0 = no wait),
- *                                  n_p copies of n_loc doubles, then *d_peer_arrive_flag[p] = arrive_value (a counter in
- *                                  peer p's buffer).  The caller orders streams[p] behind the kernel that wrote the block.
- *   spr_field_gather_p2p_join      `stream` waits until every *d_arrive_flag[p] >= arrive_value (counters in this rank's
- *                                  own buffer, one per peer): the field is complete for whatever is enqueued next.
- *   spr_field_gather_p2p_release   *d_peer_release_flag[p] = value for every peer, behind everything enqueued on `stream`
- *                                  so far (the consumers of the previous field).
+ *                                  streams[p] (streams may repeat): wait until *d_release_flag[p] >= release_value (a counter
+ *                                  in THIS rank's memory that peer p raises when it no longer reads what its copy held; 0 =
+ *                                  no wait), n_p copies of n_loc doubles, *d_peer_arrive_flag[p] = arrive_value (a counter in
+ *                                  peer p's memory), and, if given, *d_pushed_flag[p] = arrive_value (this rank's own: "the
+ *                                  push to p has left").  The caller orders streams[p] behind the kernel that wrote the block.
+ *   spr_field_gather_p2p_join      `stream` waits (one kernel) until every one of the n counters -- the peers' arrivals and
+ *                                  this rank's own pushed counters -- has reached arrive_value.
+ *   spr_field_gather_p2p_release   *d_peer_release_flag[p] = value for every peer (one kernel), behind everything enqueued
+ *                                  on `stream` so far (the consumers of the previous field).
  * All pointer tables are HOST arrays of device pointers.  Replaces the remote half of Ur @ Ar.T being whole on every caller
  * (sparse_sensing.py:371-375) next to torch.distributed's all_gather; SPR_P2P_BLIT=1 swaps the SDMA copies for blit kernels
  * (A/B only). */
 size_t spr_p2p_handle_bytes(void);
-int spr_p2p_alloc(size_t n_bytes, void **d_ptr, void *h_handle);
+int spr_p2p_alloc(size_t n_bytes, int32_t kind, void **d_ptr, void *h_handle);
 int spr_p2p_free(void *d_ptr);
 int spr_p2p_open(const void *h_handle, void **d_mapped);
 int spr_p2p_close(void *d_mapped);
 int spr_p2p_signal(void *d_flag, uint64_t value, void *stream);
 int spr_p2p_wait(void *d_flag, uint64_t value, void *stream);
+int spr_p2p_flags_set(void *const *d_flags, int32_t n, uint64_t value, void *stream);
+int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t value, double timeout_s, void *d_status, void *stream);
 int spr_p2p_copy(void *d_dst, const void *d_src, int64_t n_bytes, void *stream);
 int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc, int32_t n_peers,
                          void *const *d_peer_field, void *const *d_release_flag, uint64_t release_value,
-                         void *const *d_peer_arrive_flag, uint64_t arrive_value, void *const *streams);
-int spr_field_gather_p2p_join(void *const *d_arrive_flag, int32_t n_peers, uint64_t arrive_value, void *stream);
+                         void *const *d_peer_arrive_flag, uint64_t arrive_value, void *const *d_pushed_flag,
+                         void *const *streams);
+int spr_field_gather_p2p_join(void *const *d_flags, int32_t n_flags, uint64_t arrive_value, double timeout_s, void *d_status,
+                              void *stream);
 int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream);
 
 /* ---- K6 : QR column pivoting of Ur^T (sensor selection) -----------------------------

@@ -69,15 +69,17 @@ PROTOTYPES = {
     'spr_field_unstage_f64': (C.c_int, [_p, _i32, _i32, _i64, _p, _i64, _p]),
     'spr_field_unstage_blocks_f64': (C.c_int, [_p, _i32, _i32, _i64, _p, _p, _i64, _p]),
     'spr_p2p_handle_bytes': (_sz, []),
-    'spr_p2p_alloc': (C.c_int, [_sz, _p, _p]),
+    'spr_p2p_alloc': (C.c_int, [_sz, _i32, _p, _p]),
     'spr_p2p_free': (C.c_int, [_p]),
     'spr_p2p_open': (C.c_int, [_p, _p]),
     'spr_p2p_close': (C.c_int, [_p]),
     'spr_p2p_signal': (C.c_int, [_p, _u64, _p]),
     'spr_p2p_wait': (C.c_int, [_p, _u64, _p]),
+    'spr_p2p_flags_set': (C.c_int, [_p, _i32, _u64, _p]),
+    'spr_p2p_flags_wait': (C.c_int, [_p, _i32, _u64, _dbl, _p, _p]),
     'spr_p2p_copy': (C.c_int, [_p, _p, _i64, _p]),
-    'spr_field_gather_p2p': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p, _u64, _p, _u64, _p]),
-    'spr_field_gather_p2p_join': (C.c_int, [_p, _i32, _u64, _p]),
+    'spr_field_gather_p2p': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p, _u64, _p, _u64, _p, _p]),
+    'spr_field_gather_p2p_join': (C.c_int, [_p, _i32, _u64, _dbl, _p, _p]),
     'spr_field_gather_p2p_release': (C.c_int, [_p, _i32, _u64, _p]),
     'spr_qr_workspace': (_sz, [_i64]),
     'spr_qr_workspace_r': (_sz, [_i64, _i32]),

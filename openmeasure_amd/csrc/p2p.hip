@@ -13,8 +13,9 @@
 //   * a rank's block goes straight from its own copy of the field into the same place of every peer's copy with
 //     hipMemcpyAsync(..., hipMemcpyDeviceToDeviceNoCU): the SDMA engines, one stream per peer so the copies to different
 //     peers use different engines / xGMI links;
-//   * arrival and buffer release are 64-bit counters in the exported buffers, written with hipStreamWriteValue64 behind the
-//     copies and awaited with hipStreamWaitValue64 in front of the consumer -- command-processor packets, no kernel.
+//   * arrival and buffer release are 64-bit counters in exported fine-grained memory: raised with hipStreamWriteValue64 behind
+//     the copies (copy streams), set / awaited on the compute stream by ONE single-wave kernel each -- microseconds of one
+//     wave, nothing that occupies a compute unit while the bytes move.
 //
 // Measured on one MI355X, two processes (tools/lab/p2p_probe.hip, profiles/r05_p2p_probe.txt): a NoCU copy into the other
 // process's buffer runs at 61 GB/s and leaves a CU-filling kernel's time unchanged (24.87 ms with and without), the same
@@ -38,12 +39,16 @@ hipMemcpyKind p2p_kind() {
 
 extern "C" size_t spr_p2p_handle_bytes(void) { return sizeof(hipIpcMemHandle_t); }
 
-extern "C" int spr_p2p_alloc(size_t n_bytes, void **d_ptr, void *h_handle) {
+extern "C" int spr_p2p_alloc(size_t n_bytes, int32_t kind, void **d_ptr, void *h_handle) {
   SPR_REQUIRE(d_ptr && h_handle, SPR_E_INVALID, "spr_p2p_alloc: NULL output");
   SPR_REQUIRE(n_bytes > 0 && n_bytes % 4096 == 0, SPR_E_INVALID, "spr_p2p_alloc: n_bytes=%zu must be a positive multiple of 4096",
               n_bytes);
+  SPR_REQUIRE(kind >= 0 && kind <= 2, SPR_E_INVALID, "spr_p2p_alloc: kind=%d (0 coarse-grained, 1 fine-grained, 2 uncached)", kind);
   void *p = nullptr;
-  SPR_HIP_TRY(hipMalloc(&p, n_bytes));
+  if (kind == 0)
+    SPR_HIP_TRY(hipMalloc(&p, n_bytes));
+  else
+    SPR_HIP_TRY(hipExtMallocWithFlags(&p, n_bytes, kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
   hipIpcMemHandle_t h;
   hipError_t e = hipIpcGetMemHandle(&h, p);
   if (e != hipSuccess) {
@@ -95,10 +100,83 @@ extern "C" int spr_p2p_copy(void *d_dst, const void *d_src, int64_t n_bytes, voi
   return SPR_OK;
 }
 
+// ---- counters set and awaited by single-wave kernels ------------------------------------------------------------------
+// hipStreamWriteValue64 / hipStreamWaitValue64 are themselves one tiny kernel each on this runtime (__amd_rocclr_streamOpsWrite /
+// streamOpsWait in a rocprofv3 trace, 4-8 us plus 10-15 us of dispatch gap): seven of each in front of every reconstruct
+// kernel cost 0.15 ms -- and 0.9 ms when the stream also had to wait for events behind SDMA copies of another hardware queue
+// (profiles/r05_p2p_gap_experiments.txt).  On the COMPUTE stream the exchange therefore uses ONE kernel per release and ONE per
+// join, over a table of counters passed by value; completion of this rank's own pushes is a counter as well (written on the
+// copy stream behind the copies), so the compute stream never waits for an event of another queue.
+namespace {
+constexpr int kMaxFlags = 128;
+struct FlagTable {
+  unsigned long long *p[kMaxFlags];
+};
+
+__global__ __launch_bounds__(128) void p2p_flags_set_kernel(FlagTable t, int n, unsigned long long value) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    __hip_atomic_store(t.p[i], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Every lane polls one counter until it has reached `value`.  Exit condition every wave reaches: `timeout_ticks` of the
+// 100 MHz wall clock; a lane that gives up leaves (its index + 1) in status[0] and the value it saw in status[1] -- the
+// host reads the two words where it synchronises anyway and raises.
+__global__ __launch_bounds__(128) void p2p_flags_wait_kernel(FlagTable t, int n, unsigned long long value,
+                                                             unsigned long long timeout_ticks,
+                                                             unsigned long long *__restrict__ status) {
+  const unsigned long long t0 = wall_clock64();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    unsigned long long seen;
+    while ((seen = __hip_atomic_load(t.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < value) {
+      if (wall_clock64() - t0 > timeout_ticks) {
+        if (status) {
+          __hip_atomic_store(status + 1, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(status, (unsigned long long)(i + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: what the counters announce is visible to what runs next
+}
+
+int fill_table(FlagTable &t, void *const *ptrs, int n, const char *who) {
+  SPR_REQUIRE(n >= 1 && n <= kMaxFlags && ptrs, SPR_E_INVALID, "%s: n=%d counters (1..%d) / NULL table", who, n, kMaxFlags);
+  for (int i = 0; i < n; ++i) {
+    SPR_REQUIRE(ptrs[i] && (uintptr_t)ptrs[i] % 8 == 0, SPR_E_INVALID, "%s: counter %d is NULL or unaligned", who, i);
+    t.p[i] = static_cast<unsigned long long *>(ptrs[i]);
+  }
+  return SPR_OK;
+}
+}  // namespace
+
+extern "C" int spr_p2p_flags_set(void *const *d_flags, int32_t n, uint64_t value, void *stream) {
+  FlagTable t;
+  if (int rc = fill_table(t, d_flags, n, "spr_p2p_flags_set")) return rc;
+  hipLaunchKernelGGL(p2p_flags_set_kernel, dim3(1), dim3(n > 64 ? 128 : 64), 0, static_cast<hipStream_t>(stream), t, (int)n,
+                     (unsigned long long)value);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+extern "C" int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t value, double timeout_s, void *d_status,
+                                  void *stream) {
+  FlagTable t;
+  if (int rc = fill_table(t, d_flags, n, "spr_p2p_flags_wait")) return rc;
+  SPR_REQUIRE(timeout_s > 0.0 && timeout_s <= 3600.0, SPR_E_INVALID, "spr_p2p_flags_wait: timeout_s=%g (0, 3600]", timeout_s);
+  SPR_REQUIRE(d_status == nullptr || (uintptr_t)d_status % 8 == 0, SPR_E_INVALID, "spr_p2p_flags_wait: unaligned status");
+  hipLaunchKernelGGL(p2p_flags_wait_kernel, dim3(1), dim3(n > 64 ? 128 : 64), 0, static_cast<hipStream_t>(stream), t, (int)n,
+                     (unsigned long long)value, (unsigned long long)(timeout_s * 1e8),
+                     static_cast<unsigned long long *>(d_status));
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
 extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc,
                                     int32_t n_peers, void *const *d_peer_field, void *const *d_release_flag,
                                     uint64_t release_value, void *const *d_peer_arrive_flag, uint64_t arrive_value,
-                                    void *const *streams) {
+                                    void *const *d_pushed_flag, void *const *streams) {
   SPR_REQUIRE(d_field && n_p >= 1 && first >= 0 && n_loc >= 0 && ldo >= first + n_loc, SPR_E_INVALID,
               "spr_field_gather_p2p: n_p=%d first=%lld n_loc=%lld ldo=%lld", n_p, (long long)first, (long long)n_loc,
               (long long)ldo);
@@ -109,7 +187,7 @@ extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t 
   for (int p = 0; p < n_peers; ++p) {
     hipStream_t st = static_cast<hipStream_t>(streams[p]);
     SPR_REQUIRE(d_peer_field[p] && d_peer_arrive_flag[p], SPR_E_INVALID, "spr_field_gather_p2p: peer %d has a NULL pointer", p);
-    if (release_value)   // the peer must have let go of what this buffer held (it writes the slot when it enters its own gather)
+    if (release_value)   // the peer must have let go of what this buffer held (it raises the slot when it enters its own gather)
       SPR_HIP_TRY(hipStreamWaitValue64(st, d_release_flag[p], release_value, hipStreamWaitValueGte, ~0ull));
     if (n_loc > 0) {
       double *dst = static_cast<double *>(d_peer_field[p]);
@@ -117,25 +195,17 @@ extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t 
         SPR_HIP_TRY(hipMemcpyAsync(dst + (int64_t)v * ldo + first, d_field + (int64_t)v * ldo + first, (size_t)n_loc * 8, kind, st));
     }
     SPR_HIP_TRY(hipStreamWriteValue64(st, d_peer_arrive_flag[p], arrive_value, 0));
+    if (d_pushed_flag && d_pushed_flag[p])   // "my push to peer p has left": a counter of THIS rank, raised behind the copies
+      SPR_HIP_TRY(hipStreamWriteValue64(st, d_pushed_flag[p], arrive_value, 0));
   }
   return SPR_OK;
 }
 
-extern "C" int spr_field_gather_p2p_join(void *const *d_arrive_flag, int32_t n_peers, uint64_t arrive_value, void *stream) {
-  SPR_REQUIRE(n_peers >= 1 && d_arrive_flag, SPR_E_INVALID, "spr_field_gather_p2p_join: n_peers=%d (>= 1) / NULL flag table", n_peers);
-  for (int p = 0; p < n_peers; ++p) {
-    SPR_REQUIRE(d_arrive_flag[p], SPR_E_INVALID, "spr_field_gather_p2p_join: flag %d is NULL", p);
-    SPR_HIP_TRY(hipStreamWaitValue64(static_cast<hipStream_t>(stream), d_arrive_flag[p], arrive_value, hipStreamWaitValueGte, ~0ull));
-  }
-  return SPR_OK;
+extern "C" int spr_field_gather_p2p_join(void *const *d_flags, int32_t n_flags, uint64_t arrive_value, double timeout_s,
+                                         void *d_status, void *stream) {
+  return spr_p2p_flags_wait(d_flags, n_flags, arrive_value, timeout_s, d_status, stream);
 }
 
 extern "C" int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream) {
-  SPR_REQUIRE(n_peers >= 1 && d_peer_release_flag, SPR_E_INVALID, "spr_field_gather_p2p_release: n_peers=%d (>= 1) / NULL flag table",
-              n_peers);
-  for (int p = 0; p < n_peers; ++p) {
-    SPR_REQUIRE(d_peer_release_flag[p], SPR_E_INVALID, "spr_field_gather_p2p_release: flag %d is NULL", p);
-    SPR_HIP_TRY(hipStreamWriteValue64(static_cast<hipStream_t>(stream), d_peer_release_flag[p], value, 0));
-  }
-  return SPR_OK;
+  return spr_p2p_flags_set(d_peer_release_flag, n_peers, value, stream);
 }

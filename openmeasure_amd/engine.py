@@ -271,7 +271,8 @@ class HipEngine:
         """The CU-free field exchange of a sharded reconstruct() (openmeasure_amd/p2p.py); buffers are made by ensure()."""
         import os
         from .p2p import P2PFieldGather
-        return P2PFieldGather(self, world, rank, all_gather, double_buffer=os.environ.get('SPR_P2P_BUFFERS') == '2')
+        return P2PFieldGather(self, world, rank, all_gather, double_buffer=os.environ.get('SPR_P2P_BUFFERS') == '2',
+                              loopback=int(os.environ.get('SPR_P2P_LOOPBACK', '0') or 0))
 
     def stage_to_host(self, stage):
         """The same re-arrangement on the way to the host: block (q, v) of the staged field is copied straight to its place

@@ -5,26 +5,31 @@ array of sparse_sensing.py:371-375 is whole on every caller).  Over RCCL that is
 share a compute unit with the Gram / projection workgroups; here every rank keeps ONE persistent copy of the field in a
 buffer the other ranks of the node have mapped (interprocess handles, exchanged once through torch.distributed), the
 reconstruct kernel writes the rank's own block straight into it, and the block is pushed into the same place of every peer's
-copy by the SDMA engines -- one stream per peer, a 64-bit arrival counter written behind the copies, awaited by the
-consumer's stream.  No compute unit is used, so the exchange really runs under the next fit()'s MFMA-bound Gram pass.
+copy by the SDMA engines -- a few copy streams, a 64-bit arrival counter raised behind the copies, awaited by ONE single-wave
+kernel on the consumer's stream.  Nothing occupies a compute unit while the bytes move, so the exchange really runs under
+the next fit()'s MFMA-bound Gram pass.
 
-PyTorch is plumbing: streams, the device context, and ``torch.distributed`` as the channel for the 64 handle bytes per
-rank.  Buffers come from the library (an interprocess handle needs the base pointer of an allocation).
+PyTorch is plumbing: streams, the device context, and ``torch.distributed`` as the channel for the handle bytes.  Buffers
+come from the library (an interprocess handle needs the base pointer of an allocation): one for the field copies (+ a
+scratch page the self-test uses), one fine-grained 4 KB page for the counters.
 
 Protocol (counters only ever grow; k = number of gathers issued so far on this object, identical on all ranks because a
 gather is a collective call; b = k % n_buf, n_buf = 1 unless asked otherwise):
-  release   on entering gather k a rank raises release[me] = k in every peer's flag page, on its COMPUTE stream -- behind every
-            kernel that read an earlier field: "the fields I was handed before gather k are dead";
-  push      per peer p, on that peer's copy stream: wait until release[p] >= k - n_buf + 1 (in MY flag page: p no longer reads
-            what its buffer b holds), copy my block into p's buffer b, raise arrive[b][me] = k + 1 in p's flag page;
-  join      the consumer's stream waits until arrive[b][p] >= k + 1 for every peer p (MY flag page) and for my own pushes to
-            have left (their source is my buffer b).
+  release   on entering gather k a rank raises release[me] = k in every peer's counter page (one kernel on its COMPUTE stream --
+            behind every kernel that read an earlier field): "the fields I was handed before gather k are dead";
+  push      per peer p, on one of the copy streams: wait until release[p] >= k - n_buf + 1 (MY page: p no longer reads what
+            its buffer b holds), copy my block into p's buffer b, raise arrive[b][me] = k + 1 in p's page and pushed[p] = k + 1
+            in mine;
+  join      the consumer's stream waits (one kernel) until arrive[b][p] >= k + 1 and pushed[p] >= k + 1 for every peer p: the
+            peers' blocks are here and my own pushes have left (their source is my buffer b).  No event of another hardware
+            queue is waited for: behind SDMA copies such waits cost 0.9 ms per step (profiles/r05_p2p_gap_experiments.txt).
 The field handed out is a VIEW of buffer b: it stays valid until this rank enters its next gather.  (A second buffer only lets
 the peers' COPY streams run a step ahead of a slow rank; no compute stream ever waits for a push, so one buffer is the default.)
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -33,7 +38,8 @@ from . import _lib
 
 _FLAG_BYTES = 4096
 _SCRATCH_BYTES = 4096
-_MAX_WORLD = 120                     # 4 counter arrays of `world` uint64 in the 4 KB flag page
+_MAX_WORLD = 100                     # 5 counter arrays of `world` uint64 + 2 status words in the 4 KB counter page
+_KINDS = {'coarse': 0, 'fine': 1, 'uncached': 2}
 
 
 class _Raw:
@@ -53,150 +59,214 @@ class P2PUnavailable(RuntimeError):
 
 
 class P2PFieldGather:
-    """One per sharded ROM object and field shape; every method that says COLLECTIVE must be called by all ranks."""
+    """One per sharded ROM object; every method that says COLLECTIVE must be called by all ranks."""
 
     SELFTEST_TIMEOUT_S = 10.0
+    JOIN_TIMEOUT_S = 120.0           # the join kernel gives up after this long (status words; see check())
 
-    def __init__(self, eng, world, rank, all_gather, double_buffer=False):
+    def __init__(self, eng, world, rank, all_gather, double_buffer=False, loopback=0):
+        # loopback = L (diagnostic, one-rank groups only: bench.py --share-of N --p2p-loopback N-1): L imaginary peers whose
+        # copies of the field live behind this rank's own in the same buffer.  The rank then issues exactly the copies,
+        # counters and waits of an (L+1)-rank exchange -- L pushes of its block per gather, through the SDMA engines, under
+        # whatever runs next -- with both ends in its own HBM.  What one GPU can show of the exchange's cost.
+        self.loopback = int(loopback) if int(world) == 1 else 0
+        if self.loopback:
+            world = 1 + self.loopback
         if world > _MAX_WORLD:
-            raise P2PUnavailable(f'{world} ranks exceed the {_MAX_WORLD} the flag page holds')
+            raise P2PUnavailable(f'{world} ranks exceed the {_MAX_WORLD} the counter page holds')
         self.eng, self.world, self.rank = eng, int(world), int(rank)
         self.lib = eng.lib
         self._all_gather = all_gather                          # tensor -> (world, *shape) tensor, COLLECTIVE
         self.n_buf = 2 if double_buffer else 1
         self.k = 0                                             # gathers issued
-        self.base = None                                       # my buffer (device pointer)
-        self.peer_base = {}                                    # rank -> mapped pointer
+        self.base = None                                       # my field buffer (device pointer)
+        self.fbase = None                                      # my counter page
+        self.peer_base, self.peer_fbase = {}, {}               # rank -> mapped pointers
         self.shape = None                                      # (n_p, n_total)
         self.field_bytes = 0
+        self.memory = None                                     # 'coarse' | 'uncached': what the field buffers are made of
         torch = eng.torch
-        self.peers = [q for q in range(self.world) if q != self.rank]
-        self.streams = [torch.cuda.Stream(eng.device) for _ in self.peers]
-        self._pushed = None                                    # events behind the pushes of the last gather
+        # copy streams: the pushes to different peers are independent and may use different SDMA engines / xGMI links, but a
+        # HIP process maps its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and a copy stream that
+        # shares a hardware queue with the compute stream puts its SDMA-completion barriers IN FRONT of the next kernel;
+        # so few copy streams (SPR_P2P_STREAMS, default 3), the peers dealt round-robin, starting with the next rank
+        peers = [q for q in range(self.world) if q != self.rank]
+        self.peers = sorted(peers, key=lambda q: (q - self.rank) % self.world)      # rank+1, rank+2, ...: no hot receiver
+        n_streams = max(1, min(len(self.peers), int(os.environ.get('SPR_P2P_STREAMS', '3') or 3)))
+        self._pool = [torch.cuda.Stream(eng.device) for _ in range(n_streams if self.peers else 0)]
+        self.streams = [self._pool[i % n_streams] for i in range(len(self.peers))]
         self.selftest_report = None
+        self.host_ms = dict(begin=0.0, push=0.0, join=0.0, calls=0)   # host wall time spent issuing (bench.py reports the means)
 
     # ------------------------------------------------------------------ set-up (COLLECTIVE)
     def ensure(self, n_p, n_total):
         """Buffers for an (n_p, n_total) float64 field; (re)allocated and exchanged when the shape grows.  COLLECTIVE when
-        it allocates -- every rank sees the same shapes, so every rank takes the same branch."""
+        it allocates -- every rank sees the same shapes, so every rank takes the same branch.  The field buffers are plain
+        device memory when the self-test shows that what a peer writes is seen behind the join (it re-reads lines it has
+        read before), uncached device memory otherwise (SPR_P2P_MEMORY=coarse|uncached skips the first / goes straight
+        to the second)."""
         n_p, n_total = int(n_p), int(n_total)
         need = -(-n_p * n_total * 8 // 4096) * 4096
         if self.base is not None and need <= self.field_bytes:
             self.shape = (n_p, n_total)
             return
-        self.close()
+        want = os.environ.get('SPR_P2P_MEMORY')
+        if want not in (None, '', 'coarse', 'uncached'):
+            raise ValueError("SPR_P2P_MEMORY: 'coarse' or 'uncached'")
+        kinds = [want] if want else ['coarse', 'uncached']
+        why = ''
+        for kind in kinds:
+            self.close()
+            ok, why = self._allocate(need, kind)
+            if ok:
+                self.shape = (n_p, n_total)
+                self.k = 0
+                self.memory = kind
+                return
+        self.close(collective=False)
+        raise P2PUnavailable(why)
+
+    def _allocate(self, need, kind):
+        """-> (ok on ALL ranks, reason).  COLLECTIVE."""
         torch = self.eng.torch
         self.field_bytes = need
-        total = self.n_buf * need + _SCRATCH_BYTES + _FLAG_BYTES
+        copies = self.n_buf * (1 + self.loopback)
+        total = copies * need + _SCRATCH_BYTES
+        self._scratch = copies * need                          # offset of the scratch page in the field buffer
         hb = int(self.lib.spr_p2p_handle_bytes())
-        handle = (C.c_ubyte * hb)()
+        h_field, h_flags = (C.c_ubyte * hb)(), (C.c_ubyte * hb)()
         ok, why = True, ''
         try:
-            base = C.c_void_p()
-            _lib.check(self.lib.spr_p2p_alloc(total, C.byref(base), handle), 'spr_p2p_alloc')
+            base, fbase = C.c_void_p(), C.c_void_p()
+            _lib.check(self.lib.spr_p2p_alloc(total, _KINDS[kind], C.byref(base), h_field), 'spr_p2p_alloc')
             self.base, self.total_bytes = int(base.value), total
-            self._mem = torch.as_tensor(_Raw(self.base, total), device=self.eng.device)  # uint8 view of my buffer
-            self._mem[self.n_buf * need:].zero_()              # scratch + flags
+            _lib.check(self.lib.spr_p2p_alloc(_FLAG_BYTES, _KINDS['fine'], C.byref(fbase), h_flags), 'spr_p2p_alloc')
+            self.fbase = int(fbase.value)
+            self._mem = torch.as_tensor(_Raw(self.base, total), device=self.eng.device)          # uint8 view of my field buffer
+            self._flags = torch.as_tensor(_Raw(self.fbase, _FLAG_BYTES), device=self.eng.device).view(torch.int64)
+            self._mem[self._scratch:].zero_()
+            self._flags.zero_()
             torch.cuda.synchronize(self.eng.device)
         except Exception as exc:                               # noqa: BLE001 -- "not available", decided together below
             ok, why = False, f'rank {self.rank}: {exc}'
-        # every rank's handle bytes and whether it has a buffer at all: one exchange, so that all ranks go on or give up together
-        mine = np.zeros(hb + 8, dtype=np.uint8)
-        mine[:hb] = np.frombuffer(bytes(handle), dtype=np.uint8)
-        mine[hb] = 1 if ok else 0
-        allh = self.eng.to_host(self._all_gather(torch.tensor(mine, device=self.eng.device)))      # (world, hb + 8)
-        if not allh[:, hb].all():
-            bad = [int(q) for q in np.flatnonzero(allh[:, hb] == 0)]
-            self.close(collective=False)
-            raise P2PUnavailable(why or f'ranks {bad} could not allocate an exportable buffer')
+        if self.loopback:
+            if ok:
+                for q in self.peers:                           # imaginary peer q: the q-th copy behind mine, my own counters
+                    self.peer_base[q] = self.base + q * self.n_buf * need
+                    self.peer_fbase[q] = self.fbase
+            return ok, why
+        # every rank's handle bytes and whether it has buffers at all: one exchange, so that all ranks go on or give up together
+        mine = np.zeros(2 * hb + 8, dtype=np.uint8)
+        mine[:hb] = np.frombuffer(bytes(h_field), dtype=np.uint8)
+        mine[hb:2 * hb] = np.frombuffer(bytes(h_flags), dtype=np.uint8)
+        mine[2 * hb] = 1 if ok else 0
+        allh = self.eng.to_host(self._all_gather(torch.tensor(mine, device=self.eng.device)))      # (world, 2 hb + 8)
+        if not allh[:, 2 * hb].all():
+            bad = [int(q) for q in np.flatnonzero(allh[:, 2 * hb] == 0)]
+            return False, why or f'ranks {bad} could not allocate exportable buffers'
         try:
             for q in self.peers:
-                hq = (C.c_ubyte * hb)(*allh[q, :hb].tolist())
-                mapped = C.c_void_p()
-                _lib.check(self.lib.spr_p2p_open(hq, C.byref(mapped)), 'spr_p2p_open')
-                self.peer_base[q] = int(mapped.value)
+                for lo, table in ((0, self.peer_base), (hb, self.peer_fbase)):
+                    hq = (C.c_ubyte * hb)(*allh[q, lo:lo + hb].tolist())
+                    mapped = C.c_void_p()
+                    _lib.check(self.lib.spr_p2p_open(hq, C.byref(mapped)), 'spr_p2p_open')
+                    table[q] = int(mapped.value)
         except Exception as exc:                               # noqa: BLE001
             ok, why = False, f'rank {self.rank}: {exc}'
-        self.shape = (n_p, n_total)
-        self.k = 0
-        ok, why = self._selftest(ok, why)
-        if not ok:
-            self.close(collective=False)
-            raise P2PUnavailable(why)
+        return self._selftest(ok, why, kind)
 
-    def _flag(self, base, kind, idx, b=0):
-        """address of a counter in the flag page of the buffer at `base`: kind 0 arrive[b][idx], 1 release[idx], 2 self-test[idx]"""
-        off = self.n_buf * self.field_bytes + _SCRATCH_BYTES
-        slot = {0: b * self.world + idx, 1: 2 * self.world + idx, 2: 3 * self.world + idx}[kind]
-        return base + off + 8 * slot
+    # counter page (int64 words): arrive[b][src] | release[src] | pushed[peer] | self-test[src] | status (2 words)
+    def _slot(self, kind, idx, b=0):
+        w = self.world
+        return {'arrive': b * w + idx, 'release': 2 * w + idx, 'pushed': 3 * w + idx, 'test': 4 * w + idx, 'status': 5 * w}[kind]
 
-    def _my_flags(self):
-        off = self.n_buf * self.field_bytes + _SCRATCH_BYTES
-        return self._mem[off:off + _FLAG_BYTES].view(self.eng.torch.int64)
+    def _flag(self, page, kind, idx, b=0):
+        """address of a counter in the counter page at `page`"""
+        return page + 8 * self._slot(kind, idx, b)
 
-    def _selftest(self, ok, why):
-        """Every rank pushes a 4 KB pattern and a counter into every peer's buffer and waits for the peers' with the very
-        calls the gather uses; nothing here can block for ever: the stream wait is watched from the host and, on a timeout,
-        satisfied locally.  -> (ok on ALL ranks, reason).  COLLECTIVE."""
+    def _peer_flag(self, q, kind, b=0):
+        """the counter peer q holds FOR ME (arrive / release / test slots are indexed by the writing rank)"""
+        if self.loopback:
+            # all pages are mine: the counter imaginary peer q would hold for me IS the one I await for peer q
+            return self.fbase + 8 * self._slot(kind, q, b)
+        return self.peer_fbase[q] + 8 * self._slot(kind, self.rank, b)
+
+    def _selftest(self, ok, why, kind):
+        """Two rounds of what a gather does, with the very calls it uses, under a host-side watch (nothing here can block
+        for ever: a wait that does not complete in SELFTEST_TIMEOUT_S is satisfied locally): every rank pushes a pattern and
+        a counter into every peer's scratch page, joins, READS the page (which leaves its lines in this GPU's caches), and
+        the second round overwrites them with another pattern -- a rank that then still sees the first one has stale lines
+        behind the join, and this kind of memory will not do.  -> (ok on ALL ranks, reason).  COLLECTIVE."""
         torch, eng = self.eng.torch, self.eng
         t0 = time.perf_counter()
-        report = {}
-        scratch_off = self.n_buf * self.field_bytes
-        if ok:
-            try:
-                pat = torch.full((_SCRATCH_BYTES // 8,), 1000 + self.rank, dtype=torch.int64, device=eng.device)
-                side = torch.cuda.Stream(eng.device)
-                with torch.cuda.stream(side):                  # the waits first: they must see values that arrive later
-                    for q in self.peers:
-                        _lib.check(self.lib.spr_p2p_wait(self._flag(self.base, 2, q), 7, side.cuda_stream), 'spr_p2p_wait')
-            except Exception as exc:                           # noqa: BLE001 -- any failure means "not available"
-                ok, why = False, f'self-test set-up: {exc}'
-        # everybody has its waits enqueued (or has failed) before anybody writes
-        oks = self.eng.to_host(self._all_gather(torch.tensor([1.0 if ok else 0.0], device=eng.device)))
-        if not oks.all():
-            bad = [int(q) for q in np.flatnonzero(oks.reshape(-1) == 0)]
-            if ok:                                             # my waits are enqueued: satisfy them myself
-                self._my_flags()[3 * self.world:4 * self.world] = 7
-                torch.cuda.synchronize(eng.device)
-            return False, why or f'ranks {bad} could not map their peers'
-        try:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(eng.device))
-            for s, q in zip(self.streams, self.peers):
-                s.wait_event(ev)
-                # pattern into MY 32-byte-per-rank slot... the scratch page of peer q, at offset 32 * rank
-                _lib.check(self.lib.spr_p2p_copy(self.peer_base[q] + scratch_off + 32 * self.rank, pat.data_ptr(), 32,
-                                                 s.cuda_stream), 'spr_p2p_copy')
-                _lib.check(self.lib.spr_p2p_signal(self._flag(self.peer_base[q], 2, self.rank), 7, s.cuda_stream),
-                           'spr_p2p_signal')
-            deadline = time.perf_counter() + self.SELFTEST_TIMEOUT_S
-            while not side.query():
-                if time.perf_counter() > deadline:
-                    ok, why = False, 'a stream wait on a counter written by a peer did not complete in ' \
-                                     f'{self.SELFTEST_TIMEOUT_S:.0f} s'
-                    self._my_flags()[3 * self.world:4 * self.world] = 7      # unblock the side stream
-                    break
-                time.sleep(0.0005)
+        if not self.peers:                                     # a one-rank group: nothing to exchange, nothing to test
+            return ok, why
+        side = torch.cuda.Stream(eng.device)
+        cur = torch.cuda.current_stream(eng.device)
+
+        def agree(flag, reason):
+            oks = eng.to_host(self._all_gather(torch.tensor([1.0 if flag else 0.0], device=eng.device))).reshape(-1)
+            if oks.all():
+                return True, ''
+            bad = [int(q) for q in np.flatnonzero(oks == 0)]
+            return False, reason or f'{kind} memory: self-test failed on ranks {bad}'
+
+        def unblock():
+            self._flags[self._slot('test', 0):self._slot('test', 0) + self.world] = 1 << 40
             torch.cuda.synchronize(eng.device)
+
+        for rnd in (1, 2):
+            value = 7 + rnd
             if ok:
-                got = self._mem[scratch_off:scratch_off + _SCRATCH_BYTES].view(torch.int64).cpu().numpy().reshape(-1, 4)
-                want = np.array([[1000 + q] * 4 for q in range(self.world)])
-                rows = [q for q in self.peers if not np.array_equal(got[q], want[q])]
-                if rows:
-                    ok, why = False, f'the pattern pushed by ranks {rows} did not arrive intact'
-        except Exception as exc:                               # noqa: BLE001
-            ok, why = False, f'self-test: {exc}'
+                try:
+                    tab = _ptr_array([self._flag(self.fbase, 'test', q) for q in self.peers])
+                    with torch.cuda.stream(side):              # the wait first: it must see values that arrive later
+                        _lib.check(self.lib.spr_p2p_flags_wait(tab, len(self.peers), value, self.SELFTEST_TIMEOUT_S + 5.0,
+                                                               None, side.cuda_stream), 'spr_p2p_flags_wait')
+                except Exception as exc:                       # noqa: BLE001 -- any failure means "not available"
+                    ok, why = False, f'self-test set-up: {exc}'
+            # everybody has its wait enqueued (or has failed) before anybody writes
+            all_ok, reason = agree(ok, why)
+            if not all_ok:
+                if ok:
+                    unblock()
+                return False, reason
             try:
-                self._my_flags()[3 * self.world:4 * self.world] = 7
+                pat = torch.full((4,), 1000 * rnd + self.rank, dtype=torch.int64, device=eng.device)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                for s, q in zip(self.streams, self.peers):
+                    s.wait_event(ev)
+                    _lib.check(self.lib.spr_p2p_copy(self.peer_base[q] + self._scratch + 32 * self.rank, pat.data_ptr(), 32,
+                                                     s.cuda_stream), 'spr_p2p_copy')
+                    _lib.check(self.lib.spr_p2p_signal(self._peer_flag(q, 'test'), value, s.cuda_stream), 'spr_p2p_signal')
+                deadline = time.perf_counter() + self.SELFTEST_TIMEOUT_S
+                while not side.query():
+                    if time.perf_counter() > deadline:
+                        ok, why = False, (f'{kind} memory: a wait on a counter written by a peer did not complete in '
+                                          f'{self.SELFTEST_TIMEOUT_S:.0f} s')
+                        unblock()
+                        break
+                    time.sleep(0.0005)
                 torch.cuda.synchronize(eng.device)
-            except Exception:                                  # noqa: BLE001
-                pass
-        oks = self.eng.to_host(self._all_gather(torch.tensor([1.0 if ok else 0.0], device=eng.device)))
-        report['seconds'] = time.perf_counter() - t0
-        self.selftest_report = report
-        if not oks.all():
-            bad = [int(q) for q in np.flatnonzero(oks.reshape(-1) == 0)]
-            return False, why or f'self-test failed on ranks {bad}'
+                if ok:
+                    cur.wait_stream(side)
+                    page = self._mem[self._scratch:self._scratch + _SCRATCH_BYTES].view(torch.int64)
+                    got = (page + 0).cpu().numpy().reshape(-1, 4)          # read by a KERNEL (the add), like a consumer would
+                    rows = [q for q in self.peers if not np.array_equal(got[q], [1000 * rnd + q] * 4)]
+                    if rows:
+                        ok, why = False, (f'{kind} memory: round {rnd}, the pattern pushed by ranks {rows} is not what a '
+                                          'kernel reads behind the join' + (' (stale lines)' if rnd == 2 else ''))
+            except Exception as exc:                           # noqa: BLE001
+                ok, why = False, f'self-test: {exc}'
+                try:
+                    unblock()
+                except Exception:                              # noqa: BLE001
+                    pass
+            all_ok, reason = agree(ok, why)
+            if not all_ok:
+                return False, reason
+        self.selftest_report = dict(seconds=time.perf_counter() - t0, memory=kind)
         return True, ''
 
     # ------------------------------------------------------------------ one gather
@@ -204,89 +274,107 @@ class P2PFieldGather:
         """Enter gather k (COLLECTIVE): tell the peers which of my copies they may overwrite, and hand out the tensor the
         reconstruct kernel writes this rank's block into -- the (n_p, n_total) view of buffer k % n_buf."""
         eng, torch = self.eng, self.eng.torch
-        cur = torch.cuda.current_stream(eng.device)
-        st = cur.cuda_stream
-        if self._pushed:                                       # a gather nobody joined: its pushes still read my copy
-            for e in self._pushed:
-                cur.wait_event(e)
-            self._pushed = None
+        t_host = time.perf_counter()
+        st = torch.cuda.current_stream(eng.device).cuda_stream
         if self.peers:
-            tab = _ptr_array([self._flag(self.peer_base[q], 1, self.rank) for q in self.peers])
+            tab = _ptr_array([self._peer_flag(q, 'release') for q in self.peers])
             _lib.check(self.lib.spr_field_gather_p2p_release(tab, len(self.peers), self.k, st), 'spr_field_gather_p2p_release')
         b = self.k % self.n_buf
         n_p, n_total = self.shape
+        self.host_ms['begin'] += 1e3 * (time.perf_counter() - t_host)
         return self._mem[b * self.field_bytes:b * self.field_bytes + n_p * n_total * 8].view(torch.float64).view(n_p, n_total)
 
     def push(self, first, n_loc):
         """My block -- columns [first, first + n_loc) of the tensor begin() returned, written by work already enqueued on the
         current stream -- into every peer's copy.  Returns at once; the copies run on the copy streams."""
         eng, torch = self.eng, self.eng.torch
+        t_host = time.perf_counter()
         b = self.k % self.n_buf
         n_p, n_total = self.shape
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(eng.device))
-        for s in self.streams:
-            s.wait_event(ev)
         if self.peers:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(eng.device))
+            for s in self._pool:
+                s.wait_event(ev)
             field = self.base + b * self.field_bytes
             release_value = max(self.k - self.n_buf + 1, 0)
+            if os.environ.get('SPR_P2P_EXPERIMENT') == 'norelease':   # measurement only: pushes do not wait for the peers' release
+                release_value = 0
             _lib.check(self.lib.spr_field_gather_p2p(
                 field, n_total, n_p, int(first), int(n_loc), len(self.peers),
                 _ptr_array([self.peer_base[q] + b * self.field_bytes for q in self.peers]),
-                _ptr_array([self._flag(self.base, 1, q) for q in self.peers]), release_value,
-                _ptr_array([self._flag(self.peer_base[q], 0, self.rank, b) for q in self.peers]), self.k + 1,
+                _ptr_array([self._flag(self.fbase, 'release', q) for q in self.peers]), release_value,
+                _ptr_array([self._peer_flag(q, 'arrive', b) for q in self.peers]), self.k + 1,
+                _ptr_array([self._flag(self.fbase, 'pushed', q) for q in self.peers]),
                 _ptr_array([s.cuda_stream for s in self.streams])), 'spr_field_gather_p2p')
-        self._pushed = []
-        for s in self.streams:
-            e = torch.cuda.Event()
-            e.record(s)
-            self._pushed.append(e)
         joined_k = self.k
         self.k += 1
+        self.host_ms['push'] += 1e3 * (time.perf_counter() - t_host)
+        self.host_ms['calls'] += 1
         return joined_k
 
     def join(self, k):
-        """The current stream waits for the peers' blocks of gather k and for my own pushes to have left."""
+        """The current stream waits (one kernel) for the peers' blocks of gather k and for my own pushes to have left."""
         eng, torch = self.eng, self.eng.torch
-        cur = torch.cuda.current_stream(eng.device)
+        t_host = time.perf_counter()
         b = k % self.n_buf
         if self.peers:
-            tab = _ptr_array([self._flag(self.base, 0, q, b) for q in self.peers])
-            _lib.check(self.lib.spr_field_gather_p2p_join(tab, len(self.peers), k + 1, cur.cuda_stream),
+            tab = _ptr_array([self._flag(self.fbase, 'arrive', q, b) for q in self.peers]
+                             + [self._flag(self.fbase, 'pushed', q) for q in self.peers])
+            _lib.check(self.lib.spr_field_gather_p2p_join(tab, 2 * len(self.peers), k + 1, self.JOIN_TIMEOUT_S,
+                                                          self._flag(self.fbase, 'status', 0),
+                                                          torch.cuda.current_stream(eng.device).cuda_stream),
                        'spr_field_gather_p2p_join')
-        if k == self.k - 1 and self._pushed:
-            for e in self._pushed:
-                cur.wait_event(e)
-            self._pushed = None
+        self.host_ms['join'] += 1e3 * (time.perf_counter() - t_host)
+
+    def check(self):
+        """Did a join kernel give up (a peer that never pushed)?  One 16-byte D2H copy: call it where the host synchronises
+        anyway.  Raises RuntimeError naming the counter that was not reached."""
+        if self.fbase is None:
+            return
+        s0 = self._slot('status', 0)
+        st = self._flags[s0:s0 + 2].cpu().numpy()
+        if st[0]:
+            i = int(st[0]) - 1
+            n = len(self.peers)
+            who, what = (self.peers[i], 'the block of rank') if i < n else (self.peers[i - n], 'my own push to rank')
+            raise RuntimeError(f'p2p field exchange: rank {self.rank} gave up waiting for {what} {who} after '
+                               f'{self.JOIN_TIMEOUT_S:.0f} s (counter at {int(st[1])}, gather {self.k - 1})')
 
     def arrived(self, k):
         """Host-side look at the arrival counters of gather k (one small D2H copy): which peers' blocks are still missing."""
         b = k % self.n_buf
-        fl = self._my_flags()[b * self.world:(b + 1) * self.world].cpu().numpy()
+        fl = self._flags[b * self.world:(b + 1) * self.world].cpu().numpy()
         return [q for q in self.peers if fl[q] < k + 1]
 
     # ------------------------------------------------------------------ teardown
     def close(self, collective=True):
         """Unmap the peers' buffers and free mine.  With ``collective`` every rank first drains its streams and the ranks
         meet (an all-gather of one number) between unmapping and freeing, so nobody frees what a peer still has mapped."""
-        if self.base is None:
+        if self.base is None and self.fbase is None:
             return
         torch = self.eng.torch
         torch.cuda.synchronize(self.eng.device)
-        for q, p in list(self.peer_base.items()):
-            try:
-                _lib.check(self.lib.spr_p2p_close(p), 'spr_p2p_close')
-            except Exception:                                  # noqa: BLE001 -- teardown
-                pass
-        self.peer_base = {}
-        if collective and self.world > 1:
+        if not self.loopback:
+            for table in (self.peer_base, self.peer_fbase):
+                for q, p in list(table.items()):
+                    try:
+                        _lib.check(self.lib.spr_p2p_close(p), 'spr_p2p_close')
+                    except Exception:                          # noqa: BLE001 -- teardown
+                        pass
+        self.peer_base, self.peer_fbase = {}, {}
+        if collective and self.world > 1 and not self.loopback:
             try:
                 self._all_gather(torch.zeros(1, device=self.eng.device))
             except Exception:                                  # noqa: BLE001 -- the group may be gone at interpreter exit
                 pass
-        self._mem = None
-        try:
-            _lib.check(self.lib.spr_p2p_free(self.base), 'spr_p2p_free')
-        finally:
-            self.base = None
-            self.field_bytes = 0
+        self._mem = self._flags = None
+        for attr in ('base', 'fbase'):
+            p = getattr(self, attr)
+            setattr(self, attr, None)
+            if p is not None:
+                try:
+                    _lib.check(self.lib.spr_p2p_free(p), 'spr_p2p_free')
+                except Exception:                              # noqa: BLE001 -- teardown
+                    pass
+        self.field_bytes = 0

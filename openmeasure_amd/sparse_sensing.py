@@ -1039,7 +1039,13 @@ class ROM:
             return rowmean, gram, fstats[None]
         world, rank = self._world(), self._shard.rank
         buf = eng.zeros((F * m * m + world * F * 3 + world,))
-        buf[F * m * m + world * F * 3 + rank] = float(self._row0)     # this rank's first row (exact below 2^53), see _shard_layout
+        # this rank's first row (exact below 2^53), see _shard_layout -- from a resident scalar: assigning a Python float is a
+        # synchronous pageable H2D copy, which queues on an SDMA engine BEHIND the pushes of a p2p field exchange in flight
+        # and held the next Gram pass back by their whole duration (profiles/r05_c4share8_p2p_loopback_timeline.txt)
+        r0 = self.__dict__.get('_row0_d')                       # (a device tensor: never pickled, see __getstate__)
+        if r0 is None:
+            r0 = self._row0_d = eng.to_device(np.array([float(self._row0)]))
+        buf[F * m * m + world * F * 3 + rank:F * m * m + world * F * 3 + rank + 1].copy_(r0)
         g_view = buf[:F * m * m].view(F, m, m)
         f_view = buf[F * m * m + rank * F * 3:F * m * m + (rank + 1) * F * 3].view(F, 3)
         if getattr(eng, 'supports_gram_out', False):          # the finalize kernel writes straight into the collective buffer
@@ -1819,7 +1825,11 @@ class ROM:
             return pf
         px.join(k)
         close()
-        return out if not to_host else eng.to_host(out).T
+        if not to_host:
+            return out
+        host = eng.to_host(out).T
+        px.check()                                            # the host has just synchronised: did the join kernel give up?
+        return host
 
     def _gather_unequal(self, Ur_d, A_d, lay, to_host, wait):
         """RCCL field all-gather for row blocks of different sizes: every rank contributes its (n_p, n_loc) block padded to

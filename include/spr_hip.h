@@ -78,6 +78,12 @@ int spr_device_cus(int *out_cus);
  * (sparse_sensing.py:272-279), X_scl per feature (:115), the coefficient vectors of reconstruct (:371) -- to
  * the device.  The source may be rewritten once work queued after this call on the stream has completed. */
 int spr_upload_bytes(void *d_dst, const void *h_pinned_src, int64_t n_bytes, void *stream);
+/* ... and back: n_bytes (multiple of 8, <= 4 MiB) from the device into page-locked, device-visible host memory, by a kernel on
+ * `stream`, which then stores ticket_value at h_pinned_ticket (a 64-bit word of such memory as well) with system-scope release:
+ * the host polls the ticket instead of blocking on an event.  Carries the scaled m x m Gram matrix and the feature statistics
+ * to the host eigen-solve that replaces the V factor of np.linalg.svd (sparse_sensing.py:272) -- 32 KB at BASELINE config 2. */
+int spr_download_bytes(void *h_pinned_dst, const void *d_src, int64_t n_bytes, void *h_pinned_ticket, uint64_t ticket_value,
+                       void *stream);
 /* HOST-side helper (host pointers, no device work): unit eigenvectors of the symmetric tridiagonal matrix (h_d[m], h_e[m-1]) for
  * the r eigenvalues h_lam, all at once -- the inverse iterations of LAPACK's dstein (dlagtf / dlagts) with the eigenvalue index
  * as the vectorised dimension, without dstein's re-orthogonalisation inside clusters (check the result; fit() falls back to

@@ -36,6 +36,7 @@ PROTOTYPES = {
     'spr_last_error': (C.c_char_p, []),
     'spr_device_cus': (C.c_int, [C.POINTER(C.c_int)]),
     'spr_upload_bytes': (C.c_int, [_p, _p, _i64, _p]),
+    'spr_download_bytes': (C.c_int, [_p, _p, _i64, _p, _u64, _p]),
     'spr_host_tridiag_vectors': (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32]),
     'spr_stats_gram_workspace': (_sz, [_i32, _i32]),
     'spr_stats_gram_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),

@@ -71,3 +71,33 @@ extern "C" int spr_upload_bytes(void *d_dst, const void *h_pinned_src, int64_t n
   SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
+
+// Small device -> host download as a kernel: the mirror of spr_upload_bytes.  The words go straight into page-locked,
+// device-visible host memory and a 64-bit ticket is stored behind them (system-scope release), so the host can poll the
+// ticket in its own memory instead of blocking on an event -- between the Gram pass and the projection of a small fit()
+// (BASELINE config 2: 0.3 ms of a 1.5 ms step) the copy-engine launch, the event and the wake-up of a blocked thread are a
+// tenth of the gap.  One workgroup: the payload is a few tens of KB (the m x m Gram matrix and 5 F statistics).
+namespace {
+__global__ __launch_bounds__(1024) void download_kernel(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst,
+                                                        int64_t n_words, unsigned long long *__restrict__ ticket,
+                                                        unsigned long long value) {
+  for (int64_t i = threadIdx.x; i < n_words; i += 1024) __builtin_nontemporal_store(src[i], dst + i);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: every lane's stores are on their way before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+extern "C" int spr_download_bytes(void *h_pinned_dst, const void *d_src, int64_t n_bytes, void *h_pinned_ticket,
+                                  uint64_t ticket_value, void *stream) {
+  SPR_REQUIRE(h_pinned_dst && d_src && h_pinned_ticket, SPR_E_INVALID, "spr_download_bytes: NULL pointer");
+  SPR_REQUIRE(n_bytes > 0 && n_bytes % 8 == 0 && n_bytes <= (int64_t)1 << 22, SPR_E_INVALID,
+              "spr_download_bytes: n_bytes=%lld must be a positive multiple of 8 up to 4 MiB", (long long)n_bytes);
+  SPR_REQUIRE(((uintptr_t)h_pinned_dst | (uintptr_t)d_src | (uintptr_t)h_pinned_ticket) % 8 == 0, SPR_E_INVALID,
+              "spr_download_bytes: unaligned pointer");
+  hipLaunchKernelGGL(download_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint64_t *>(d_src), static_cast<uint64_t *>(h_pinned_dst), n_bytes / 8,
+                     static_cast<unsigned long long *>(h_pinned_ticket), (unsigned long long)ticket_value);
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}

@@ -35,6 +35,10 @@ What differs from the reference, by design:
     a float32 BASIS is an explicit storage option, DeviceMatrix(tensor, basis='f32') (BASELINE config 5);
   * 'gem' placement is the noise-free limit of the reference's rule (it adds unseeded noise, :667) for the first
     r-1 sensors and, beyond, a deterministic ridge stand-in for that noise (see _gem_ridge_phase);
+  * fit() -> optimal_placement('gem') returns the GEM sensors OF THIS BASIS: the reference's rule takes the variance of
+    a row over its r entries (:622, :638), which changes with the sign of a column of Ur, and LAPACK's signs are
+    arbitrary -- the reference's own sensors coincide only after fit(basis=(Ur_ref, Ar_ref)) ('qr' placement, predict
+    and reconstruct do not depend on the signs);
   * options that have no device implementation ('COLS', the kurtosis scalings 'vast_2..4', which are
     ill-defined in the reference itself) raise ``NotImplementedError`` -- they never fall back to a CPU path.
 
@@ -366,7 +370,8 @@ def _eigh_small(G):
     return w, v
 
 
-_EIGH_TOP_MIN_M = 96           # below this dsyevd is a fraction of a millisecond: nothing to gain
+_EIGH_TOP_MIN_M = 96           # below this dsyevd is a fraction of a millisecond: nothing to gain (m = 64, r = 32: dsyevd 156-173 us,
+                               # the top-r route 140 us in isolation but 207 us inside fit() on a second host -- round 5)
 _LWORK = {}
 
 
@@ -1523,7 +1528,8 @@ class ROM:
         S_safe = np.maximum(S[:r], floor if floor > 0 else 1.0)
         W = V[:, :r] / S_safe
         self._trace.mark('W')
-        W_d = eng.to_device(W)
+        # (W's previous reader is the projection of the previous fit(), in front of the Gram download the host has waited for)
+        W_d = eng.upload_reuse(('W', id(self)), W) if hasattr(eng, 'upload_reuse') else eng.to_device(W)
         self._trace.mark('upload')
         self.precentered_ = bool(center and self._needs_precenter(S[0] / S_safe[-1]))
         nrm0 = self._norms_buffer(Xd, r, self.precentered_ and center)
@@ -1887,7 +1893,7 @@ class SPR(ROM):
         while it is small (64 MiB), a OneHotRows above that (46 GB dense at BASELINE config 3) -- same behaviour for
         C[i, :], C @ x, np.argmax(C, axis=1), train(C).  The ordered global sensor rows are also in ``self.sensors_``."""
         if calc_type == 'gem':
-            return self._placement_gem(n_sensors, mask, d_min)
+            return self._placement_gem(n_sensors, mask, d_min, verbose)
         if calc_type != 'qr':
             raise NotImplementedError('The sensor selection method has not been implemented yet')
         eng = self._engine()
@@ -1932,11 +1938,17 @@ class SPR(ROM):
         """Reference :586-698, the method optimal_placement(calc_type='gem') calls with the fitted basis: greedy entropy
         placement on the rows of ``Ur`` (n_local, r) -> the ordered sensor rows (global indices).  ``Ur`` may be the fitted
         basis (``self.Ur``: the copy in HBM is used) or any other array of that many rows, which is uploaded for the call and
-        leaves the fitted state as it was.  ``verbose`` is accepted and prints nothing (the reference prints its entropy
-        table)."""
+        leaves the fitted state as it was.  ``verbose``: the reference's table (:633-635, :652, :694) -- per sensor its row
+        variance, its conditional variance given the earlier picks and the accumulated entropy, in the reference's scaled
+        units -- recomputed on the host from the picked rows with the reference's own formulas (noise-free; _gem_table).
+
+        The picks are the GEM sensors OF THE BASIS HANDED IN.  The row variances over the r entries (:622, :638) change when
+        a column of Ur changes sign, and LAPACK's singular-vector signs are arbitrary (fit() here fixes them by its own
+        rule, _sign_fix): after a plain fit() the sensors coincide with the reference's only if the bases coincide --
+        fit(basis=(Ur_ref, Ar_ref)) -- not merely up to column signs."""
         fitted = self._host.get('Ur')
         if Ur is fitted and 'Ur' in self._d:
-            self._placement_gem(n_sensors, mask, d_min)
+            self._placement_gem(n_sensors, mask, d_min, verbose)
             return self.sensors_.copy()
         Ur = np.asarray(Ur)
         if Ur.ndim != 2 or Ur.shape[0] != self.X.shape[0]:
@@ -1953,7 +1965,7 @@ class SPR(ROM):
             if 'rowmean' not in self._d:
                 self._d['rowmean'] = eng.zeros((Ur.shape[0],))    # only its address is used (the measure kernel's centre output)
             self.r = int(Ur.shape[1])
-            self._placement_gem(n_sensors, mask, d_min)
+            self._placement_gem(n_sensors, mask, d_min, verbose)
             return self.sensors_.copy()
         finally:
             for k, v in keep_attrs.items():                    # a placement on a foreign basis is not this object's placement
@@ -1974,7 +1986,42 @@ class SPR(ROM):
             if keep_host is not missing:
                 self._host['Ur'] = keep_host
 
-    def _placement_gem(self, n_sensors, mask, d_min):
+    def _gem_table(self, piv, file=None):
+        """The table gem(verbose=True) prints in the reference (:633-635 header, :652 first row, :694 later rows): number of
+        sensors, sigma^2 of the new sensor's row, its conditional variance given the earlier picks, accumulated entropy --
+        all in the reference's scaled units (coef = 2 / sqrt(largest row variance), :622-624).  Recomputed on the host from
+        the s picked rows of Ur with the reference's formulas (np.cov of the scaled picks, :660-678), without its unseeded
+        noise; beyond r - 1 sensors, where the reference's value is decided by that noise, with the ridge this
+        implementation puts in its place (_GEM_RIDGE).  The reference indexes its MASKED variance vector with the global row
+        (:652, :694) -- right only without a mask; the variance printed here is the picked row's."""
+        eng = self._engine()
+        r = self.r
+        piv = np.asarray(piv, dtype=np.int64)
+        ip, ix, v = self._csr_device(None, (np.arange(len(piv) + 1), piv, np.ones(len(piv))))
+        rows_d, _ = eng.measure_csr(ip, ix, v, self._d['Ur'], self._row0, self._d['rowmean'])
+        Ua = np.asarray(eng.to_host(self._all_reduce(rows_d)), dtype=np.float64)
+        coef = 2.0 / np.sqrt(np.var(Ua[0], ddof=1))           # the first pick is the row of largest variance (:641)
+        A = Ua * coef
+        sig = np.var(A, ddof=1, axis=1)
+        header = ['# sensors', 'sigma^2 y', 'sigma^2 y|a', 'Htot']
+        print(f"{'-'*70} \n {header[0]:^10} {header[1]:^10} {header[2]:^10} {header[3]:^10} \n ", file=file)
+        H_tot = 0.0
+        for s in range(len(piv)):
+            if s == 0:
+                print(f"{s+1:^10} {sig[s]:^10.2e} {'  -':^10} {'  -':^10}", file=file)
+                continue
+            Ac = A[:s] - A[:s].mean(axis=1, keepdims=True)
+            S_aa = np.atleast_2d(Ac @ Ac.T / (r - 1))
+            reg = self._GEM_RIDGE if s >= r - 1 else 0.0
+            S_inv = 1.0 / S_aa if s == 1 else np.linalg.inv(S_aa + reg * np.eye(s))
+            yc = A[s] - A[s].mean()
+            S_ya = Ac @ yc / (r - 1)
+            cond = float(yc @ yc / (r - 1) - S_ya @ S_inv @ S_ya)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                H_tot += 0.5 * np.log(cond) + 0.5 * (np.log(2 * np.pi) + 1)
+            print(f"{s+1:^10} {sig[s]:^10.2e} {cond:^10.2e} {H_tot:^10.2e}", file=file)
+
+    def _placement_gem(self, n_sensors, mask, d_min, verbose=False):
         """calc_type='gem' (reference :586-698, :745-751): greedy maximisation of the conditional variance
         sigma_y^2 - S_ya S_aa^-1 S_ay of a row of Ur (its r entries as samples) given the rows picked so far,
         inside `mask`, never closer than d_min to an earlier pick.  That quantity is 1/(r-1) times the squared
@@ -2019,6 +2066,8 @@ class SPR(ROM):
         piv = eng.to_host(st['piv'])[1:].astype(np.int64)
         self.sensors_ = piv
         self.pivot_gap_ = eng.to_host(st['gap'])[1:]
+        if verbose == True:                                   # noqa: E712  (the reference's comparison, :631)
+            self._gem_table(piv)
         C = self._one_hot(piv, self._n_global)
         self._placed = (C, piv)
         return C

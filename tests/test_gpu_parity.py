@@ -573,6 +573,33 @@ def test_public_gem_method_on_the_device(eng):
     np.testing.assert_array_equal(spr.reconstruct(spr.Ar[0, :])[:, 0], spr.reconstruct(spr.Ar[:1])[:, 0])
 
 
+def test_gem_sign_dependence_on_the_device(eng, capsys):
+    """the GEM sensors depend on the signs of the basis columns (reference :622, :638 take row variances over
+    the r entries) -- flip one column and BOTH the HIP path and the oracle's literal formulas move to the same new sensors;
+    the dependence is the algorithm's, not the kernels'.  Also gem(verbose=True): the reference's table."""
+    from openmeasure_amd.sparse_sensing import SPR
+    rng = np.random.default_rng(5)
+    n_points, F, r = 4000, 2, 8
+    n = n_points * F
+    U = rng.standard_normal((n, r)) * (0.5 + rng.random((n, 1))) / np.sqrt(n)
+    xyz = rng.random((n_points, 3))
+    U2 = U.copy()
+    U2[:, 2] *= -1
+    want, lead = orc.gem_pivots(U, 6, xyz, F, None, 0.0)
+    want2, lead2 = orc.gem_pivots(U2, 6, xyz, F, None, 0.0)
+    assert min(lead.min(), lead2.min()) > 1e-3 and not np.array_equal(want, want2)
+    spr = SPR(np.zeros((n, r + 1)), F, xyz, engine=eng)
+    np.testing.assert_array_equal(spr.gem(U, 6, None, 0.0, False), want)
+    np.testing.assert_array_equal(spr.gem(U2, 6, None, 0.0, True), want2)
+    out = capsys.readouterr().out.splitlines()
+    rows = [ln.split() for ln in out if ln.strip() and ln.split()[0].isdigit()]
+    assert len(rows) == 6 and 'sigma^2 y|a' in out[1]
+    # ... and the same through fit(basis=...) + optimal_placement, the route a user of the reference's basis takes
+    spr.fit(basis=(U2, np.eye(r + 1, r)))
+    spr.optimal_placement(calc_type='gem', n_sensors=6)
+    np.testing.assert_array_equal(spr.sensors_, want2)
+
+
 def test_masked_placement_vs_oracle(eng):
     from openmeasure_amd.sparse_sensing import SPR
     X = synth_host(3000, 3, 24, 24, 0.75, 1e-3, 77)

@@ -282,6 +282,43 @@ def test_public_gem_method():
         spr.gem(U[:-1], 4, None, 0.0, False)
 
 
+def test_gem_depends_on_the_signs_of_the_basis_and_prints_the_reference_table(capsys):
+    """The GEM rule takes the variance of a row of Ur over its r entries (reference :622, :638): flipping the sign of ONE
+    column of the basis -- something LAPACK is free to do -- moves the sensors.  The dependence is the algorithm's: the
+    class and the oracle's literal formulas move to the SAME new sensors.  (Hence: fit() -> optimal_placement('gem') gives
+    the GEM sensors of this implementation's basis; the reference's only after fit(basis=(Ur_ref, Ar_ref)).)
+    verbose=True prints the reference's table (:633-635, :652, :694)."""
+    from oracle import spr_oracle as orc
+    rng = np.random.default_rng(5)
+    n_points, F, r = 400, 2, 8
+    n = n_points * F
+    U = rng.standard_normal((n, r)) * (0.5 + rng.random((n, 1))) / np.sqrt(n)
+    xyz = rng.random((n_points, 3))
+    U2 = U.copy()
+    U2[:, 2] *= -1
+    spr = SPR(np.zeros((n, r + 1)), F, xyz, engine=NumpyEngine())
+    got, got2 = spr.gem(U, 6, None, 0.0, False), spr.gem(U2, 6, None, 0.0, True)
+    want, lead = orc.gem_pivots(U, 6, xyz, F, None, 0.0)
+    want2, lead2 = orc.gem_pivots(U2, 6, xyz, F, None, 0.0)
+    assert min(lead.min(), lead2.min()) > 1e-6
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got2, want2)
+    assert not np.array_equal(want, want2)                     # the sign of one column changed the sensors
+    out = capsys.readouterr().out.splitlines()
+    assert '# sensors' in out[1] and 'sigma^2 y|a' in out[1] and 'Htot' in out[1]
+    rows = [ln.split() for ln in out if ln.strip() and ln.split()[0].isdigit()]
+    assert [int(t[0]) for t in rows] == [1, 2, 3, 4, 5, 6] and rows[0][2:] == ['-', '-']
+    # the numbers are the reference's quantities: row variance and conditional variance of every pick in its scaled units
+    coef = 2 / np.sqrt(np.var(U2, ddof=1, axis=1).max())
+    A = U2[want2] * coef
+    np.testing.assert_allclose([float(t[1]) for t in rows], np.var(A, ddof=1, axis=1), rtol=6e-3)
+    S = np.cov(A[:3], ddof=1)
+    full = np.cov(A[:3], A[3], ddof=1)
+    cond = full[-1, -1] - full[-1, :-1] @ np.linalg.inv(S) @ full[:-1, -1]
+    assert abs(float(rows[3][2]) - cond) <= 6e-3 * cond
+    assert all(float(a[3]) != float(b[3]) for a, b in zip(rows[1:], rows[2:]))    # entropy accumulates
+
+
 def test_decomposition_public(small):
     X, F, xyz = small
     rom = ROM(X, F, xyz, engine=NumpyEngine())

@@ -986,8 +986,33 @@ int check_ur(const char *who, const void *Ur, int64_t n_rows, int32_t r, int64_t
 // winners come down to theta, ONE full sweep applies the epoch's directions to every row (rewriting nrm_e) and a new
 // epoch starts with a lower theta.  The directions of an epoch (up to NT tiles of 16) sit in LDS in fragment order;
 // rows go HBM -> registers in the MFMA A layout exactly as in qr_refresh_direct_kernel.
-template <int NG, int NT, typename TU, bool POOL>
-__global__ __launch_bounds__(QR_THREADS, (NG <= 4 ? 3 : 2)) void qr_epoch_sweep_kernel(
+// The MFMAs of an epoch sweep for one 16-row block: NTT direction tiles side by side -- NTT independent accumulator chains, every
+// A operand used for NTT MFMAs -- instead of one tile after the other (16 dependent v_mfma_f64 per tile: a wave then issues one
+// MFMA per result latency, and a full sweep's time grew by 1.2-1.9 ms per extra tile, profiles/r05_epoch_sweep_ab.txt).
+template <int NG, int NTT, typename P4>
+__device__ inline void epoch_tiles_mfma(const P4 (&cur)[NG], const double *__restrict__ ql0, double (&q2)[4]) {
+  f64x4 acc[NTT];
+#pragma unroll
+  for (int tl = 0; tl < NTT; ++tl) acc[tl] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const double a4[4] = {(double)cur[g].x, (double)cur[g].y, (double)cur[g].z, (double)cur[g].w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int tl = 0; tl < NTT; ++tl)
+        acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], ql0[tl * NG * 256 + (g * 4 + t) * 64], acc[tl], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int tl = 0; tl < NTT; ++tl) {
+    q2[0] = fma(acc[tl].x, acc[tl].x, q2[0]); q2[1] = fma(acc[tl].y, acc[tl].y, q2[1]);
+    q2[2] = fma(acc[tl].z, acc[tl].z, q2[2]); q2[3] = fma(acc[tl].w, acc[tl].w, q2[3]);
+  }
+}
+
+template <int NG, int NT, typename TU, bool POOL, bool ILP = false>
+__global__ __launch_bounds__(QR_THREADS, (NG <= 4 && !ILP ? 3 : 2)) void qr_epoch_sweep_kernel(
     const TU *__restrict__ Ur, int64_t n_rows, int r, int64_t ldu, int64_t row0, const double *__restrict__ Q, int nq,
     double *__restrict__ nrm_e, double *__restrict__ nrm, const int32_t *__restrict__ pool,
     const int32_t *__restrict__ pool_n_ptr, double *__restrict__ tops) {
@@ -1044,6 +1069,13 @@ __global__ __launch_bounds__(QR_THREADS, (NG <= 4 ? 3 : 2)) void qr_epoch_sweep_
   auto process = [&](const P4 (&cur)[NG], double old, int64_t orow) {
     const bool mine = who.own && orow >= 0;
     double q2[4] = {0.0, 0.0, 0.0, 0.0};                       // this lane's direction column, summed over the tiles
+    if (ILP) {                                                 // the tiles' accumulator chains side by side
+      const double *ql0 = Ql + kk * 16 + li;
+      if (nt == 1) epoch_tiles_mfma<NG, 1, P4>(cur, ql0, q2);
+      else if (nt == 2) epoch_tiles_mfma<NG, (NT >= 2 ? 2 : 1), P4>(cur, ql0, q2);
+      else if (nt == 3) epoch_tiles_mfma<NG, (NT >= 3 ? 3 : 1), P4>(cur, ql0, q2);
+      else epoch_tiles_mfma<NG, (NT >= 4 ? 4 : 1), P4>(cur, ql0, q2);
+    } else
     for (int tile = 0; tile < nt; ++tile) {
       const double *ql = Ql + tile * NG * 256 + kk * 16 + li;
       f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1506,11 +1538,27 @@ static int qr_epoch_entry(const char *who, const TU *d_Ur, int64_t n_rows, int32
   (void)pool_n_host;
   const double *Qe = d_Q + (int64_t)j_e * r;
   const int nq = j - j_e;
+  // full sweeps of bases up to 64 columns run the tiles' MFMA chains side by side (template flag ILP: -11 % at one tile, -13 % at
+  // two, -5 % at three, profiles/r05_epoch_sweep_ab.txt; wider bases gain nothing -- r = 128: 19.0 vs 19.1 ms, MFMA-bound at 0.82
+  // of the peak -- and pool sweeps neither); SPR_QR_EPOCH_ILP=0: one tile after the other everywhere, 2: pool sweeps too (A/B)
+  static int ilp_env = -1;
+  if (ilp_env < 0) {
+    const char *e = getenv("SPR_QR_EPOCH_ILP");
+    ilp_env = e ? atoi(e) : 1;
+  }
+  const bool ilp_form = ilp_env && !d_pool;
+  const bool ilp_pool = ilp_env == 2;                          // SPR_QR_EPOCH_ILP=2: the pool sweeps as well (A/B)
 #define ES(NGV, NTV)                                                                                                     \
   do {                                                                                                                   \
-    if (d_pool)                                                                                                          \
+    if (d_pool && ilp_pool && NGV <= 4)                                                                                  \
+      hipLaunchKernelGGL((qr_epoch_sweep_kernel<NGV, NTV, TU, true, (NGV <= 4)>), dim3(grid), dim3(QR_THREADS), 0, st,    \
+                         d_Ur, n_rows, (int)r, ldu, row0, Qe, nq, d_nrm_e, d_nrm, d_pool, d_pool_n, w.tops);             \
+    else if (d_pool)                                                                                                     \
       hipLaunchKernelGGL((qr_epoch_sweep_kernel<NGV, NTV, TU, true>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows,  \
                          (int)r, ldu, row0, Qe, nq, d_nrm_e, d_nrm, d_pool, d_pool_n, w.tops);                           \
+    else if (ilp_form && NGV <= 4)                                                                                       \
+      hipLaunchKernelGGL((qr_epoch_sweep_kernel<NGV, NTV, TU, false, (NGV <= 4)>), dim3(grid), dim3(QR_THREADS), 0, st,   \
+                         d_Ur, n_rows, (int)r, ldu, row0, Qe, nq, d_nrm_e, d_nrm, d_pool, d_pool_n, w.tops);             \
     else                                                                                                                 \
       hipLaunchKernelGGL((qr_epoch_sweep_kernel<NGV, NTV, TU, false>), dim3(grid), dim3(QR_THREADS), 0, st, d_Ur, n_rows, \
                          (int)r, ldu, row0, Qe, nq, d_nrm_e, d_nrm, d_pool, d_pool_n, w.tops);                           \

@@ -33,8 +33,13 @@
  *   SPR_QR_FUSED_STEPS=0      spr_qr_steps_f64: three launches per candidate step instead of the fused one
  *   SPR_RESERVE_CUS=k         every persistent grid is sized for k compute units fewer (multi-GPU diagnostic: leaves CUs to
  *                             RCCL's kernel, which cannot share one with the Gram / projection workgroups)
+ *   SPR_QR_EPOCH_ILP=0|2      spr_qr_epoch_sweep_*: direction tiles one after the other in full sweeps too | side by side in pool
+ *                             sweeps as well (default 1: full sweeps of bases up to 64 columns side by side)
+ *   SPR_P2P_BLIT=1            spr_p2p_copy / spr_field_gather_p2p: blit kernels instead of the SDMA engines
  * and by the Python layer (openmeasure_amd/): SPR_PROJECT_STREAM=1 (streamed-W projection for every shape),
- * SPR_GAP_FILLER=0 (no filler launch in fit()'s host gap, ROM.gap_filler), SPR_PINNED_RESULT_GB=<g> (budget of page-locked
+ * SPR_GAP_FILLER=1|0 (ROM.gap_filler, opt-in: a filler launch in fit()'s host gap), SPR_GATHER=auto|p2p|rccl (field exchange of
+ * sharded objects), SPR_P2P_STREAMS / SPR_P2P_BUFFERS / SPR_P2P_MEMORY (openmeasure_amd/p2p.py), SPR_DL_KERNEL=0 (small downloads
+ * by copy + event), SPR_PINNED_RESULT_GB=<g> (budget of page-locked
  * memory for host results still alive, default 8; 0 = pageable copies only), SPR_TRACE=1 (per-phase wall clock of fit(),
  * synchronising), SPR_HIP_LIBRARY=<path> (another build of this library).  None of them is needed in production.
  */

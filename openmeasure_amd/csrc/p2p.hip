@@ -17,7 +17,7 @@
 //     the copies (copy streams), set / awaited on the compute stream by ONE single-wave kernel each -- microseconds of one
 //     wave, nothing that occupies a compute unit while the bytes move.
 //
-// Measured on one MI355X, two processes (tools/lab/p2p_probe.hip, profiles/r05_p2p_probe.txt): a NoCU copy into the other
+// Measured on one MI355X, two processes (tools/archive/lab/p2p_probe.hip, profiles/r05_p2p_probe.txt): a NoCU copy into the other
 // process's buffer runs at 61 GB/s and leaves a CU-filling kernel's time unchanged (24.87 ms with and without), the same
 // copy as a blit kernel takes 15 ms next to that kernel; write/wait values work on IPC-mapped device memory.
 #include <stdlib.h>

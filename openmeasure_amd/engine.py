@@ -188,16 +188,19 @@ class HipEngine:
         reuse the blocks earlier results have returned.  Page-locked memory is a machine-wide resource: the results
         still referenced by the caller are counted (weak references to the ndarrays handed out, _export_pinned) and a new
         one is only pinned while the total stays under the budget."""
-        import os
         torch = self.torch
         nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-        budget = self._PINNED_RESULT_BYTES
-        env = os.environ.get('SPR_PINNED_RESULT_GB')
-        if env is not None:
-            try:
-                budget = int(float(env) * (1 << 30))
-            except ValueError:
-                pass
+        budget = self.__dict__.get('_pinned_budget')
+        if budget is None:                                     # SPR_PINNED_RESULT_GB, read once
+            import os
+            budget = self._PINNED_RESULT_BYTES
+            env = os.environ.get('SPR_PINNED_RESULT_GB')
+            if env is not None:
+                try:
+                    budget = int(float(env) * (1 << 30))
+                except ValueError:
+                    pass
+            self._pinned_budget = budget
         live = getattr(self, '_pinned_live', None)
         if live is None:
             live = self._pinned_live = []
@@ -240,10 +243,17 @@ class HipEngine:
         ``out``: a C-contiguous ndarray of t's shape and dtype to fill (e.g. a block of a larger result)."""
         torch = self.torch
         from concurrent.futures import ThreadPoolExecutor
+        res = np.empty(tuple(t.shape), dtype=torch.empty((), dtype=t.dtype).numpy().dtype) if out is None else out
+        if not t.is_contiguous() and t.dim() == 2 and t.shape[0] > 1:
+            # a matrix with a padded row stride (the basis of an odd r is buf[:, :r]): row blocks, each made contiguous on its
+            # own -- t.contiguous() of the whole would put a second copy of a 46 GB basis next to X (ADVICE r04)
+            rows = max(1, self._STAGED_CHUNK // max(1, t.shape[1] * t.element_size()))
+            for i0 in range(0, t.shape[0], rows):
+                self._to_host_staged(t[i0:i0 + rows].contiguous(), out=res[i0:i0 + rows])
+            return res
         t = t.contiguous()
         flat = t.view(-1)
         n = flat.numel()
-        res = np.empty(tuple(t.shape), dtype=torch.empty((), dtype=t.dtype).numpy().dtype) if out is None else out
         dst = res.reshape(-1)
         if getattr(self, '_dstage2', None) is None:
             self._dstage2 = [torch.empty(self._STAGED_CHUNK, dtype=torch.uint8, pin_memory=True) for _ in range(2)]

@@ -1608,6 +1608,10 @@ class ROM:
             Ar = np.asarray(basis[1])
             V_r = None
         self._d['Ur'] = Ur_d
+        if '_layout_src' in self.__dict__ and '_layout' not in self.__dict__:
+            # first sharded fit(): the table of row blocks rode on the all-reduce -- check now that the blocks tile the global
+            # rows (ValueError on every rank), not at the first gather: placement, train and predict use global indices too
+            self._shard_layout(Ur_d.shape[0])
         self.Ar = Ar
         self.r = Ar.shape[1]
         Sigma_r = np.linalg.norm(Ar, axis=0)                  # :504-508

@@ -116,9 +116,8 @@ def _gap_worker(rank, world, port, out_dir):
         row0, n_loc = (0, 10) if rank == 0 else (11, 9)              # row 10 belongs to nobody
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
                   engine=NumpyEngine())
-        spr.fit(select_modes='number', n_modes=3)
         try:
-            spr.reconstruct(spr.Ar[:1])
+            spr.fit(select_modes='number', n_modes=3)              # round 5: the first fit() already refuses the layout
             msg = ''
         except ValueError as e:
             msg = str(e)
@@ -129,8 +128,9 @@ def _gap_worker(rank, world, port, out_dir):
 
 
 def test_blocks_that_do_not_cover_the_rows_are_refused_on_every_rank(tmp_path):
-    """a hole between two ranks' blocks: reconstruct() raises the same ValueError on ALL ranks (the table of blocks comes out
-    of fit()'s all-reduce, identical everywhere), so nobody is left waiting in the gather"""
+    """a hole between two ranks' blocks: the first fit() raises the same ValueError on ALL ranks (the table of blocks comes out
+    of its all-reduce, identical everywhere) -- before placement, train or predict can use a wrong global index, and nobody
+    is left waiting in a collective"""
     mp.spawn(_gap_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     msgs = [open(tmp_path / f'gap{r}.txt').read() for r in range(2)]
     assert msgs[0] == msgs[1] and 'do not cover' in msgs[0] and '[[0, 10], [11, 9]]' in msgs[0]

@@ -2,7 +2,7 @@
 Times the MFMA refresh sweep (46 GB read) on a random 90M x 64 basis allocated before / after a 184 GB block."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from openmeasure_amd.engine import HipEngine
 eng = HipEngine()

@@ -1,7 +1,7 @@
 """Does restoring the BLAS pool size after the small eigen-solve stall the next H2D copy? (GPU box)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from threadpoolctl import ThreadpoolController
 from openmeasure_amd.engine import HipEngine

@@ -1,7 +1,7 @@
 """Where does the collective path of fit() lose time?  One-rank RCCL group at c3s, host and GPU timelines. (GPU box)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.distributed as dist
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))

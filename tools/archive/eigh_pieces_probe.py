@@ -44,7 +44,7 @@ for m, r in ((256, 64), (512, 128)):
               f'{t_trd + t_erf + t_in + t_bk:.3f} ms | top-r vectors vs dsyevd {np.abs(np.abs(V.T @ ref) - np.eye(r)).max():.1e}, '
               f'orthogonality {np.abs(V.T @ V - np.eye(r)).max():.1e}', flush=True)
     import sys, os
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import openmeasure_amd.sparse_sensing as ss
     t_full = t(lambda: ss._eigh_small(G))[0]
     t_top = t(lambda: ss._eigvecs_top(ss._eigh_tridiagonal(G)[1], ss._eigh_tridiagonal(G)[0], r))[0]

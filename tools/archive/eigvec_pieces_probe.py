@@ -4,7 +4,7 @@ host, one BLAS thread: what is LAPACK, what is the library's batched inverse ite
 usage: python tools/eigvec_pieces_probe.py [m r ...]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from scipy.linalg import lapack
 import openmeasure_amd.sparse_sensing as ss
 from openmeasure_amd import _lib

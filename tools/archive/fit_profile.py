@@ -1,7 +1,7 @@
 """Host-side profile of fit()+reconstruct() at a small workload (where the Python/ctypes overhead between the kernels is
 a visible share of the step): python tools/fit_profile.py [workload]"""
 import cProfile, pstats, sys, os, io
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from openmeasure_amd.engine import HipEngine

@@ -6,7 +6,7 @@ workgroups polling a pinned flag, sleeping or spinning on f32 FMAs) changed noth
 the chip ramps its clock with the LOAD of the previous milliseconds, not with mere occupancy."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from openmeasure_amd.engine import HipEngine
 from openmeasure_amd.synth import make_R

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does a keep-alive kernel in the host gap of fit() pay?  (GPU box; round-4 record in profiles/r04_gap_filler_probe.txt.)
-The spinner variants need the lab kernel tools/lab/keepalive.hip built into the library (see its header); without it only the
+The spinner variants need the lab kernel tools/archive/lab/keepalive.hip built into the library (see its header); without it only the
 idle / real-kernel-filler variants run.
 
 One rank's block of BASELINE config 4 at N = 8 (11.25M rows x 256): the step's kernel sequence
@@ -9,7 +9,7 @@ for the gap filled by spr_keepalive_start in its modes (1: f64 MFMA on registers
 Also the sequence with NO gap at all (what the kernels cost back to back)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from openmeasure_amd.engine import HipEngine
 from openmeasure_amd.synth import make_R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/lab/pmc_lab.sh <out-tag> <program and args...>   -- two PMC passes over one program, summary to stdout
+# usage (GPU box): tools/archive/lab/pmc_lab.sh <out-tag> <program and args...>   -- two PMC passes over one program, summary to stdout
 # (the program itself goes after `--`: no env/bash wrapper under rocprofv3)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"

@@ -6,7 +6,7 @@
 // MFMAs per 16-row block with the B digits read from a 128 KB LDS image, and the combination of the eight digit groups in f64.
 // What is not: the LDS image holds arbitrary bytes, the row scales in the epilogue come from the wrong lanes, nothing is centred.
 // One wave per SIMD (the register budget: 128 row data + 32 digits + 128 accumulators + 16 B), 16-row blocks dealt round-robin.
-// Build: hipcc -O3 --offload-arch=gfx950 tools/lab/proj_i8_model.hip -o build/probes/proj_i8_model ; run: proj_i8_model [rows]
+// Build: hipcc -O3 --offload-arch=gfx950 tools/archive/lab/proj_i8_model.hip -o build/probes/proj_i8_model ; run: proj_i8_model [rows]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

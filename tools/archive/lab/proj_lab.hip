@@ -1,6 +1,6 @@
 // Lab harness (GPU box): the W-stationary projection kernel (csrc/project_ws.hip) against the general one
 // (spr_project_f64 of the shipped library) on random data -- same inputs, max difference, HIP-event times.
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Iopenmeasure_amd/csrc -DPROJ_WS_LAB tools/lab/proj_lab.hip \
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Iopenmeasure_amd/csrc -DPROJ_WS_LAB tools/archive/lab/proj_lab.hip \
 //         openmeasure_amd/libspr_hip.so -Wl,-rpath,$PWD/openmeasure_amd -o build/proj_lab
 #include <algorithm>
 #include <cmath>

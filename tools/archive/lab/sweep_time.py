@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Times ONE full epoch sweep (qr_epoch_sweep_kernel, all rows) and one refresh with made-up orthonormal directions, for
 A/B runs of kernel variants selected with SPR_HIP_LIBRARY (ablations give wrong norms; only the times matter).
-usage: python tools/lab/sweep_time.py [rows] [r] [directions] [f32]"""
+usage: python tools/archive/lab/sweep_time.py [rows] [r] [directions] [f32]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from openmeasure_amd.engine import HipEngine
 

@@ -2,7 +2,7 @@
 usage: placement_probe.py [rows of a random basis | c3 | c3s]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from openmeasure_amd.engine import HipEngine
 from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix

@@ -5,7 +5,7 @@ usage: python tools/pool_sweep_params.py [c3|c3s|c5s|c5|c2] [cells]
 Result of round 4 (profiles/r04_placement_pool_probe.txt): no share beats 1/16 across shapes; the defaults stayed."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 import openmeasure_amd.sparse_sensing as ss

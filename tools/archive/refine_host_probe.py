@@ -3,7 +3,7 @@
 eigh(H), M = L^1/2 Z^T D V^T, svd(M), eigvalsh of the retained block -- one BLAS thread against the default pool."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import openmeasure_amd.sparse_sensing as ss
 from scipy.linalg import lapack
 

@@ -1,7 +1,7 @@
 """fit() wall time with the device eigen-solver (spectrum.hip, no host sync) vs the host dsyevd path, by m. (GPU box)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from openmeasure_amd.engine import HipEngine
 import openmeasure_amd.sparse_sensing as ss

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from openmeasure_amd.engine import HipEngine
 eng = HipEngine()
 rng = np.random.default_rng(0)

@@ -6,7 +6,7 @@ with 1 / 4 copy threads; hipHostRegister of the caller's array in place."""
 import os, sys, time
 import numpy as np
 from concurrent.futures import ThreadPoolExecutor
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 dev = torch.device('cuda:0')

@@ -1,7 +1,7 @@
 """How long does a small pageable H2D copy take next to a nearly full HBM? (GPU box)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from openmeasure_amd.engine import HipEngine
 eng = HipEngine()

@@ -1,6 +1,6 @@
 """predict() on a wide basis (r > 128): normal-equations workspace kernel vs the SVD (pinv) workspace kernel, per call."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from openmeasure_amd.engine import HipEngine
 eng = HipEngine('cuda:0')

@@ -4,7 +4,7 @@ time drops on zeros was clock-limited by power on real data, one whose time stay
 'DVFS give-back' item 1).  Gram pass and W-stationary projection of a 45M x 256 block."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from openmeasure_amd.engine import HipEngine
 from openmeasure_amd.synth import make_R

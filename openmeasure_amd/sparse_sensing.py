@@ -813,6 +813,8 @@ class ROM:
             if isinstance(self.X, DeviceMatrix):
                 self._d['X'] = self.X.tensor
             else:
+                if self.X.ndim < 2:
+                    raise IndexError('tuple index out of range')    # what the reference's X.shape[1] raises for a 1-D X
                 if self.X.ndim != 2:
                     raise ValueError('X must be a 2-D array.')
                 # a float32 snapshot matrix stays float32 in HBM (storage only, see DeviceMatrix)

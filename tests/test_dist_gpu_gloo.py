@@ -190,3 +190,118 @@ def test_config4_shaped_shards_four_ranks_one_gpu(tmp_path):
     assert int(d['n_allreduce']) == 12 and int(d['n_gather']) == 4 and int(d['n_exposed']) == 8 and float(d['min_ms']) >= 0.0
     del Xd, one
     torch.cuda.empty_cache()
+
+
+def _p2p_edge_worker(rank, world, port, out_dir, case):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.engine import HipEngine
+        from openmeasure_amd.p2p import P2PFieldGather, P2PUnavailable
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden
+        eng = HipEngine('cuda:0')
+        res = {}
+        if case == 'fallback':
+            # one rank cannot map its peers (another node, no interprocess handles): EVERY rank must end up on the collective
+            # path, with the reason, and the results must not care
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            n_loc = n // world
+            row0 = rank * n_loc
+            if rank == world - 1:
+                real = eng.lib.spr_p2p_open
+                eng.lib.spr_p2p_open = lambda *a: -3
+            spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+            spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+            X3 = spr.reconstruct(g['Ar_pred3'] * np.sign(np.sum(spr.Ar * g['Ar'], axis=0)))
+            if rank == world - 1:
+                eng.lib.spr_p2p_open = real
+            res = dict(path=str(spr.gather_path_), X3=X3)
+            try:
+                RowShard(0, 10, gather='p2p')
+                spr2 = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None,
+                           shard=RowShard(row0, n, gather='p2p'), engine=eng)
+                spr2.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+                if rank == world - 1:
+                    eng.lib.spr_p2p_open = lambda *a: -3
+                try:
+                    spr2.reconstruct(spr2.Ar[:1])
+                    res['forced'] = 'no error'
+                except P2PUnavailable as exc:                  # asked for explicitly: every rank raises, nobody hangs
+                    res['forced'] = 'P2PUnavailable: ' + str(exc)[:60]
+            finally:
+                if rank == world - 1:
+                    eng.lib.spr_p2p_open = real
+        else:
+            # the join kernel's exit: a peer that never pushes.  Rank 0 pushes and joins with a short timeout; the kernel gives
+            # up, leaves the missing counter in the status words, check() names the peer.  Nothing hangs.
+            def all_gather(t):
+                out = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(out, t.contiguous())
+                return torch.stack(out)
+            px = P2PFieldGather(eng, world, rank, all_gather)
+            px.JOIN_TIMEOUT_S = 0.5
+            px.ensure(1, 4096)
+            out = px.begin()
+            out[:, rank * 2048:(rank + 1) * 2048] = float(rank + 1)
+            if rank == 0:
+                k = px.push(0, 2048)
+                t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+                t0.record()
+                px.join(k)
+                t1.record()
+                torch.cuda.synchronize()
+                res['join_ms'] = t0.elapsed_time(t1)
+                try:
+                    px.check()
+                    res['check'] = 'no error'
+                except RuntimeError as exc:
+                    res['check'] = str(exc)
+            dist.barrier()
+            if rank == 1:                                      # ... the late peer pushes after all: the exchange completes
+                k = px.push(2048, 2048)
+                px.join(k)
+                torch.cuda.synchronize()
+                px.check()
+                res['late'] = out.cpu().numpy()[0, ::2047].tolist()
+            dist.barrier()
+            if rank == 0:
+                px._flags[px._slot('status', 0):px._slot('status', 0) + 2] = 0
+                px.join(0)                                     # rank 1's block has arrived by now
+                torch.cuda.synchronize()
+                px.check()
+                res['late'] = out.cpu().numpy()[0, ::2047].tolist()
+            px.close()
+        np.savez(os.path.join(out_dir, f'edge{rank}.npz'), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['fallback', 'timeout'])
+def test_p2p_exchange_edges(tmp_path, case):
+    """round 5: the p2p field exchange when it cannot be had (one rank cannot map its peers -> every rank on the collective path,
+    or every rank raising when p2p was demanded) and when a peer never pushes (the join kernel's wall-clock exit + check())."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_p2p_edge_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f'edge{r}.npz') for r in range(world)]
+    if case == 'fallback':
+        from tests.conftest import load_golden
+        from tests.parity import REL_FRO, rel_fro
+        g = load_golden('g3_num8')
+        for o in outs:
+            assert str(o['path']).startswith('rccl (p2p unavailable'), o['path']
+            assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO
+            assert str(o['forced']).startswith('P2PUnavailable'), o['forced']
+    else:
+        assert 400.0 <= float(outs[0]['join_ms']) <= 5000.0, outs[0]['join_ms']       # gave up after ~0.5 s, did not hang
+        assert 'gave up waiting for the block of rank 1' in str(outs[0]['check']), outs[0]['check']
+        for o in outs:
+            assert o['late'].tolist() == [1.0, 1.0, 2.0], o['late']                   # both blocks in both copies in the end

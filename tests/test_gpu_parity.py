@@ -1777,3 +1777,40 @@ def test_project_f64_sixteen_tile_form(eng, n_points, F, m, q, f32, pre, i0):
     eng.project_f64(Xd, i0, rows, 0, n_points, F, eng.to_device(np.ones(F)), eng.to_device(W), None, out0, center=False)
     ref0 = X[i0:i0 + rows] @ W
     assert np.abs(eng.to_host(out0)[:, :q] - ref0).max() <= 1e-12 * np.abs(ref0).max()
+
+
+def test_small_downloads_by_kernel_and_ticket(eng, monkeypatch):
+    """round 5: HipEngine.to_host of small results goes through spr_download_bytes (a kernel writes into page-locked memory
+    and raises a ticket the host polls) -- every dtype / shape the path carries, the `then` hook, values equal to the copy + event
+    path, and the reusable W upload (spr_upload_bytes into a buffer that is overwritten by the next call with the same key)."""
+    import torch
+    from openmeasure_amd.engine import HipEngine
+    rng = np.random.default_rng(3)
+    cases = [rng.standard_normal((64, 64)), rng.standard_normal(7), rng.integers(-5, 5, size=(3, 5, 2)).astype(np.int64),
+             rng.standard_normal((130, 2)).astype(np.float32), rng.integers(0, 255, size=(16,)).astype(np.uint8),
+             rng.standard_normal((512, 256))]                                  # 1 MiB: the largest the kernel path takes
+    assert eng._dl_kernel
+    called = []
+    for a in cases:
+        t = torch.as_tensor(a).to(eng.device)
+        got = eng.to_host(t, then=lambda: called.append(1))
+        assert got.dtype == a.dtype and got.shape == a.shape
+        np.testing.assert_array_equal(got, a)
+        got[...] = 0                                                           # a fresh array every time, not the staging buffer
+        np.testing.assert_array_equal(eng.to_host(t), a)
+    assert len(called) == len(cases) and eng._dl['seq'] >= 2 * len(cases)
+    # a strided view and an odd byte count take the other path and still come back right
+    t = torch.as_tensor(cases[0]).to(eng.device)
+    np.testing.assert_array_equal(eng.to_host(t[:, ::2]), cases[0][:, ::2])
+    np.testing.assert_array_equal(eng.to_host(torch.arange(5, dtype=torch.uint8, device=eng.device)), np.arange(5, dtype=np.uint8))
+    other = HipEngine('cuda:0')
+    other._dl_kernel = False
+    for a in cases[:3]:
+        np.testing.assert_array_equal(other.to_host(torch.as_tensor(a).to(eng.device)), a)
+    W1, W2 = rng.standard_normal((64, 32)), rng.standard_normal((64, 32))
+    d1 = eng.upload_reuse(('W', 1), W1)
+    np.testing.assert_array_equal(eng.to_host(d1), W1)
+    d2 = eng.upload_reuse(('W', 1), W2)
+    assert d2.data_ptr() == d1.data_ptr()                                      # the same device buffer, new contents
+    np.testing.assert_array_equal(eng.to_host(d2), W2)
+    np.testing.assert_array_equal(eng.to_host(eng.upload_reuse(('W', 1), W1[:10])), W1[:10])   # another shape: a new buffer

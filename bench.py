@@ -302,6 +302,11 @@ def parse_args(argv=None):
                     help='developer aid, with --share-of: the p2p field exchange with L imaginary peers inside this GPU (the '
                          "rank issues the L pushes of its block an (L+1)-rank exchange would, both ends in its own HBM); the "
                          'line says so')
+    ap.add_argument('--defer-reconstruct', action='store_true',
+                    help="switch ROM.defer_reconstruct on (opt-in): the step's reconstruct kernel -- and, sharded, the push of its "
+                         "block -- is enqueued in the host gap of the NEXT step's fit() instead of behind this step's projection; "
+                         'every step still runs inside the timed region (the last one is flushed before the closing barrier); the '
+                         'line says so')
     ap.add_argument('--gap-filler', action='store_true',
                     help='switch ROM.gap_filler on (opt-in: fit() re-queues its Gram kernel on part of X into the host gap to '
                          'hold the clock; the line then says so and counts the rows)')
@@ -410,6 +415,8 @@ def run_rank(args):
         spr.placement_norms = args.placement_norms == 'on'
     if args.gap_filler:
         spr.gap_filler = True
+    if args.defer_reconstruct:
+        spr.defer_reconstruct = True
     wd = Watchdog(float(os.environ.get('SPR_BENCH_WATCHDOG_S', '300')), rank,
                   lambda: dict(collective_brackets={k: len(v) for k, v in (spr.comm_timing or {}).items()},
                                last_collective=getattr(spr, 'last_comm_', None), gather_path=getattr(spr, 'gather_path_', None)))
@@ -549,14 +556,31 @@ def run_rank(args):
     x_bytes = float(n_job) * m * B
     value = x_bytes / (dt / args.steps) / 1e9
 
-    k_ms = {k: float(np.mean([tm[i][0].elapsed_time(tm[i][1]) for tm in timers]))
+    def ev_ms(a, b):
+        try:
+            return a.elapsed_time(b)
+        except (RuntimeError, ValueError):            # a pair that never got its launch (deferred reconstruct: the last step's)
+            return None
+
+    def mean_ms(vals):
+        vals = [v for v in vals if v is not None]
+        return float(np.mean(vals)) if vals else float('nan')
+
+    k_ms = {k: mean_ms([ev_ms(tm[i][0], tm[i][1]) for tm in timers])
             for i, k in enumerate(('stats_gram', 'project', 'reconstruct'))}
     # what lies BETWEEN the three kernels on the compute stream (same events): the host gap of fit() (download, eigen-solve,
     # upload), the join / release of the field exchange in front of reconstruct, and reconstruct -> the next step's Gram pass
-    gaps_ms = dict(gram_to_project=float(np.mean([tm[0][1].elapsed_time(tm[1][0]) for tm in timers])),
-                   project_to_reconstruct=float(np.mean([tm[1][1].elapsed_time(tm[2][0]) for tm in timers])),
-                   reconstruct_to_next_gram=(float(np.mean([a[2][1].elapsed_time(b[0][0]) for a, b in zip(timers, timers[1:])]))
-                                             if len(timers) > 1 else None))
+    if args.defer_reconstruct and not args.sync_gather:
+        # the reconstruct kernel of step k sits between the Gram kernel and the projection of step k + 1 (its event pair is the
+        # one armed in step k + 1)
+        gaps_ms = dict(gram_to_reconstruct=mean_ms([ev_ms(tm[0][1], tm[2][0]) for tm in timers[1:]]),
+                       reconstruct_to_project=mean_ms([ev_ms(tm[2][1], tm[1][0]) for tm in timers[1:]]),
+                       gram_to_project=mean_ms([ev_ms(tm[0][1], tm[1][0]) for tm in timers]),
+                       project_to_next_gram=mean_ms([ev_ms(a[1][1], b[0][0]) for a, b in zip(timers, timers[1:])]))
+    else:
+        gaps_ms = dict(gram_to_project=mean_ms([ev_ms(tm[0][1], tm[1][0]) for tm in timers]),
+                       project_to_reconstruct=mean_ms([ev_ms(tm[1][1], tm[2][0]) for tm in timers]),
+                       reconstruct_to_next_gram=mean_ms([ev_ms(a[2][1], b[0][0]) for a, b in zip(timers, timers[1:])]))
     r = spr.r
     # per-launch algorithmic work of each kernel on THIS rank's shard
     alg = {
@@ -827,7 +851,10 @@ def run_rank(args):
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
         }
         out['rank_timeline_ms'] = {k_: (None if v != v else round(v, 4)) for k_, v in mine.items()}
-        out['gaps_ms'] = {k_: (None if v is None else round(v, 4)) for k_, v in gaps_ms.items()}
+        out['gaps_ms'] = {k_: (None if (v is None or v != v) else round(v, 4)) for k_, v in gaps_ms.items()}
+        out['reconstruct_launch'] = ("deferred (--defer-reconstruct): step k's reconstruct kernel is enqueued in the host gap of step "
+                                     "k + 1's fit(); the last one is flushed inside the timed region" if args.defer_reconstruct
+                                     else "behind the step's own projection")
         out['compute_stream'] = 'own (non-default) stream' if own_stream else 'default stream'
         out['hw_queues'] = os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)')
         out['gap_filler'] = dict(on=bool(spr.gap_filler), rows_per_fit=(int(np.mean(fill_rows)) if fill_rows else 0),

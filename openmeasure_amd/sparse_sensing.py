@@ -270,29 +270,63 @@ class OneHotRows:
 
 class PendingField:
     """Result of ``reconstruct(..., to_host=False, wait=False)``: the (n_p, n) field in HBM whose exchange between the
-    ranks may still be in flight (RCCL's all-gather on its communication stream, or the SDMA pushes of the p2p path).
-    ``wait()`` makes the current stream wait for it and returns the tensor; nothing else may read the tensor before that.
+    ranks may still be in flight (RCCL's all-gather on its communication stream, or the SDMA pushes of the p2p path) -- or,
+    with ``ROM.defer_reconstruct``, whose kernel has not even been launched yet (``launch``: it runs in the host gap of the
+    object's next fit(), or here).  ``wait()`` makes the current stream wait for it and returns the tensor; nothing else may
+    read the tensor before that.
     ``needs_cus``: the exchange runs a device kernel (RCCL) and competes with the caller's kernels for compute units."""
 
-    def __init__(self, tensor, works=(), keep=(), on_wait=None, join=None, needs_cus=True):
+    def __init__(self, tensor, works=(), keep=(), on_wait=None, join=None, needs_cus=True, launch=None, shape=None):
         self._tensor = tensor
         self._works = list(works)
         self._join = join                      # p2p path: enqueues the stream waits on the arrival counters
         self._keep = keep                      # the gather's source buffers stay alive until it has been joined
         self._on_wait = on_wait                # ROM.comm_timing: brackets the join with two stream events
-        self.needs_cus = bool(needs_cus) and (bool(self._works) or join is not None)
+        self._launch = launch                  # deferred: () -> tensor or PendingField
+        self._inner = None
+        self._shape = tuple(shape) if shape is not None else None
+        self._needs_cus = bool(needs_cus)
+
+    @property
+    def needs_cus(self):
+        if self._inner is not None:
+            return self._inner.needs_cus
+        return self._needs_cus and (bool(self._works) or self._join is not None)
 
     @property
     def shape(self):
-        return tuple(self._tensor.shape)
+        return self._shape if self._tensor is None else tuple(self._tensor.shape)
+
+    @property
+    def launched(self):
+        return self._launch is None
 
     @property
     def pending(self):
-        """True while the exchange has not been joined."""
+        """True while the field has not been launched or its exchange has not been joined."""
+        if self._launch is not None:
+            return True
+        if self._inner is not None:
+            return self._inner.pending
         return bool(self._works) or self._join is not None
 
+    def launch(self):
+        """Enqueue a deferred reconstruct now (no-op otherwise)."""
+        fn, self._launch = self._launch, None
+        if fn is not None:
+            res = fn()
+            if isinstance(res, PendingField):
+                self._inner = res
+            else:
+                self._tensor = res
+
     def wait(self):
-        done = self._on_wait() if (self.pending and self._on_wait is not None) else None
+        self.launch()
+        if self._inner is not None:
+            self._tensor = self._inner.wait()
+            self._inner = None
+            return self._tensor
+        done = self._on_wait() if ((self._works or self._join is not None) and self._on_wait is not None) else None
         for w in self._works:
             w.wait()
         if self._join is not None:
@@ -613,7 +647,7 @@ class _DeviceState(dict):
 
 #: attributes that never travel in a pickle: the engine, device state (downloaded instead), events, in-flight work
 _TRANSIENT = ('_eng', '_d', '_trace', '_pending', '_pending_field', '_gram_events', '_gram_events_pending', '_layout_src',
-              '_gap_t0', '_G', '_last_decomp', 'comm_timing', 'last_comm_', '_layout', '_p2p', '_gather_sel', '_basis_checked', '_basis_diverged')
+              '_gap_t0', '_G', '_last_decomp', 'comm_timing', 'last_comm_', '_layout', '_p2p', '_gather_sel', '_basis_checked', '_basis_diverged', '_deferred', '_row0_d')
 
 
 class ROM:
@@ -662,6 +696,7 @@ class ROM:
         lives in HBM downloaded first (a DeviceMatrix becomes the host ndarray of its values; the basis comes down whole: a
         pickle of a fitted config-3 object is 230 GB, as the reference's would be).  The engine, events and in-flight
         work stay behind; a process group cannot travel either (the shard keeps its row block, group = default)."""
+        self._flush_deferred()
         self._materialize()
         pf = self.__dict__.get('_pending_field')
         if pf is not None and pf.pending:
@@ -715,6 +750,24 @@ class ROM:
     #: ones leave no clock drop worth filling).  Sharded objects size it from their own host-gap history: ranks with different
     #: histories queue fillers of different length in front of their projections (unmeasured on more than one GPU).
     gap_filler = False
+
+    #: Deferred reconstruct (OPT-IN).  Between the Gram pass and the projection of fit() the device idles while the host
+    #: eigen-solves (0.3 ms of a 1.5 ms step at BASELINE config 2, 1.8 ms of 22 on one rank's block of config 4 at N = 8).  With
+    #: this on, ``reconstruct(a, to_host=False, wait=False)`` -- the asynchronous form, which promises the field only behind
+    #: ``PendingField.wait()`` -- does not launch: the kernel (and, sharded, the push of the block to the peers) is enqueued
+    #: in the host gap of the object's NEXT fit(), before that fit's projection overwrites the basis (the launch works on the
+    #: basis, centre and scale of the fit it was called after), or by ``wait()`` / any other method of the object,
+    #: whichever comes first.  Same results; a loop fit -> reconstruct -> fit -> ... fills its gaps with useful work instead of
+    #: discarded work (gap_filler).  bench.py --defer-reconstruct.
+    defer_reconstruct = False
+
+    def _flush_deferred(self):
+        """Launch the reconstruct a previous reconstruct(wait=False) deferred (defer_reconstruct); -> True if there was one"""
+        pf = self.__dict__.pop('_deferred', None)
+        if pf is not None and not pf.launched:
+            pf.launch()
+            return True
+        return False
     _GAP_FILL_FRACTION = 0.85
     _GAP_FILL_MIN_M = 128
     #: ... and only when the host gap is long enough for the clock to matter: behind a 2.8 ms gap the filler took 0.7 ms off a
@@ -898,6 +951,7 @@ class ROM:
     def Ur(self, value):
         # subclasses written against the reference assign the result of decomposition() (gpr.py:386):
         # that array already has its device twin; anything else is uploaded
+        self._flush_deferred()
         self._d.pop('nrm0', None)                             # row norms of the basis fit() stored, not of this one
         last = self.__dict__.get('_last_decomp')
         if last is not None and value is last[0]:
@@ -1137,12 +1191,17 @@ class ROM:
             # statistics merge, feature scales and G = sum_f G_f / scl_f^2 on the device (csrc/combine.hip): one
             # download of m^2 + 5F doubles, the scales never leave HBM
             packed_d, scale_d, inv_d = eng.gram_combine(gram, fs_d, scale_type)
-            if self._filler_wanted(Xd) and getattr(self, '_fit_fills_gap', False):
-                packed = eng.to_host(packed_d, then=lambda: self._queue_gap_filler(Xd))
+            fill = self._filler_wanted(Xd) and getattr(self, '_fit_fills_gap', False)
+
+            def gap_hook():
+                # the download is enqueued, the host is about to block on it: what goes into the gap behind it -- a
+                # reconstruct the caller deferred (useful work), else the filler (discarded work, opt-in)
+                if not self._flush_deferred() and fill:
+                    self._queue_gap_filler(Xd)
+            packed = eng.to_host(packed_d, then=gap_hook)
+            if fill:
                 import time
                 self._gap_t0 = time.perf_counter()
-            else:
-                packed = eng.to_host(packed_d)
             tr_.mark('collect')
             feat = packed[m * m:].reshape(F, 5)
             self._G = packed[:m * m].reshape(m, m)
@@ -1158,7 +1217,7 @@ class ROM:
             tr_.mark('merge')
             return
         # one download for both: every host round trip is a sync point the GPU idles at
-        packed = eng.to_host(eng.torch.cat([gram.reshape(-1), fs_d.reshape(-1)]))
+        packed = eng.to_host(eng.torch.cat([gram.reshape(-1), fs_d.reshape(-1)]), then=self._flush_deferred)
         G_f = packed[:gram.numel()].reshape(F, m, m)
         fs = packed[gram.numel():].reshape(fs_d.shape[0], F, 3)
         tr_.mark('collect')
@@ -1230,6 +1289,7 @@ class ROM:
 
     def scale_data(self, scale_type='std', axis_cnt=1):
         """Reference :83-171.  Sets X_cnt / X_scl and returns the scaled matrix X0."""
+        self._flush_deferred()
         self._check_scaling(scale_type, axis_cnt)
         self._stats_pass(scale_type, axis_cnt)
         return self.X0
@@ -1285,6 +1345,7 @@ class ROM:
     def unscale_data(self, x0, sampling=None):
         """Reference :212-240: x = X_scl * x0 + X_cnt for an (n_local,) vector, or with ``sampling`` (s, n)
         x = (S X_scl) * x0 + S X_cnt for an (s,) vector."""
+        self._flush_deferred()
         if type(x0) is not np.ndarray:
             raise NotImplementedError('unscale_data of a cvxpy expression is outside the device path.')
         eng = self._engine()
@@ -1537,6 +1598,7 @@ class ROM:
         nrm0 = self._norms_buffer(Xd, r, self.precentered_ and center)
         kw = {} if nrm0 is None else {'norms': nrm0}
         self._close_gap()
+        self._flush_deferred()                                # (normally done in the gap already: see _merge_stats)
         Ur_d = eng.project(Xd, self._row0, self.n_points, self.n_features, inv_scale_d, W_d,
                            center=center, out=self._d.pop('Ur', None), rowmean=self._d.get('rowmean'),
                            basis_dtype=self._basis_dtype(), precenter=self.precentered_, **kw)
@@ -1551,6 +1613,7 @@ class ROM:
         Returns (Ur, Ar, exp_variance[:r]) as host arrays.  When X0 is the very array scale_data() returned
         (the pattern of GPR.fit, gpr.py:379-381) the Gram blocks of that pass and the resident X are used instead
         of uploading X0 and reading it twice."""
+        self._flush_deferred()
         eng = self._engine()
         if X0 is self._host.get('X0') and '_G' in self.__dict__ and 'rowmean' in self._d:
             G = self._G
@@ -1606,6 +1669,7 @@ class ROM:
             self.exp_variance_ = expv
             self.S_ = S
         else:
+            self._flush_deferred()
             Ur_d = eng.to_device(basis[0])
             Ar = np.asarray(basis[1])
             V_r = None
@@ -1651,6 +1715,7 @@ class ROM:
         self._d['inv_scale'] = sp['inv_scale']
         nrm0 = self._norms_buffer(Xd, r)
         kw = {} if nrm0 is None else {'norms': nrm0}
+        self._flush_deferred()
         self._d['Ur'] = eng.project(Xd, self._row0, self.n_points, F, sp['inv_scale'], sp['W'], center=True,
                                     out=self._d.pop('Ur', None), rowmean=rowmean, basis_dtype=self._basis_dtype(), **kw)
         if nrm0 is not None:
@@ -1692,6 +1757,7 @@ class ROM:
         runs on the communication stream under whatever the caller launches next -- e.g. the MFMA-bound Gram
         pass of the next fit(); call ``.wait()`` before reading it."""
         eng = self._engine()
+        self._flush_deferred()                                # an earlier deferred launch keeps its place in the order
         Ar = np.asarray(Ar, dtype=np.float64) if not hasattr(Ar, 'is_cuda') else Ar
         if Ar.ndim < 2:
             Ar = Ar[None, :]
@@ -1710,6 +1776,26 @@ class ROM:
         n_loc = Ur_d.shape[0]
         n_p = A_d.shape[0]
         world = self._world()
+        if self.defer_reconstruct and not to_host and not wait and not self.__dict__.get('_in_deferred', False):
+            # defer_reconstruct: record the launch instead -- on the basis, centre and scale this object holds NOW
+            state = {k: self._d[k] for k in ('Ur', 'rowmean', 'scale')}
+
+            def launch():
+                now = {k: dict.get(self._d, k) for k in state}       # what the object holds by then (a newer fit's, possibly)
+                self._d.update(state)
+                self._in_deferred = True
+                try:
+                    return self.reconstruct(A_d, to_host=False, wait=False)
+                finally:
+                    self._in_deferred = False
+                    for k, v in now.items():
+                        if v is None:
+                            dict.pop(self._d, k, None)
+                        else:
+                            self._d[k] = v
+            total = int(self._shard_layout(n_loc)[:, 1].sum()) if self._dist() else n_loc
+            pf = self._deferred = PendingField(None, launch=launch, shape=(n_p, total), needs_cus=False)
+            return pf
         if not self._dist():
             if to_host and hasattr(eng, 'reconstruct_to_host'):
                 # the reference's contract (:371-375): a host ndarray.  Big fields go out in row chunks whose copies run
@@ -1804,6 +1890,7 @@ class ROM:
     def use_gather(self, path):
         """Switch the field exchange of later reconstruct() calls ('auto' | 'p2p' | 'rccl'; COLLECTIVE like the calls
         themselves: every rank must switch at the same point).  A pending field is joined first."""
+        self._flush_deferred()
         if path not in ('auto', 'p2p', 'rccl'):
             raise ValueError("path must be 'auto', 'p2p' or 'rccl'")
         pf = self.__dict__.get('_pending_field')
@@ -1898,6 +1985,7 @@ class SPR(ROM):
         """Reference :700-756.  Returns the one-hot measurement matrix C of shape (s, n): the reference's dense ndarray
         while it is small (64 MiB), a OneHotRows above that (46 GB dense at BASELINE config 3) -- same behaviour for
         C[i, :], C @ x, np.argmax(C, axis=1), train(C).  The ordered global sensor rows are also in ``self.sensors_``."""
+        self._flush_deferred()
         if calc_type == 'gem':
             return self._placement_gem(n_sensors, mask, d_min, verbose)
         if calc_type != 'qr':
@@ -1952,6 +2040,7 @@ class SPR(ROM):
         a column of Ur changes sign, and LAPACK's singular-vector signs are arbitrary (fit() here fixes them by its own
         rule, _sign_fix): after a plain fit() the sensors coincide with the reference's only if the bases coincide --
         fit(basis=(Ur_ref, Ar_ref)) -- not merely up to column signs."""
+        self._flush_deferred()
         fitted = self._host.get('Ur')
         if Ur is fitted and 'Ur' in self._d:
             self._placement_gem(n_sensors, mask, d_min, verbose)
@@ -2163,6 +2252,7 @@ class SPR(ROM):
     # ------------------------------------------------------------------ a7 train
     def train(self, C, is_Theta=False, limits=None, method='OLS', solver='CLARABEL', cond=False, verbose=False):
         """Reference :758-820."""
+        self._flush_deferred()
         n = self._n_global
         if (C.shape[1] != n) and not is_Theta:
             raise ValueError('The number of columns of C does not match the number'

@@ -418,3 +418,43 @@ def run_documented_idioms(g, engine, monkeypatch):
         np.testing.assert_array_equal(a, b)
     assert rel_fro(outs[1][4][:, 0], x_test) < 0.1 or r < 4          # a sane reconstruction, not only equal ones
     return outs[1]
+
+
+def run_deferred_reconstruct(eng):
+    """ROM.defer_reconstruct (round 5, opt-in): reconstruct(wait=False) records its launch; the object's next fit() enqueues
+    it in its host gap -- on the basis, centre and scale of the fit it was called AFTER, before the new projection overwrites
+    them -- or wait() / any other method does.  Same values as the immediate form."""
+    from openmeasure_amd.sparse_sensing import SPR
+
+    def _np(t):
+        return t.detach().cpu().numpy()
+    rng = np.random.default_rng(8)
+    n_points, F, m = 150, 2, 12
+    X = rng.standard_normal((n_points * F, 5)) @ rng.standard_normal((5, m)) + 0.01 * rng.standard_normal((n_points * F, m))
+    launches = []
+    real = eng.reconstruct
+    eng.reconstruct = lambda *a, **k: (launches.append(a[0].shape), real(*a, **k))[1]
+    spr = SPR(X, F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=3)
+    a3 = spr.Ar[:2].copy()
+    want3 = spr.reconstruct(a3)                                  # immediate, host contract
+    assert len(launches) == 1
+    spr.defer_reconstruct = True
+    pf = spr.reconstruct(a3, to_host=False, wait=False)
+    assert pf.pending and not pf.launched and pf.shape == (2, n_points * F) and len(launches) == 1     # nothing enqueued yet
+    spr.fit(select_modes='number', n_modes=5)                    # another basis (5 columns): the deferred launch precedes it
+    assert pf.launched and len(launches) == 2 and launches[1] == (n_points * F, 3)
+    np.testing.assert_array_equal(_np(pf.wait()).T, want3)
+    assert spr.r == 5 and spr.Ur.shape == (n_points * F, 5)
+    # wait() launches what no fit() has launched; to_host / wait=True never defer; other methods flush first
+    pf2 = spr.reconstruct(spr.Ar[:1], to_host=False, wait=False)
+    want5 = spr.reconstruct(spr.Ar[:1])                          # flushes pf2 first (order kept), then runs itself
+    assert pf2.launched and len(launches) == 4
+    np.testing.assert_array_equal(_np(pf2.wait()).T, want5)
+    pf3 = spr.reconstruct(spr.Ar[:1], to_host=False, wait=False)
+    spr.optimal_placement()
+    assert pf3.launched
+    pf4 = spr.reconstruct(spr.Ar[:1], to_host=False, wait=False)
+    assert not pf4.launched
+    np.testing.assert_array_equal(_np(pf4.wait()).T, want5)
+    assert isinstance(spr.reconstruct(spr.Ar[:1], to_host=False, wait=True), type(pf4.wait()))

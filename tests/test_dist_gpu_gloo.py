@@ -69,6 +69,19 @@ def _worker(rank, world, port, fixture, out_dir, uneven=False):
             assert prev.pending and not prev.needs_cus
         np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[-1])
         np.testing.assert_array_equal(spr.reconstruct(A3), X3)             # ... and with the host contract
+        # the same loop with the launches deferred into the next fit()'s host gap (ROM.defer_reconstruct): kernel + push of step
+        # k are enqueued inside fit k + 1, the last one by wait()
+        spr.defer_reconstruct = True
+        prev = None
+        for it, A in enumerate(As[:4]):
+            spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'], n_modes=g['n_modes'])
+            if prev is not None:
+                assert prev.launched
+                np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[it - 1])
+            prev = spr.reconstruct(A, to_host=False, wait=False)
+            assert not prev.launched
+        np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[3])
+        spr.defer_reconstruct = False
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, Sigma=spr.Sigma_r, X3=X3, A3=A3, Ar=spr.Ar,
                  passes=spr.gram_refine_passes_)
     finally:

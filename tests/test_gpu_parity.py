@@ -1814,3 +1814,10 @@ def test_small_downloads_by_kernel_and_ticket(eng, monkeypatch):
     assert d2.data_ptr() == d1.data_ptr()                                      # the same device buffer, new contents
     np.testing.assert_array_equal(eng.to_host(d2), W2)
     np.testing.assert_array_equal(eng.to_host(eng.upload_reuse(('W', 1), W1[:10])), W1[:10])   # another shape: a new buffer
+
+
+def test_deferred_reconstruct_on_the_device(eng):
+    """ROM.defer_reconstruct on the HIP engine: the launch recorded by reconstruct(wait=False) is enqueued in the next fit()'s
+    host gap (behind the Gram download, before the projection overwrites the basis) with the basis it was called after."""
+    from tests.parity import run_deferred_reconstruct
+    run_deferred_reconstruct(eng)

@@ -319,6 +319,11 @@ def test_gem_depends_on_the_signs_of_the_basis_and_prints_the_reference_table(ca
     assert all(float(a[3]) != float(b[3]) for a, b in zip(rows[1:], rows[2:]))    # entropy accumulates
 
 
+def test_deferred_reconstruct_runs_in_the_next_fits_gap():
+    from tests.parity import run_deferred_reconstruct
+    run_deferred_reconstruct(NumpyEngine())
+
+
 def test_decomposition_public(small):
     X, F, xyz = small
     rom = ROM(X, F, xyz, engine=NumpyEngine())

@@ -1510,7 +1510,15 @@ class ROM:
         eng = self._engine()
         n_loc, m = Xd.shape
         eps = np.finfo(float).eps
-        block = int(max(1 << 16, min(n_loc, (1 << 31) // (8 * (m + (m & 1))))))
+        # row blocks of the f64 scratch matrix Y: up to 8 GiB (a quarter of what is free), so that a pass over 9M rows is 3
+        # projection + Gram launch pairs instead of 9 (each pair has its ramp and tail)
+        budget = 1 << 31
+        try:
+            free = eng.torch.cuda.mem_get_info(eng.device)[0] if hasattr(eng, 'device') and eng.device.type == 'cuda' else 0
+            budget = int(min(8 << 30, max(1 << 31, free // 4)))
+        except (RuntimeError, AttributeError):
+            pass
+        block = int(max(1 << 16, min(n_loc, budget // (8 * (m + (m & 1))))))
         Y = eng.empty((min(block, n_loc), m + (m & 1)))
         passes = 0
         import time
@@ -1533,10 +1541,19 @@ class ROM:
             H = eng.to_host(self._all_reduce(H_d))
             t_b = time.perf_counter()
             H = 0.5 * (H + H.T)
-            lamH, Z = _eigh_small(H)
-            t_c = time.perf_counter()
+            # X0 = Q M with Q orthonormal: from the Cholesky factor H = R^T R (Q = Y R^-1, M = R diag(d) V^T: 0.3 ms at
+            # m = 256 against 2.7 ms for the eigen-decomposition H = Z L Z^T, M = L^1/2 Z^T diag(d) V^T, which remains the
+            # route when H is not numerically positive definite -- a first stage too far off, the null mode of a full-rank fit)
             with _one_blas_thread():                           # m x m: a many-core BLAS pool only gets in the way
-                M = (np.sqrt(np.maximum(lamH, 0.0))[:, None] * Z.T) * d[None, :] @ V.T
+                from scipy.linalg import lapack
+                Rc, info = lapack.dpotrf(H, lower=0, clean=1)
+                if info == 0 and np.all(np.isfinite(Rc)) and Rc.diagonal().min() > 1e-7 * Rc.diagonal().max():
+                    t_c = time.perf_counter()
+                    M = (Rc * d[None, :]) @ V.T
+                else:
+                    lamH, Z = _eigh_small(H)
+                    t_c = time.perf_counter()
+                    M = (np.sqrt(np.maximum(lamH, 0.0))[:, None] * Z.T) * d[None, :] @ V.T
                 t_d = time.perf_counter()
                 _, S_new, Vt = np.linalg.svd(M)
             t_e = time.perf_counter()

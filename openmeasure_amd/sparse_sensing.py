@@ -1904,6 +1904,20 @@ class ROM:
         self.gather_path_ = why
         return sel
 
+    def close(self):
+        """Give back what a sharded object holds outside PyTorch's allocator: the persistent copy of the field and the counter
+        page of the p2p exchange, mapped by the peers (COLLECTIVE: every rank calls it; the ranks meet between unmapping and
+        freeing).  The object can be used again afterwards (the buffers are set up anew).  Without it they live until the process
+        ends -- an interprocess mapping cannot be torn down from a finaliser."""
+        self._flush_deferred()
+        pf = self.__dict__.get('_pending_field')
+        if pf is not None and pf.pending:
+            pf.wait()
+        px = self.__dict__.pop('_p2p', None)
+        if px is not None:
+            px.close()
+        self.__dict__.pop('_gather_sel', None)
+
     def use_gather(self, path):
         """Switch the field exchange of later reconstruct() calls ('auto' | 'p2p' | 'rccl'; COLLECTIVE like the calls
         themselves: every rank must switch at the same point).  A pending field is joined first."""

@@ -82,6 +82,10 @@ def _worker(rank, world, port, fixture, out_dir, uneven=False):
             assert not prev.launched
         np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[3])
         spr.defer_reconstruct = False
+        spr.close()                                                        # collective: unmap, meet, free
+        assert '_p2p' not in spr.__dict__
+        np.testing.assert_array_equal(spr.reconstruct(A3), X3)             # ... and the exchange is set up anew on demand
+        assert spr.gather_path_.startswith('p2p')
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, Sigma=spr.Sigma_r, X3=X3, A3=A3, Ar=spr.Ar,
                  passes=spr.gram_refine_passes_)
     finally:

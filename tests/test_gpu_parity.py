@@ -1709,6 +1709,7 @@ def test_pinned_result_budget(eng, monkeypatch):
     import torch
     t = torch.arange(10_000_000, dtype=torch.float64, device='cuda')          # 80 MB
     monkeypatch.setenv('SPR_PINNED_RESULT_GB', '0.1')
+    eng.__dict__.pop('_pinned_budget', None)                                  # (the variable is read once per engine)
     a = eng.to_host(t)
     assert len([1 for w, _ in eng._pinned_live if w() is not None]) >= 1
     b = eng.to_host(t)                                                        # 160 MB alive > 0.1 GiB: pageable
@@ -1719,10 +1720,12 @@ def test_pinned_result_budget(eng, monkeypatch):
     assert len([1 for w, _ in eng._pinned_live if w() is not None]) == n_live
     np.testing.assert_array_equal(b, c)
     monkeypatch.setenv('SPR_PINNED_RESULT_GB', '0')
+    eng.__dict__.pop('_pinned_budget', None)
     before = len(eng._pinned_live)
     d = eng.to_host(t)
     assert len([1 for w, _ in eng._pinned_live if w() is not None]) <= before
     np.testing.assert_array_equal(d, c)
+    eng.__dict__.pop('_pinned_budget', None)                                  # the next to_host() reads the restored environment
 
 
 def test_big_attributes_stream_to_the_host(eng, monkeypatch):
@@ -1730,10 +1733,18 @@ def test_big_attributes_stream_to_the_host(eng, monkeypatch):
     materialised next to X in HBM: staged D2H through two pinned buffers, X0 by row blocks -- same values as the one-shot paths."""
     import torch
     from openmeasure_amd.sparse_sensing import SPR
+    try:
+        _big_attributes_body(eng, monkeypatch, torch, SPR)
+    finally:
+        eng.__dict__.pop('_pinned_budget', None)                               # later tests read the restored environment
+
+
+def _big_attributes_body(eng, monkeypatch, torch, SPR):
     t = torch.randn((3_000_017, 7), dtype=torch.float64, device='cuda')       # 168 MB, ragged against the 64 MiB chunks
     ref = t.cpu().numpy()
     np.testing.assert_array_equal(eng._to_host_staged(t), ref)
     monkeypatch.setenv('SPR_PINNED_RESULT_GB', '0')                            # beyond the budget: to_host() takes the staged path
+    eng.__dict__.pop('_pinned_budget', None)
     np.testing.assert_array_equal(eng.to_host(t), ref)
     t32 = t[:1_000_003].float()
     np.testing.assert_array_equal(eng._to_host_staged(t32), t32.cpu().numpy())

@@ -96,6 +96,13 @@ int spr_download_bytes(void *h_pinned_dst, const void *d_src, int64_t n_bytes, v
  * the two passes of fit() -- the reference's np.linalg.svd call site (sparse_sensing.py:272), of which :336 keeps r vectors. */
 int spr_host_tridiag_vectors(const double *h_d, const double *h_e, int32_t m, const double *h_lam, int32_t r, double *h_Z,
                              int32_t iterations);
+/* ... and the whole route in one host call: h_G (m x m, symmetric) -> h_lam[m] (all eigenvalues, DESCENDING) and h_V (m x r
+ * row-major: the unit eigenvectors of the r largest, column j belonging to h_lam[j]).  fn_dsytrd / fn_dsterf / fn_dormtr: the
+ * addresses of the caller's LAPACK routines with the Fortran calling convention without hidden string lengths, as SciPy exports
+ * them (scipy.linalg.cython_lapack.__pyx_capi__) -- this library links no LAPACK.  Returns 0; 1 when LAPACK reports a failure;
+ * 2 when the vectors miss their orthonormality checks (close eigenvalues): the caller then takes dstein / dsyevd.  < 0: SPR_E_*. */
+int spr_host_eig_top(const double *h_G, int32_t m, int32_t r, double *h_lam, double *h_V, void *fn_dsytrd, void *fn_dsterf,
+                     void *fn_dormtr);
 
 /* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
  * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised

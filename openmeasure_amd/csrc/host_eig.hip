@@ -170,3 +170,89 @@ extern "C" int spr_host_tridiag_vectors(const double *h_d, const double *h_e, in
   free(work);
   return SPR_OK;
 }
+
+
+// ---- the whole top-r route in ONE host call ---------------------------------------------------------------------------------
+// fit()'s host gap at small m is mostly call overhead around four short LAPACK routines (m = 64, r = 32: dsytrd 33 us, dsterf 24,
+// the batched vectors 27, the back-transformation 18 -- and 140-207 us once Python has glued them together, against 173 us for
+// dsyevd; tools/eigvec_pieces_probe.py).  The caller hands over the addresses of its LAPACK's dsytrd / dsterf / dormtr (SciPy
+// exports them as C function pointers, scipy.linalg.cython_lapack.__pyx_capi__: the library itself links no LAPACK) and gets
+// all eigenvalues and the r leading eigenvectors back.  Same checks as the Python route (_eigvecs_top): orthonormality of the
+// tridiagonal vectors to 1e-8 (then one symmetric correction), of the result to 1e-12; status 2 tells the caller to take
+// dstein / dsyevd instead.
+namespace {
+typedef void (*dsytrd_fn)(char *, int *, double *, int *, double *, double *, double *, double *, int *, int *);
+typedef void (*dsterf_fn)(int *, double *, double *, int *);
+typedef void (*dormtr_fn)(char *, char *, char *, int *, int *, double *, int *, double *, double *, int *, double *, int *, int *);
+
+// max |A^T A - I| for the m x r row-major A; optionally E = A^T A - I (r x r)
+SPR_HOST_CLONES double gram_defect(const double *A, int m, int r, double *E) {
+  for (int i = 0; i < r * r; ++i) E[i] = 0.0;
+  for (int k = 0; k < m; ++k) {
+    const double *ak = A + (size_t)k * r;
+    for (int i = 0; i < r; ++i) {
+      const double aki = ak[i];
+      double *ei = E + (size_t)i * r;
+#pragma clang loop vectorize(enable)
+      for (int j = 0; j < r; ++j) ei[j] += aki * ak[j];
+    }
+  }
+  double worst = 0.0;
+  for (int i = 0; i < r; ++i) {
+    E[(size_t)i * r + i] -= 1.0;
+    for (int j = 0; j < r; ++j) {
+      const double v = fabs(E[(size_t)i * r + j]);
+      if (!(v <= worst)) worst = v;          // NaN-propagating maximum
+    }
+  }
+  return worst;
+}
+}  // namespace
+
+extern "C" int spr_host_eig_top(const double *h_G, int32_t m, int32_t r, double *h_lam, double *h_V, void *fn_dsytrd,
+                                void *fn_dsterf, void *fn_dormtr) {
+  SPR_REQUIRE(h_G && h_lam && h_V && fn_dsytrd && fn_dsterf && fn_dormtr, SPR_E_INVALID, "spr_host_eig_top: NULL pointer");
+  SPR_REQUIRE(m >= 2 && r >= 1 && r <= m && m <= 4096, SPR_E_INVALID, "spr_host_eig_top: bad shape m=%d r=%d", m, r);
+  const size_t mm = (size_t)m * m, mr = (size_t)m * r;
+  int lwork = m * 64;
+  double *buf = static_cast<double *>(malloc(sizeof(double) * (mm + 5 * (size_t)m + (size_t)lwork + 2 * mr + 2 * (size_t)r * r + 5 * mr + 3 * (size_t)r)));
+  SPR_REQUIRE(buf != nullptr, SPR_E_WORKSPACE, "spr_host_eig_top: out of host memory");
+  double *A = buf, *d = A + mm, *e = d + m, *tau = e + m, *d2 = tau + m, *e2 = d2 + m, *work = e2 + m;
+  double *Z = work + lwork, *Zc = Z + mr, *E = Zc + mr, *E2 = E + (size_t)r * r, *vwork = E2 + (size_t)r * r;
+  memcpy(A, h_G, sizeof(double) * mm);                       // symmetric: row-major = column-major
+  char L = 'L', N = 'N';
+  int mi = m, ri = r, info = 0;
+  reinterpret_cast<dsytrd_fn>(fn_dsytrd)(&L, &mi, A, &mi, d, e, tau, work, &lwork, &info);
+  if (info == 0) {
+    memcpy(d2, d, sizeof(double) * m);
+    memcpy(e2, e, sizeof(double) * (m - 1));
+    reinterpret_cast<dsterf_fn>(fn_dsterf)(&mi, d2, e2, &info);
+  }
+  if (info != 0) { free(buf); return 1; }
+  for (int i = 0; i < m; ++i) h_lam[i] = d2[m - 1 - i];      // descending
+  int rc = 0;
+  tridiag_vectors_core(d, e, m, d2 + (m - r), r, Z, 4, vwork);   // column j <-> ascending eigenvalue m - r + j
+  double defect = gram_defect(Z, m, r, E);
+  if (!(defect <= 1e-8)) rc = 2;
+  if (rc == 0) {
+    // Z <- Z (I - E / 2), written column-major for dormtr
+    for (int k = 0; k < m; ++k) {
+      const double *zk = Z + (size_t)k * r;
+      for (int j = 0; j < r; ++j) {
+        double acc = zk[j];
+        for (int i = 0; i < r; ++i) acc -= 0.5 * zk[i] * E[(size_t)i * r + j];
+        Zc[(size_t)j * m + k] = acc;
+      }
+    }
+    reinterpret_cast<dormtr_fn>(fn_dormtr)(&L, &L, &N, &mi, &ri, A, &mi, tau, Zc, &mi, work, &lwork, &info);
+    if (info != 0) rc = 1;
+  }
+  if (rc == 0) {
+    for (int k = 0; k < m; ++k)                               // row-major, columns in DESCENDING order of eigenvalue
+      for (int j = 0; j < r; ++j) h_V[(size_t)k * r + j] = Zc[(size_t)(r - 1 - j) * m + k];
+    defect = gram_defect(h_V, m, r, E2);
+    if (!(defect <= 1e-12)) rc = 2;
+  }
+  free(buf);
+  return rc;
+}

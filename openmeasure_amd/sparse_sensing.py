@@ -406,6 +406,8 @@ def _eigh_small(G):
 
 _EIGH_TOP_MIN_M = 96           # below this dsyevd is a fraction of a millisecond: nothing to gain (m = 64, r = 32: dsyevd 156-173 us,
                                # the top-r route 140 us in isolation but 207 us inside fit() on a second host -- round 5)
+_EIGH_TOP_NATIVE_MIN_M = 32    # ... between the two, ONE native call (spr_host_eig_top): m = 64, r = 32 150 us against 173 us for dsyevd,
+                               # m = 41, r = 14 63 against 86; from m = 128 on its plain loops lose to the BLAS calls of the Python route
 _LWORK = {}
 
 
@@ -447,6 +449,59 @@ def _tridiag_vectors_batched(d, e, w):
     if not np.all(np.isfinite(E)) or np.abs(E).max() > 1e-8:
         return None
     return np.asfortranarray(Z - 0.5 * (Z @ E))
+
+
+_LAPACK_PTRS = None
+
+
+def _lapack_pointers():
+    """Addresses of SciPy's LAPACK routines dsytrd / dsterf / dormtr (scipy.linalg.cython_lapack exports them as C function
+    pointers in capsules); False when they cannot be had."""
+    global _LAPACK_PTRS
+    if _LAPACK_PTRS is None:
+        try:
+            import ctypes
+            from scipy.linalg import cython_lapack
+            get_name = ctypes.pythonapi.PyCapsule_GetName
+            get_name.restype, get_name.argtypes = ctypes.c_char_p, [ctypes.py_object]
+            get_ptr = ctypes.pythonapi.PyCapsule_GetPointer
+            get_ptr.restype, get_ptr.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+            out = []
+            for name in ('dsytrd', 'dsterf', 'dormtr'):
+                cap = cython_lapack.__pyx_capi__[name]
+                ptr = get_ptr(cap, get_name(cap))
+                if not ptr:
+                    raise ValueError(name)
+                out.append(ptr)
+            _LAPACK_PTRS = tuple(out)
+        except Exception:                                  # noqa: BLE001 -- any SciPy without these capsules: the Python route
+            _LAPACK_PTRS = False
+    return _LAPACK_PTRS
+
+
+def _eig_top_native(G, r):
+    """The top-r route in ONE host call of the library (spr_host_eig_top: dsytrd, dsterf, the batched inverse iterations and
+    dormtr back to back, LAPACK reached through SciPy's function pointers): at small m the route is mostly call overhead -- m = 64,
+    r = 32: 173 us for dsyevd, 140-207 us for the same four steps glued in Python.  -> (lam descending (m,), V (m, r)) or None
+    (no library / no pointers / the vectors failed their checks: the caller goes on with the Python route)."""
+    ptrs = _lapack_pointers()
+    if not ptrs:
+        return None
+    try:
+        from . import _lib
+        lib = _lib.load()
+    except (RuntimeError, OSError, AttributeError):
+        return None
+    m = G.shape[0]
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    lam, V = np.empty(m), np.empty((m, r))
+    with _one_blas_thread():
+        rc = lib.spr_host_eig_top(G.ctypes.data, m, r, lam.ctypes.data, V.ctypes.data, *ptrs)
+    if rc == 1:
+        raise np.linalg.LinAlgError('Eigenvalues did not converge')
+    if rc != 0 or not np.all(np.isfinite(V)):
+        return None
+    return lam, V
 
 
 def _eigvecs_top(fac, lam, r):
@@ -1422,6 +1477,14 @@ class ROM:
         The top-r route (dsytrd + dsterf + r inverse iterations + dormqr) for m >= 96 when the caller only needs r <= m/2
         vectors and sigma_1/sigma_r is within the plain Gram route's range (the refinement pass needs all of V)."""
         m = G.shape[0]
+        if (rank_of is not None and _EIGH_TOP_NATIVE_MIN_M <= m < _EIGH_TOP_MIN_M
+                and getattr(rank_of, 'known_r', None) is not None):
+            # the number of modes is given (select_modes='number'): the whole route in one library call
+            r = rank_of.known_r
+            if 2 * r <= m:
+                got = _eig_top_native(G, r)
+                if got is not None and np.isfinite(got[0][0]) and not np.sqrt(max(got[0][r - 1], 0.0)) * _GRAM_KAPPA_REFINE < np.sqrt(max(got[0][0], 0.0)):
+                    return got
         if rank_of is not None and m >= _EIGH_TOP_MIN_M:
             lam_a, fac = _eigh_tridiagonal(G)
             lam = lam_a[::-1].copy()
@@ -1589,7 +1652,11 @@ class ROM:
         m = Xd.shape[1]
         import time
         t_eig = time.perf_counter()
-        S, V, exp_variance = self._spectrum(G, lambda ev: self._select_rank(ev, m, select_modes, n_modes))
+        def rank_of(ev):
+            return self._select_rank(ev, m, select_modes, n_modes)
+        # select_modes='number': r is known before the eigenvalues are (the one-call top-r route, _eig_top_native)
+        rank_of.known_r = n_modes if (select_modes == 'number' and type(n_modes) is int and 1 <= n_modes <= m) else None
+        S, V, exp_variance = self._spectrum(G, rank_of)
         self.eig_ms_ = 1e3 * (time.perf_counter() - t_eig)      # host wall time of the m x m eigen-solve (bench.py: per rank)
         self._trace.mark('eigh')
         r = self._select_rank(exp_variance, m, select_modes, n_modes)

@@ -324,6 +324,45 @@ def test_deferred_reconstruct_runs_in_the_next_fits_gap():
     run_deferred_reconstruct(NumpyEngine())
 
 
+@pytest.mark.parametrize('m,r', [(32, 8), (41, 14), (64, 32), (95, 40)])
+def test_native_top_r_eigen_route(m, r):
+    """spr_host_eig_top (round 5): dsytrd + dsterf + batched inverse iterations + dormtr in ONE host call of the library, LAPACK
+    reached through SciPy's exported function pointers -- against dsyevd; a cluster of equal eigenvalues makes it decline (the
+    Python route with dstein / dsyevd takes over); fit() takes it for 32 <= m < 96 when the number of modes is given."""
+    import openmeasure_amd.sparse_sensing as ss
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((6 * m, m)) * (0.9 ** np.arange(m))
+    A -= A.mean(axis=1, keepdims=True)
+    G = A.T @ A
+    got = ss._eig_top_native(G, r)
+    if got is None:
+        pytest.skip('library or LAPACK pointers not available')
+    lam, V = got
+    w, vv = ss._eigh_small(G)
+    w, vv = w[::-1], vv[:, ::-1][:, :r]
+    np.testing.assert_allclose(lam, w, rtol=0, atol=1e-13 * w[0])
+    assert np.abs(V.T @ V - np.eye(r)).max() <= 1e-12
+    assert np.abs(G @ V - V * lam[:r]).max() <= 1e-13 * lam[0]
+    sg = np.sign(np.sum(V * vv, axis=0))
+    np.testing.assert_allclose(V * sg, vv, rtol=0, atol=1e-7)
+    # r equal eigenvalues: inverse iteration without re-orthogonalisation cannot separate them -> declined, never wrong
+    Q = np.linalg.qr(rng.standard_normal((m, m)))[0]
+    lamc = np.concatenate([np.full(r, 5.0), np.linspace(1.0, 0.1, m - r)])
+    assert ss._eig_top_native((Q * lamc) @ Q.T, r) is None
+    # ... and fit() uses it: same basis as with the route switched off
+    from tests.numpy_engine import NumpyEngine
+    X = rng.standard_normal((300, 6)) @ rng.standard_normal((6, m)) + 0.01 * rng.standard_normal((300, m))
+    a = SPR(X, 3, None, engine=NumpyEngine()); a.fit(select_modes='number', n_modes=4)
+    old = ss._EIGH_TOP_NATIVE_MIN_M
+    try:
+        ss._EIGH_TOP_NATIVE_MIN_M = 10 ** 6
+        b = SPR(X, 3, None, engine=NumpyEngine()); b.fit(select_modes='number', n_modes=4)
+    finally:
+        ss._EIGH_TOP_NATIVE_MIN_M = old
+    np.testing.assert_allclose(a.Sigma_r, b.Sigma_r, rtol=1e-12)
+    np.testing.assert_allclose(np.abs(a.Ur), np.abs(b.Ur), atol=1e-9)
+
+
 def test_decomposition_public(small):
     X, F, xyz = small
     rom = ROM(X, F, xyz, engine=NumpyEngine())

@@ -544,6 +544,8 @@ def run_rank(args):
     comm = comm_summary(comm_main, comm_sync, dist_on, args.sync_gather, F, m, world, n_loc, gather_path=head_why,
                         paths=path_results or None)
     px = spr.__dict__.get('_p2p')
+    if px is not None:
+        px.check()                                    # a join kernel that gave up on a peer: no result line for such a run
     if dist_on and px is not None and px.host_ms['calls']:
         comm['p2p_host_ms_per_gather'] = {k_: round(v / px.host_ms['calls'], 4) for k_, v in px.host_ms.items() if k_ != 'calls'}
         comm['p2p_copy_streams'] = len(px._pool)

@@ -38,7 +38,7 @@ from . import _lib
 
 _FLAG_BYTES = 4096
 _SCRATCH_BYTES = 4096
-_MAX_WORLD = 100                     # 5 counter arrays of `world` uint64 + 2 status words in the 4 KB counter page
+_MAX_WORLD = 100                     # 5 counter arrays of `world` uint64 in the 4 KB counter page
 _KINDS = {'coarse': 0, 'fine': 1, 'uncached': 2}
 
 
@@ -97,6 +97,10 @@ class P2PFieldGather:
         self.streams = [self._pool[i % n_streams] for i in range(len(self.peers))]
         self.selftest_report = None
         self.host_ms = dict(begin=0.0, push=0.0, join=0.0, calls=0)   # host wall time spent issuing (bench.py reports the means)
+        # where a join kernel that gives up leaves (counter index + 1, value seen): page-locked HOST memory the kernel writes
+        # directly, so that check() is a plain memory read -- no copy, no synchronisation -- and can run at every gather
+        self._status = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self._status_np = self._status.numpy()
 
     # ------------------------------------------------------------------ set-up (COLLECTIVE)
     def ensure(self, n_p, n_total):
@@ -175,10 +179,10 @@ class P2PFieldGather:
             ok, why = False, f'rank {self.rank}: {exc}'
         return self._selftest(ok, why, kind)
 
-    # counter page (int64 words): arrive[b][src] | release[src] | pushed[peer] | self-test[src] | status (2 words)
+    # counter page (int64 words): arrive[b][src] | release[src] | pushed[peer] | self-test[src]
     def _slot(self, kind, idx, b=0):
         w = self.world
-        return {'arrive': b * w + idx, 'release': 2 * w + idx, 'pushed': 3 * w + idx, 'test': 4 * w + idx, 'status': 5 * w}[kind]
+        return {'arrive': b * w + idx, 'release': 2 * w + idx, 'pushed': 3 * w + idx, 'test': 4 * w + idx}[kind]
 
     def _flag(self, page, kind, idx, b=0):
         """address of a counter in the counter page at `page`"""
@@ -275,6 +279,7 @@ class P2PFieldGather:
         reconstruct kernel writes this rank's block into -- the (n_p, n_total) view of buffer k % n_buf."""
         eng, torch = self.eng, self.eng.torch
         t_host = time.perf_counter()
+        self.check()
         st = torch.cuda.current_stream(eng.device).cuda_stream
         if self.peers:
             tab = _ptr_array([self._peer_flag(q, 'release') for q in self.peers])
@@ -322,24 +327,25 @@ class P2PFieldGather:
             tab = _ptr_array([self._flag(self.fbase, 'arrive', q, b) for q in self.peers]
                              + [self._flag(self.fbase, 'pushed', q) for q in self.peers])
             _lib.check(self.lib.spr_field_gather_p2p_join(tab, 2 * len(self.peers), k + 1, self.JOIN_TIMEOUT_S,
-                                                          self._flag(self.fbase, 'status', 0),
+                                                          self._status.data_ptr(),
                                                           torch.cuda.current_stream(eng.device).cuda_stream),
                        'spr_field_gather_p2p_join')
         self.host_ms['join'] += 1e3 * (time.perf_counter() - t_host)
 
     def check(self):
-        """Did a join kernel give up (a peer that never pushed)?  One 16-byte D2H copy: call it where the host synchronises
-        anyway.  Raises RuntimeError naming the counter that was not reached."""
-        if self.fbase is None:
-            return
-        s0 = self._slot('status', 0)
-        st = self._flags[s0:s0 + 2].cpu().numpy()
+        """Did a join kernel give up (a peer that never pushed)?  A read of two words of page-locked host memory the kernel
+        writes on its way out: free, so begin() calls it at every gather -- a dead peer surfaces as a RuntimeError naming the
+        missing counter at the latest one gather after the join that waited for it, instead of as a stale field."""
+        st = self._status_np
         if st[0]:
             i = int(st[0]) - 1
             n = len(self.peers)
             who, what = (self.peers[i], 'the block of rank') if i < n else (self.peers[i - n], 'my own push to rank')
+            seen = int(st[1])
+            st[:] = 0
             raise RuntimeError(f'p2p field exchange: rank {self.rank} gave up waiting for {what} {who} after '
-                               f'{self.JOIN_TIMEOUT_S:.0f} s (counter at {int(st[1])}, gather {self.k - 1})')
+                               f'{self.JOIN_TIMEOUT_S:.0f} s (counter at {seen}, gather {self.k - 1}); the field handed out by '
+                               'that join is incomplete')
 
     def arrived(self, k):
         """Host-side look at the arrival counters of gather k (one small D2H copy): which peers' blocks are still missing."""

@@ -290,8 +290,7 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
                 res['late'] = out.cpu().numpy()[0, ::2047].tolist()
             dist.barrier()
             if rank == 0:
-                px._flags[px._slot('status', 0):px._slot('status', 0) + 2] = 0
-                px.join(0)                                     # rank 1's block has arrived by now
+                px.join(0)                                     # rank 1's block has arrived by now (check() cleared the status)
                 torch.cuda.synchronize()
                 px.check()
                 res['late'] = out.cpu().numpy()[0, ::2047].tolist()

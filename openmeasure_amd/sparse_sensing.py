@@ -2006,6 +2006,11 @@ class ROM:
         px = self._p2p
         n_loc, n_p = Ur_d.shape[0], A_d.shape[0]
         first, total = int(lay[0, 0]), int(lay[:, 1].sum())
+        pf = self.__dict__.get('_pending_field')
+        if pf is not None and pf.pending:
+            # an exchange nobody joined: its pushes still READ this rank's block of the copy the next kernel is about to
+            # overwrite -- join it first (one single-wave kernel; every rank does the same, the call being collective)
+            pf.wait()
         px.ensure(n_p, total)                                 # a larger field than before: new buffers (collective)
         out = px.begin()
         off = self._row0 - first

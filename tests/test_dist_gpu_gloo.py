@@ -69,6 +69,11 @@ def _worker(rank, world, port, fixture, out_dir, uneven=False):
             assert prev.pending and not prev.needs_cus
         np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[-1])
         np.testing.assert_array_equal(spr.reconstruct(A3), X3)             # ... and with the host contract
+        # an exchange nobody joins is joined by the next one (its pushes still read this rank's block of the copy)
+        dropped = spr.reconstruct(As[0], to_host=False, wait=False)
+        nxt = spr.reconstruct(As[1], to_host=False, wait=False)
+        assert not dropped.pending
+        np.testing.assert_array_equal(nxt.wait().cpu().numpy(), wants[1])
         # the same loop with the launches deferred into the next fit()'s host gap (ROM.defer_reconstruct): kernel + push of step
         # k are enqueued inside fit k + 1, the last one by wait()
         spr.defer_reconstruct = True

@@ -259,9 +259,13 @@ def comm_summary(comm_main, comm_sync, dist_on, sync_gather, F, m, world, n_loc,
                 gather_exposed_ms=comm_main.get('gather_exposed', 0.0 if (dist_on and not sync_gather) else None),
                 allreduce_bytes=(F * m * m + world * F * 3) * 8 if dist_on else 0,
                 gather_bytes_per_rank=n_loc * 8 if dist_on else 0,
-                note=('mean per step over the timed steps; allreduce_ms: bracket around the call on the compute stream; '
-                      'gather_ms: issue to join in the sync-gather loop; gather_exposed_ms: the join of the pipelined loop '
-                      '(what did not hide under the next Gram pass)') if dist_on else 'no collectives at N = 1')
+                note=('per step over the timed steps; allreduce_ms: mean bracket around the call on the compute stream; '
+                      'gather_ms: mean issue to join in the sync-gather loop; gather_exposed_ms: MEDIAN join of the pipelined loop '
+                      '(what did not hide under the next Gram pass); gather_exposed_last_ms: the loop\'s final join, which has '
+                      'nothing to hide under') if dist_on else 'no collectives at N = 1')
+    if dist_on:
+        comm['gather_exposed_last_ms'] = (round(comm_main['gather_exposed_last'], 4)
+                                          if comm_main.get('gather_exposed_last') is not None else None)
     for k_ in ('allreduce_ms', 'gather_ms', 'gather_exposed_ms'):
         if comm[k_] is not None:
             comm[k_] = round(comm[k_], 4)
@@ -489,7 +493,12 @@ def run_rank(args):
         comm = {}
         if dist_on:
             for key, pairs in spr.comm_timing.items():
-                comm[key] = float(np.mean([eng.elapsed_ms(e0, e1) for e0, e1 in pairs])) if pairs else None
+                ms = [eng.elapsed_ms(e0, e1) for e0, e1 in pairs]
+                # the exposed part of a pipelined exchange: the MEDIAN over the joins (the last join of the loop has nothing to
+                # hide under -- its exchange is joined right behind its own reconstruct -- and is reported on its own)
+                comm[key] = (float(np.median(ms)) if key == 'gather_exposed' else float(np.mean(ms))) if ms else None
+                if key == 'gather_exposed' and ms:
+                    comm['gather_exposed_last'] = float(ms[-1])
         return dt, dt_own, timers, comm, field
 
     # N > 1: the field exchange of the headline loop is RowShard(gather=...) as resolved at the first sharded reconstruct()

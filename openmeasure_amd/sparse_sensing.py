@@ -44,7 +44,9 @@ What differs from the reference, by design:
 
 Row sharding: pass ``shard=RowShard(row0, n_global, group)`` and the local block of rows;
 the Gram matrix is all-reduced, pivot candidates are all-gathered per step, Theta is
-all-reduced and the reconstructed field is all-gathered (RCCL through torch.distributed).
+all-reduced (RCCL through torch.distributed) and every rank's block of the reconstructed field reaches every rank --
+pushed by the SDMA engines into copies of the field the ranks of a node have mapped from each other (openmeasure_amd/p2p.py),
+or all-gathered over RCCL (``RowShard(gather=...)``).
 """
 from __future__ import annotations
 

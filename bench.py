@@ -558,6 +558,8 @@ def run_rank(args):
     if dist_on and px is not None and px.host_ms['calls']:
         comm['p2p_host_ms_per_gather'] = {k_: round(v / px.host_ms['calls'], 4) for k_, v in px.host_ms.items() if k_ != 'calls'}
         comm['p2p_copy_streams'] = len(px._pool)
+        # the first exchange through the mapped buffers was compared block by block with what the peers sent (ROM._p2p_first_exchange)
+        comm['p2p_first_exchange'] = px.verified
     # never print a number for a run that computed garbage: spectrum, basis sample and field must be finite
     fld = field if torch.is_tensor(field) else None
     if not (np.all(np.isfinite(spr.S_[:s])) and bool(torch.isfinite(spr._d['Ur'][:4096].double()).all())

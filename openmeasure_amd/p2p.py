@@ -63,6 +63,7 @@ class P2PFieldGather:
 
     SELFTEST_TIMEOUT_S = 10.0
     JOIN_TIMEOUT_S = 120.0           # the join kernel gives up after this long (status words; see check())
+    FIRST_TIMEOUT_S = 20.0           # ... and after this long in the first exchange through new buffers (ROM._p2p_first_exchange)
 
     def __init__(self, eng, world, rank, all_gather, double_buffer=False, loopback=0):
         # loopback = L (diagnostic, one-rank groups only: bench.py --share-of N --p2p-loopback N-1): L imaginary peers whose
@@ -96,6 +97,9 @@ class P2PFieldGather:
         self._pool = [torch.cuda.Stream(eng.device) for _ in range(n_streams if self.peers else 0)]
         self.streams = [self._pool[i % n_streams] for i in range(len(self.peers))]
         self.selftest_report = None
+        # None until the first full-size exchange through these buffers has been compared, block by block, with what the peers
+        # say they sent (sparse_sensing.py, ROM._p2p_first_exchange); then a short report
+        self.verified = None
         self.host_ms = dict(begin=0.0, push=0.0, join=0.0, calls=0)   # host wall time spent issuing (bench.py reports the means)
         # where a join kernel that gives up leaves (counter index + 1, value seen): page-locked HOST memory the kernel writes
         # directly, so that check() is a plain memory read -- no copy, no synchronisation -- and can run at every gather
@@ -126,6 +130,7 @@ class P2PFieldGather:
                 self.shape = (n_p, n_total)
                 self.k = 0
                 self.memory = kind
+                self.verified = None
                 return
         self.close(collective=False)
         raise P2PUnavailable(why)
@@ -352,6 +357,18 @@ class P2PFieldGather:
         b = k % self.n_buf
         fl = self._flags[b * self.world:(b + 1) * self.world].cpu().numpy()
         return [q for q in self.peers if fl[q] < k + 1]
+
+    def abandon(self):
+        """After a failed exchange: raise every counter of MY page far beyond any gather count, so that the waits my copy
+        streams and my join kernels still hold (all of them poll my page) drain instead of sitting in the queues until the
+        process ends.  The buffers stay allocated and mapped -- peers may still be writing -- and the object is not used again."""
+        torch = self.eng.torch
+        if self._flags is not None:
+            side = torch.cuda.Stream(self.eng.device)          # not behind a join kernel that is still polling
+            with torch.cuda.stream(side):
+                self._flags.fill_(1 << 40)
+            side.synchronize()
+        self._status_np[:] = 0
 
     # ------------------------------------------------------------------ teardown
     def close(self, collective=True):

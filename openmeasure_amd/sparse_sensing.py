@@ -2014,6 +2014,8 @@ class ROM:
             # overwrite -- join it first (one single-wave kernel; every rank does the same, the call being collective)
             pf.wait()
         px.ensure(n_p, total)                                 # a larger field than before: new buffers (collective)
+        if px.verified is None and px.peers and not px.loopback:
+            return self._p2p_first_exchange(Ur_d, A_d, lay, to_host, wait)
         out = px.begin()
         off = self._row0 - first
         eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'], self._d['scale'], A_d,
@@ -2034,6 +2036,73 @@ class ROM:
         host = eng.to_host(out).T
         px.check()                                            # the host has just synchronised: did the join kernel give up?
         return host
+
+    def _p2p_first_exchange(self, Ur_d, A_d, lay, to_host, wait):
+        """The FIRST exchange through freshly mapped buffers (COLLECTIVE, once per allocation): the set-up's self-test moved
+        32-byte patterns; this is the first time whole blocks cross the links, so the result is checked before anybody uses it.
+        Every rank sums the bit patterns of its own block (int64, wrap-around: exact), the sums are all-gathered, and every rank
+        compares them with the same sums over the blocks it RECEIVED; the join waits FIRST_TIMEOUT_S at most.  All ranks share
+        the verdict.  On failure -- a HIP error in a push, a block that never arrives, a block that differs -- ``gather='auto'``
+        drops to the collective all-gather for the rest of this object's life (``gather_path_`` says why) and this call returns
+        that path's field; ``gather='p2p'`` raises on every rank."""
+        import os
+        import sys
+        eng = self._engine()
+        t = eng.torch
+        px = self._p2p
+        n_loc, n_p = Ur_d.shape[0], A_d.shape[0]
+        first = int(lay[0, 0])
+        off = self._row0 - first
+        rank = self._shard.rank
+
+        def block_sum(blk):
+            return blk.view(t.int64).sum()
+
+        ok, why, out = True, '', None
+        mine = t.zeros((), dtype=t.int64, device=eng.device)
+        keep = px.JOIN_TIMEOUT_S
+        px.JOIN_TIMEOUT_S = min(keep, px.FIRST_TIMEOUT_S)
+        try:
+            out = px.begin()
+            eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'], self._d['scale'], A_d,
+                            out=out[:, off:off + n_loc])
+            import time
+            self.last_comm_ = ('field exchange (p2p, first: verified)', (n_p, int(lay[:, 1].sum())), time.time())
+            k = px.push(off, n_loc)
+            px.join(k)
+            mine = block_sum(out[:, off:off + n_loc])
+        except Exception as exc:                              # noqa: BLE001 -- any failure means "not this path", decided together
+            ok, why = False, f'rank {rank}: {exc}'
+        finally:
+            px.JOIN_TIMEOUT_S = keep
+        sums = eng.to_host(self._all_gather(mine.reshape(1))).reshape(-1)       # synchronises: the join kernel has ended
+        if ok:
+            try:
+                px.check()
+                got = eng.to_host(t.stack([block_sum(out[:, int(o) - first:int(o) - first + int(c)]) for o, c in lay]))
+                bad = [int(q) for q in np.flatnonzero(got != sums)]
+                if bad:
+                    ok, why = False, f'rank {rank}: the blocks of ranks {bad} differ from what those ranks sent'
+            except RuntimeError as exc:
+                ok, why = False, str(exc)
+        oks = eng.to_host(self._all_gather(t.tensor([1.0 if ok else 0.0], device=eng.device))).reshape(-1)
+        if oks.all():
+            px.verified = dict(blocks=int(lay.shape[0]), bytes_per_block=int(n_p * n_loc * 8), check='per-block int64 sums')
+            if to_host:
+                return eng.to_host(out).T
+            return out if wait else PendingField(out)
+        failed = [int(q) for q in np.flatnonzero(oks == 0)]
+        why = why or f'ranks {failed} reported a failed exchange'
+        px.abandon()
+        self._p2p_dropped = self.__dict__.pop('_p2p')          # stays allocated: peers have it mapped; never used again
+        if (os.environ.get('SPR_GATHER') or self._shard.gather) == 'p2p':
+            self.__dict__.pop('_gather_sel', None)
+            raise RuntimeError(f"RowShard(gather='p2p'): the first full-size exchange failed -- {why}")
+        self._gather_sel = 'rccl'
+        self.gather_path_ = f'rccl (p2p failed its first full-size exchange: {why})'
+        if rank == 0:
+            print(f'[openmeasure_amd] field exchange falls back to the RCCL all-gather: {why}', file=sys.stderr)
+        return self.reconstruct(A_d, to_host=to_host, wait=wait)
 
     def _gather_unequal(self, Ur_d, A_d, lay, to_host, wait):
         """RCCL field all-gather for row blocks of different sizes: every rank contributes its (n_p, n_loc) block padded to

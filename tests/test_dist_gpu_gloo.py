@@ -261,6 +261,51 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
             finally:
                 if rank == world - 1:
                     eng.lib.spr_p2p_open = real
+        elif case in ('first_mismatch', 'first_timeout'):
+            # the first full-size exchange is checked before anybody uses it: the last rank's push leaves out the last row of
+            # its block (first_mismatch) or never happens (first_timeout).  gather='auto': EVERY rank drops to the collective
+            # path, with the reason, and returns that path's field; gather='p2p': every rank raises.  Nothing hangs.
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            n_loc = n // world
+            row0 = rank * n_loc
+            real_push = P2PFieldGather.push
+            P2PFieldGather.FIRST_TIMEOUT_S = 1.0
+
+            def bad_push(self, first, n_rows):
+                if case == 'first_mismatch':
+                    return real_push(self, first, n_rows - 1)
+                k = self.k
+                self.k += 1
+                return k
+            try:
+                if rank == world - 1:
+                    P2PFieldGather.push = bad_push
+                spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+                spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+                sgn = np.sign(np.sum(spr.Ar * g['Ar'], axis=0))
+                X3 = spr.reconstruct(g['Ar_pred3'] * sgn)
+                X3b = spr.reconstruct(g['Ar_pred3'] * sgn)          # and stays on that path
+                res = dict(path=str(spr.gather_path_), X3=X3, same=bool(np.array_equal(X3, X3b)),
+                           dropped='_p2p' not in spr.__dict__)
+                spr2 = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None,
+                           shard=RowShard(row0, n, gather='p2p'), engine=eng)
+                spr2.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+                try:
+                    spr2.reconstruct(spr2.Ar[:1])
+                    res['forced'] = 'no error'
+                except RuntimeError as exc:
+                    res['forced'] = 'RuntimeError: ' + str(exc)[:90]
+                # a healthy object afterwards: verified, p2p
+                P2PFieldGather.push = real_push
+                spr3 = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+                spr3.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+                X3c = spr3.reconstruct(g['Ar_pred3'] * sgn)
+                res.update(path3=str(spr3.gather_path_), verified=str(spr3._p2p.verified), same3=bool(np.array_equal(X3, X3c)))
+                spr3.close()
+            finally:
+                P2PFieldGather.push = real_push
         else:
             # the join kernel's exit: a peer that never pushes.  Rank 0 pushes and joins with a short timeout; the kernel gives
             # up, leaves the missing counter in the status words, check() names the peer.  Nothing hangs.
@@ -305,10 +350,12 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['fallback', 'timeout'])
+@pytest.mark.parametrize('case', ['fallback', 'timeout', 'first_mismatch', 'first_timeout'])
 def test_p2p_exchange_edges(tmp_path, case):
     """round 5: the p2p field exchange when it cannot be had (one rank cannot map its peers -> every rank on the collective path,
-    or every rank raising when p2p was demanded) and when a peer never pushes (the join kernel's wall-clock exit + check())."""
+    or every rank raising when p2p was demanded), when a peer never pushes (the join kernel's wall-clock exit + check()), and
+    when the first full-size exchange through new buffers delivers a wrong block or none (checked per block; all ranks drop to
+    the collective path together, or raise together when p2p was demanded)."""
     import torch.multiprocessing as mp
     world = 2
     mp.spawn(_p2p_edge_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
@@ -321,6 +368,15 @@ def test_p2p_exchange_edges(tmp_path, case):
             assert str(o['path']).startswith('rccl (p2p unavailable'), o['path']
             assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO
             assert str(o['forced']).startswith('P2PUnavailable'), o['forced']
+    elif case.startswith('first_'):
+        from tests.conftest import load_golden
+        from tests.parity import REL_FRO, rel_fro
+        g = load_golden('g3_num8')
+        for o in outs:
+            assert str(o['path']).startswith('rccl (p2p failed its first full-size exchange'), o['path']
+            assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO and bool(o['same']) and bool(o['dropped'])
+            assert str(o['forced']).startswith("RuntimeError: RowShard(gather='p2p'): the first full-size exchange failed"), o['forced']
+            assert str(o['path3']).startswith('p2p') and 'per-block int64 sums' in str(o['verified']) and bool(o['same3'])
     else:
         assert 400.0 <= float(outs[0]['join_ms']) <= 5000.0, outs[0]['join_ms']       # gave up after ~0.5 s, did not hang
         assert 'gave up waiting for the block of rank 1' in str(outs[0]['check']), outs[0]['check']

@@ -709,6 +709,7 @@ def run_rank(args):
                 pivot_sweeps=int(spr.pivot_sweeps_), pivot_pool_sweeps=int(spr.pivot_pool_sweeps_),
                 min_pivot_gap=gap_min, placement_from_row_norms=bool(spr.placement_from_norms_),
                 placement_GBs_of_basis=round(n_loc * r * B / t_place / 1e6, 1),
+                sensors_crc32=int(__import__('zlib').crc32(np.ascontiguousarray(spr.sensors_, dtype=np.int64).tobytes())),
                 timing='median of 3 calls after 2 warm-up calls, barrier + device sync on both sides')
     if f32_basis:
         # f32-stored basis (config 5): the sensors are those of the STORED basis; every pick led its runner-up by at least

@@ -35,6 +35,8 @@
  *                             RCCL's kernel, which cannot share one with the Gram / projection workgroups)
  *   SPR_QR_EPOCH_ILP=0|2      spr_qr_epoch_sweep_*: direction tiles one after the other in full sweeps too | side by side in pool
  *                             sweeps as well (default 1: full sweeps of bases up to 64 columns side by side)
+ *   SPR_QR_ORTH_TILE=0        spr_qr_step_f64 / spr_qr_steps_f64: the Gram-Schmidt passes of a step as chains of loads instead of
+ *                             the register-tiled form (A/B only)
  *   SPR_P2P_BLIT=1            spr_p2p_copy / spr_field_gather_p2p: blit kernels instead of the SDMA engines
  * and by the Python layer (openmeasure_amd/): SPR_PROJECT_STREAM=1 (streamed-W projection for every shape),
  * SPR_GAP_FILLER=1|0 (ROM.gap_filler, opt-in: a filler launch in fit()'s host gap), SPR_GATHER=auto|p2p|rccl (field exchange of

@@ -581,12 +581,66 @@ __global__ __launch_bounds__(1024) void qr_cand_best_kernel(
   for (int k = threadIdx.x; k < r; k += 1024) rec[3 + k] = (gp >= 0) ? cand_U[(int64_t)gp * ldc + k] : 0.0;
 }
 
+// The two Gram-Schmidt passes of orth_step for r <= 128, Q read ONCE: the 256 threads form a 16 x 16 grid over the (step x r)
+// block of earlier directions -- thread (a, b) keeps Q[a + 16 i][b + 16 j] in registers (NJ x NJ doubles, NJ = ceil(r / 16)) --
+// so that the dot products c = Q v reduce over the 16 lanes of a row group (DPP) and the update v -= Q^T c over the row groups
+// (two shuffles, then the four waves through LDS).  One L2 round trip per step instead of four chains of dependent loads: the
+// step kernel's last workgroup spent up to 30 us here at step 63 of a 64-column basis, on a critical path of 64+ launches
+// per placement.  part: 4 * 16 * NJ doubles of LDS.  v holds the candidate row on entry (synchronised), the residual on exit.
+template <int NJ>
+__device__ inline void orth_gs_tile(const double *__restrict__ Q, int r, int step, double *v, double *part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = lane & 15, a = threadIdx.x >> 4;
+  double q[NJ][NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int t = a + 16 * i;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int k = b + 16 * j;
+      q[i][j] = (t < step && k < r) ? Q[(int64_t)t * r + k] : 0.0;
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    double vk[NJ], u[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int k = b + 16 * j; vk[j] = (k < r) ? v[k] : 0.0; u[j] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      double d = 0.0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) d = fma(q[i][j], vk[j], d);
+      d = group_sum_t<16>(d);                                  // c[a + 16 i], in all 16 lanes of the row group
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) u[j] = fma(d, q[i][j], u[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      u[j] += __shfl_xor(u[j], 16, 64);
+      u[j] += __shfl_xor(u[j], 32, 64);
+      if (lane < 16) part[(wave * NJ + j) * 16 + b] = u[j];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < r; k += QR_THREADS) {
+      const int j = k >> 4, bb = k & 15;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < QR_THREADS / 64; ++w) acc += part[(w * NJ + j) * 16 + bb];
+      v[k] -= acc;
+    }
+    __syncthreads();
+  }
+}
+
 // one workgroup: pick the winner among the ranks' records, certify it against tau, orthogonalise,
-// store q / pivot / flags.  v, c: r doubles of LDS each; red: one double per wave; win_p: one int (all LDS).
+// store q / pivot / flags.  v, c: r doubles of LDS each (c: at least 512 doubles when r <= 128 -- the tiled passes stage their
+// partial sums in it); red: one double per wave; win_p: one int (all LDS).  MAXNJ: 16 MAXNJ bounds r where the caller knows it
+// at compile time (the fused step kernel), so that only the tile sizes that can occur are built into it.
+template <int MAXNJ = 8>
 __device__ inline void orth_step(const double *__restrict__ recs, int n_rec, const double *__restrict__ taus, int n_tau,
                                  int first, int r, int step, double *__restrict__ Q, int64_t *__restrict__ piv,
                                  double *__restrict__ gap, double *__restrict__ okflag, double *v, double *c, double *red,
-                                 int *win_p) {
+                                 int *win_p, int tiled) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int stride = r + 3;
   if (threadIdx.x == 0) {
@@ -610,6 +664,11 @@ __device__ inline void orth_step(const double *__restrict__ recs, int n_rec, con
   const double *row = recs + (int64_t)(*win_p) * stride + 3;
   for (int k = threadIdx.x; k < r; k += QR_THREADS) v[k] = row[k];
   __syncthreads();
+  if (tiled && r <= 16) orth_gs_tile<1>(Q, r, step, v, c);
+  else if (tiled && MAXNJ >= 2 && r <= 32) orth_gs_tile<(MAXNJ >= 2 ? 2 : 1)>(Q, r, step, v, c);
+  else if (tiled && MAXNJ >= 4 && r <= 64) orth_gs_tile<(MAXNJ >= 4 ? 4 : 1)>(Q, r, step, v, c);
+  else if (tiled && MAXNJ >= 8 && r <= 128) orth_gs_tile<(MAXNJ >= 8 ? 8 : 1)>(Q, r, step, v, c);
+  else
   for (int pass = 0; pass < 2; ++pass) {
     for (int t = wave; t < step; t += QR_THREADS / 64) {
       double d = 0.0;
@@ -640,12 +699,12 @@ __device__ inline void orth_step(const double *__restrict__ recs, int n_rec, con
 __global__ __launch_bounds__(QR_THREADS) void qr_orth_kernel(
     const double *__restrict__ recs, int n_rec, const double *__restrict__ taus, int n_tau, int first, int r,
     int step, double *__restrict__ Q, int64_t *__restrict__ piv, double *__restrict__ gap,
-    double *__restrict__ okflag, unsigned *__restrict__ zero_me) {
+    double *__restrict__ okflag, unsigned *__restrict__ zero_me, int tiled) {
   __shared__ double v[SPR_MAX_R_WIDE], c[SPR_MAX_R_WIDE];
   __shared__ double red[QR_THREADS / 64];
   __shared__ int win;
   if (zero_me && threadIdx.x == 0) *zero_me = 0u;          // ticket counter of the fused step kernels that follow
-  orth_step(recs, n_rec, taus, n_tau, first, r, step, Q, piv, gap, okflag, v, c, red, &win);
+  orth_step(recs, n_rec, taus, n_tau, first, r, step, Q, piv, gap, okflag, v, c, red, &win, tiled);
 }
 
 // |p - c| < d_min with the reference's arithmetic (np.linalg.norm of the difference, :649-652)
@@ -700,13 +759,13 @@ __global__ __launch_bounds__(QR_THREADS) void qr_step_fused_kernel(
     double *__restrict__ Q, int64_t *__restrict__ piv, double *__restrict__ gap, double *__restrict__ okflag, int step,
     int do_next, const double *__restrict__ tau, double *__restrict__ cand_res, double *__restrict__ rec,
     const double *__restrict__ xyz, int dim, int64_t n_points, double d_min, double *__restrict__ partial,
-    unsigned *__restrict__ ticket) {
+    unsigned *__restrict__ ticket, int tiled) {
   constexpr int RPW = 64 / LPR, NWV = QR_THREADS / 64;
   __shared__ double sv1[NWV], sv2[NWV];
   __shared__ long long si1[NWV];
   __shared__ int spos[NWV];
   __shared__ int s_last;
-  __shared__ double ov[SPR_MAX_R], oc[SPR_MAX_R], ored[NWV];
+  __shared__ double ov[SPR_MAX_R], oc[4 * SPR_MAX_R], ored[NWV];   // oc: 64 NJ doubles for the tiled Gram-Schmidt passes
   __shared__ int owin;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / LPR, lig = lane % LPR;
@@ -799,7 +858,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_step_fused_kernel(
   for (int k = threadIdx.x; k < r; k += QR_THREADS) rec[3 + k] = (gp >= 0) ? cand_U[(int64_t)gp * ldc + k] : 0.0;
   if (!do_next) return;
   __syncthreads();                                           // the record is complete for every thread of this workgroup
-  orth_step(rec, 1, tau, 1, 0, r, step + 1, Q, piv, gap, okflag, ov, oc, ored, &owin);
+  orth_step<(LPR >= 64 ? 8 : LPR >= 32 ? 4 : LPR >= 16 ? 2 : 1)>(rec, 1, tau, 1, 0, r, step + 1, Q, piv, gap, okflag, ov, oc, ored, &owin, tiled);
 }
 
 // the same for rows longer than 128 entries: 64 lanes per row, each walks its column pairs
@@ -869,6 +928,12 @@ __global__ void mask_rows_kernel(TU *__restrict__ Ur, int64_t n_rows, int r, int
     const int64_t row = e / r;
     if (!mask[row]) Ur[row * ldu + (e - row * r)] = (TU)0;
   }
+}
+
+// SPR_QR_ORTH_TILE=0: the Gram-Schmidt passes of a step as chains of loads (the form before round 5's orth_gs_tile; A/B only)
+int orth_tiled() {
+  static const int on = [] { const char *e = getenv("SPR_QR_ORTH_TILE"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on;
 }
 
 int pick_lpr(int r) {
@@ -1329,7 +1394,7 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   const int lpr = pick_lpr(r);
   const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows) * QR_TOPT;
   hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_recs, (int)n_rec, d_taus, (int)n_tau,
-                     (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok, (unsigned *)nullptr);
+                     (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok, (unsigned *)nullptr, orth_tiled());
   SPR_LAUNCH_CHECK();
   const int rows_per_block = (QR_THREADS / 64) * (64 / lpr);
   int grid = (n_cand + rows_per_block - 1) / rows_per_block;
@@ -1393,11 +1458,11 @@ extern "C" int spr_qr_steps_f64(int64_t n_rows, int32_t r, int32_t step0, int32_
     double *partial = w.tops;
     unsigned *ticket = reinterpret_cast<unsigned *>(w.tops + 4 * 256);
     hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_rec, 1, d_tau, 1, (int)(first_exact != 0), (int)r,
-                       (int)step0, d_Q, d_piv, d_gap, d_ok, ticket);
+                       (int)step0, d_Q, d_piv, d_gap, d_ok, ticket, orth_tiled());
     SPR_LAUNCH_CHECK();
     for (int t = 0; t < n_steps; ++t) {
       const int step = step0 + t, do_next = (t + 1 < n_steps);
-#define FS(L) hipLaunchKernelGGL(qr_step_fused_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q, d_piv, d_gap, d_ok, step, do_next, d_tau, w.cand_res, d_rec, d_xyz, (int)xyz_dim, n_points, d_min, partial, ticket); break
+#define FS(L) hipLaunchKernelGGL(qr_step_fused_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q, d_piv, d_gap, d_ok, step, do_next, d_tau, w.cand_res, d_rec, d_xyz, (int)xyz_dim, n_points, d_min, partial, ticket, orth_tiled()); break
       switch (lpr) {
         case 1: FS(1);
         case 2: FS(2);

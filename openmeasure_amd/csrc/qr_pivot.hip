@@ -1393,12 +1393,36 @@ extern "C" int spr_qr_step_f64(int64_t n_rows, int32_t r, int32_t step, const do
   QrWs w(d_workspace, r);
   const int lpr = pick_lpr(r);
   const int ldc = r + (r & 1), n_cand = sweep_grid(n_rows) * QR_TOPT;
+  static const bool fused_on = [] { const char *e = getenv("SPR_QR_FUSED_STEPS"); return !(e && e[0] == '0'); }();
+  const bool fused = fused_on && r <= SPR_MAX_R;
+  // fused: the down-dating and the search for the next best candidate in ONE launch behind the orthogonalisation (the step
+  // kernel of spr_qr_steps_f64 with do_next = 0: every workgroup leaves its best, the last one merges them and writes the
+  // record) instead of a down-date launch and a one-workgroup scan of all candidates (16 us) -- two launches per step of a
+  // sharded placement instead of three.  The block lists of the last sweep are dead while steps run: their space holds the
+  // partial results and the ticket, which qr_orth_kernel zeroes.
+  double *partial = w.tops;
+  unsigned *ticket = reinterpret_cast<unsigned *>(w.tops + 4 * 256);
   hipLaunchKernelGGL(qr_orth_kernel, dim3(1), dim3(QR_THREADS), 0, st, d_recs, (int)n_rec, d_taus, (int)n_tau,
-                     (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok, (unsigned *)nullptr, orth_tiled());
+                     (int)first, (int)r, (int)step, d_Q, d_piv, d_gap, d_ok, fused ? ticket : (unsigned *)nullptr, orth_tiled());
   SPR_LAUNCH_CHECK();
   const int rows_per_block = (QR_THREADS / 64) * (64 / lpr);
   int grid = (n_cand + rows_per_block - 1) / rows_per_block;
   if (grid > 256) grid = 256;
+  if (fused) {
+#define FS1(L) hipLaunchKernelGGL(qr_step_fused_kernel<L>, dim3(grid), dim3(QR_THREADS), 0, st, w.cand_U, n_cand, (int)r, ldc, w.cand_idx, d_Q, d_piv, d_gap, d_ok, (int)step, 0, d_taus, w.cand_res, d_rec, d_xyz, (int)xyz_dim, n_points, d_min, partial, ticket, orth_tiled()); break
+    switch (lpr) {
+      case 1: FS1(1);
+      case 2: FS1(2);
+      case 4: FS1(4);
+      case 8: FS1(8);
+      case 16: FS1(16);
+      case 32: FS1(32);
+      default: FS1(64);
+    }
+#undef FS1
+    SPR_LAUNCH_CHECK();
+    return SPR_OK;
+  }
   if (r > SPR_MAX_R) {
     int gw = (n_cand + QR_THREADS / 64 - 1) / (QR_THREADS / 64);
     if (gw > 1024) gw = 1024;

@@ -308,8 +308,6 @@ class P2PFieldGather:
                 s.wait_event(ev)
             field = self.base + b * self.field_bytes
             release_value = max(self.k - self.n_buf + 1, 0)
-            if os.environ.get('SPR_P2P_EXPERIMENT') == 'norelease':   # measurement only: pushes do not wait for the peers' release
-                release_value = 0
             _lib.check(self.lib.spr_field_gather_p2p(
                 field, n_total, n_p, int(first), int(n_loc), len(self.peers),
                 _ptr_array([self.peer_base[q] + b * self.field_bytes for q in self.peers]),

@@ -18,8 +18,10 @@ def short(n):
     return n.split('(')[0][:48]
 
 
-# placements: from one qr_tops_from_norms_kernel / qr_refresh kernel that opens a placement to the last qr_* kernel before the next
-starts = [i for i, (s, e, n) in enumerate(rows) if 'qr_tops_from_norms' in n]
+# placements: from the kernel that opens one (qr_tops_from_norms_kernel, or the initialising sweep qr_refresh_*<.., true>) to the
+# last qr_* kernel before the next
+starts = [i for i, (s, e, n) in enumerate(rows)
+          if 'qr_tops_from_norms' in n or ('qr_refresh' in n and ', true>(' in n)]
 runs = []
 for a, b in zip(starts, starts[1:] + [len(rows)]):
     seg = [(s, e, short(n)) for s, e, n in rows[a:b]]

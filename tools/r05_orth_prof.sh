@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 out=gpurun_out/${1:-r05_orth_prof}; mkdir -p $out
 export TMPDIR=/tmp
-for wl in ${WLS:-c3 c2}; do for tile in 0 1; do
+for wl in ${WLS:-c3 c2}; do for tile in ${TILES:-0 1}; do
   export SPR_QR_ORTH_TILE=$tile
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${wl}_tile$tile -o p -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu > $out/${wl}_tile$tile.json 2> $out/${wl}_tile$tile.err || { tail -5 $out/${wl}_tile$tile.err; exit 1; }
   f=$(find $out/${wl}_tile$tile -name "*kernel_stats.csv" | head -1)

@@ -242,7 +242,7 @@ int spr_project_stream_f64(const double *d_X, int64_t n_rows, int32_t m, int64_t
  * (spr_qr_init_*).  These variants write d_rownorm2[n_rows] -- the norms of the values AS STORED, i.e. rounded to the
  * basis type first -- from the accumulators of the projection that stores d_Ur, and spr_qr_init_norms_* starts the
  * pivoting from that vector (8 bytes per row instead of r values).  Same arguments and results otherwise.
- * spr_project_norms_*        only the W-stationary form produces norms (m = 128 / 192 / 256 packed rows, 16-byte aligned,
+ * spr_project_norms_*        only the W-stationary form produces norms (m = 64 / 128 / 192 / 256 packed rows, 16-byte aligned,
  *                            r <= 64, n_rows >= 4096): spr_project_norms_supported() says whether a shape qualifies;
  *                            SPR_E_UNSUPPORTED and nothing launched otherwise.
  * spr_project_stream_norms_* every shape spr_project_stream_* takes (any m, r <= SPR_MAX_R per call). */

@@ -274,7 +274,7 @@ int project_entry(const char *who, const TX *d_X, int64_t n_rows, int32_t m, int
   }
   // the general kernel spreads a row's columns over several waves: no row norms from it (spr_project_stream_norms_*
   // takes every shape)
-  SPR_REQUIRE(!d_rownorm2, SPR_E_UNSUPPORTED, "%s: row norms only come from the W-stationary form (m = 128/192/256 packed, "
+  SPR_REQUIRE(!d_rownorm2, SPR_E_UNSUPPORTED, "%s: row norms only come from the W-stationary form (m = 64/128/192/256 packed, "
               "r <= 64); use spr_project_stream_norms_* for m=%d r=%d", who, m, r);
 #define PJ(MTV) return launch_rt<MTV, TX, TU>(rt, d_X, n_rows, m, ldx, row0, n_points, n_features, center, d_inv_scale, d_rowmean, d_W, r, d_Ur, ldu, accumulate, d_acc_in, lda, st)
   switch (spr_round_mt(m)) {
@@ -340,7 +340,7 @@ extern "C" int32_t spr_project_norms_supported(int32_t m, int32_t r, int64_t n_r
   const char *e = getenv("SPR_PROJECT_WS");
   if (e && e[0] == '0') return 0;
   const size_t es = x_is_f32 ? sizeof(float) : sizeof(double);
-  return (m == 128 || m == 192 || m == 256) && r >= 1 && r <= 64 && n_rows >= 4096 && (es * ldx) % 16 == 0 &&
+  return (m == 64 || m == 128 || m == 192 || m == 256) && r >= 1 && r <= 64 && n_rows >= 4096 && (es * ldx) % 16 == 0 &&
          (reinterpret_cast<uintptr_t>(d_X) & 15) == 0;
 }
 

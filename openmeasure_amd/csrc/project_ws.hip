@@ -211,7 +211,10 @@ int ws_launch(const TX *X, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
   const int cus = spr_cached_cus();
   SegPlan plan;
   plan.row0 = row0; plan.n_rows = n_rows; plan.n_points = n_points; plan.n_features = n_features;
-  plan.total_wg = cus > 0 ? cus : 256;                 // the LDS image of W allows one workgroup per CU
+  // the LDS image of W allows one workgroup per CU at m = 256; the narrow image of m = 64 (16-32 KB; HBM-bound shape) leaves
+  // room for more rows in flight: SPR_WS_WG_PER_CU workgroups per CU there (default 2)
+  static const int narrow_per_cu = [] { const char *e = getenv("SPR_WS_WG_PER_CU"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();
+  plan.total_wg = (cus > 0 ? cus : 256) * (MT <= 4 ? narrow_per_cu : 1);
   plan.chunk_rows = WS_ROWS;
   const int grid = seg_total_wgs(plan);
   // only the packed, 16-byte-aligned layout is built (one 64-byte piece per row and wave instruction); anything else
@@ -250,7 +253,7 @@ int spr_project_ws(const TX *d_X, int64_t n_rows, int32_t m, int64_t ldx, int64_
 #ifdef PROJ_WS_LAB
   WS(16, 4);
 #else
-  WS(8, 2); WS(8, 4); WS(12, 2); WS(12, 4); WS(16, 2); WS(16, 4);
+  WS(4, 2); WS(4, 4); WS(8, 2); WS(8, 4); WS(12, 2); WS(12, 4); WS(16, 2); WS(16, 4);
 #endif
 #undef WS
   return SPR_E_UNSUPPORTED;

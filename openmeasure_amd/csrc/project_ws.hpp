@@ -2,7 +2,7 @@
 #pragma once
 #include "common.hpp"
 
-// SPR_OK when launched; SPR_E_UNSUPPORTED when the shape is outside its range (m not 128/192/256 packed and 16-byte
+// SPR_OK when launched; SPR_E_UNSUPPORTED when the shape is outside its range (m not 64/128/192/256 packed and 16-byte
 // aligned, r > 64, accumulate) -- the caller then launches the general kernel.  Other codes are errors.
 // d_rownorm2 != NULL: the squared norms of the stored rows of Ur are written there as well (n_rows doubles).
 template <typename TX, typename TU>

@@ -792,7 +792,7 @@ class ROM:
     #: every row it wrote (8 bytes per row), and optimal_placement('qr') starts from that vector instead of reading the
     #: whole basis once more (one sweep of 46 GB less at BASELINE config 3; same sensors).  None ("auto", the default of
     #: SPR): whenever the projection kernel the shape takes anyway produces them at no measurable cost (the W-stationary
-    #: and the streamed-W kernel: every BASELINE shape but config 1/2); True: always (m <= 256 shapes outside the
+    #: and the streamed-W kernel: every BASELINE shape but config 1); True: always (m <= 256 shapes outside the
     #: W-stationary kernel's range then run the streamed-W kernel); False (ROM, whose users never place sensors): never.
     placement_norms = False
 

@@ -74,7 +74,7 @@ extern "C" {
  * spr_field_unstage_blocks_f64).  A binding written for another value must refuse to
  * call into this library: openmeasure_amd/_lib.py compares spr_abi_version() with the value its prototypes were
  * written for. */
-#define SPR_ABI_VERSION 3
+#define SPR_ABI_VERSION 4
 int spr_abi_version(void);
 const char *spr_last_error(void);
 /* number of compute units of the current device (used to size persistent grids) */
@@ -334,6 +334,10 @@ int spr_field_unstage_blocks_f64(const double *d_stage, int32_t world, int32_t n
  *                                  handle can only be taken of the base pointer of an allocation.
  *   spr_p2p_open / spr_p2p_close   map / unmap a buffer exported by ANOTHER process of this node (peer access is enabled
  *                                  lazily); the handle bytes travel through any channel the caller has (torch.distributed).
+ *   spr_p2p_device_id / _peer_access   the PCI bus id of the current device (>= 16 bytes at h_buf), and whether the current
+ *                                  device IS the one with a given bus id or may access its memory (*h_can = 1 / 0; 0 also
+ *                                  for a device this process cannot see).  Exchanged next to the handles: a write into
+ *                                  mapped memory of a GPU without peer access is a memory fault, not an error code.
  *   spr_p2p_signal / spr_p2p_wait  hipStreamWriteValue64 / hipStreamWaitValue64(>=) on a 64-bit counter inside such a
  *                                  buffer (own or mapped); used on the copy streams.
  *   spr_p2p_flags_set / _wait      ONE single-wave kernel that raises / awaits n <= 128 counters (host table of device
@@ -360,6 +364,8 @@ int spr_p2p_alloc(size_t n_bytes, int32_t kind, void **d_ptr, void *h_handle);
 int spr_p2p_free(void *d_ptr);
 int spr_p2p_open(const void *h_handle, void **d_mapped);
 int spr_p2p_close(void *d_mapped);
+int spr_p2p_device_id(char *h_buf, int32_t n_buf);
+int spr_p2p_peer_access(const char *h_bus_id, int32_t *h_can);
 int spr_p2p_signal(void *d_flag, uint64_t value, void *stream);
 int spr_p2p_wait(void *d_flag, uint64_t value, void *stream);
 int spr_p2p_flags_set(void *const *d_flags, int32_t n, uint64_t value, void *stream);

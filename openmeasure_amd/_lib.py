@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SPR_HIP_LIBRARY: load another build of the same library (the ASan host build of `make asan`, tests only)
 LIB_PATH = os.environ.get('SPR_HIP_LIBRARY') or os.path.join(_HERE, 'libspr_hip.so')
 
-SPR_ABI_VERSION = 3          # include/spr_hip.h: the value these prototypes were written for
+SPR_ABI_VERSION = 4          # include/spr_hip.h: the value these prototypes were written for
 SPR_MAX_M = 256
 SPR_MAX_M_WIDE = 512
 SPR_MAX_R = 128
@@ -75,6 +75,8 @@ PROTOTYPES = {
     'spr_p2p_free': (C.c_int, [_p]),
     'spr_p2p_open': (C.c_int, [_p, _p]),
     'spr_p2p_close': (C.c_int, [_p]),
+    'spr_p2p_device_id': (C.c_int, [_p, _i32]),
+    'spr_p2p_peer_access': (C.c_int, [_p, _p]),
     'spr_p2p_signal': (C.c_int, [_p, _u64, _p]),
     'spr_p2p_wait': (C.c_int, [_p, _u64, _p]),
     'spr_p2p_flags_set': (C.c_int, [_p, _i32, _u64, _p]),

@@ -77,6 +77,38 @@ extern "C" int spr_p2p_open(const void *h_handle, void **d_mapped) {
   return SPR_OK;
 }
 
+// Which GPU is this process on, in a form another process can compare: the PCI bus id of the current device ("0000:c1:00.0").
+// Ranks exchange it next to their handles, so that nobody maps -- and then WRITES to -- memory of a device its own GPU has no
+// peer access to (or cannot even see: HIP_VISIBLE_DEVICES differs per process): such a write is a memory fault, not an error code.
+extern "C" int spr_p2p_device_id(char *h_buf, int32_t n_buf) {
+  SPR_REQUIRE(h_buf && n_buf >= 16, SPR_E_INVALID, "spr_p2p_device_id: buffer of at least 16 bytes");
+  int dev = 0;
+  SPR_HIP_TRY(hipGetDevice(&dev));
+  SPR_HIP_TRY(hipDeviceGetPCIBusId(h_buf, n_buf, dev));
+  return SPR_OK;
+}
+
+// *h_can = 1 when the device with that bus id IS the current device or the current device may access its memory
+// (hipDeviceCanAccessPeer), 0 when not -- including a device this process cannot see.
+extern "C" int spr_p2p_peer_access(const char *h_bus_id, int32_t *h_can) {
+  SPR_REQUIRE(h_bus_id && h_can, SPR_E_INVALID, "spr_p2p_peer_access: NULL pointer");
+  *h_can = 0;
+  int dev = 0, peer = -1;
+  SPR_HIP_TRY(hipGetDevice(&dev));
+  if (hipDeviceGetByPCIBusId(&peer, h_bus_id) != hipSuccess) {
+    (void)hipGetLastError();                                   // not visible here: an answer, not a failure
+    return SPR_OK;
+  }
+  if (peer == dev) {
+    *h_can = 1;
+    return SPR_OK;
+  }
+  int can = 0;
+  SPR_HIP_TRY(hipDeviceCanAccessPeer(&can, dev, peer));
+  *h_can = can ? 1 : 0;
+  return SPR_OK;
+}
+
 extern "C" int spr_p2p_close(void *d_mapped) {
   if (d_mapped) SPR_HIP_TRY(hipIpcCloseMemHandle(d_mapped));
   return SPR_OK;

@@ -38,6 +38,8 @@ from . import _lib
 
 _FLAG_BYTES = 4096
 _SCRATCH_BYTES = 4096
+_REASON_BYTES = 200                  # a rank's verdict and the reason it gives, all-gathered (_agree)
+_BUS_ID_BYTES = 24                   # "0000:c1:00.0" and its terminator, with room
 _MAX_WORLD = 100                     # 5 counter arrays of `world` uint64 in the 4 KB counter page
 _KINDS = {'coarse': 0, 'fine': 1, 'uncached': 2}
 
@@ -164,16 +166,31 @@ class P2PFieldGather:
                     self.peer_base[q] = self.base + q * self.n_buf * need
                     self.peer_fbase[q] = self.fbase
             return ok, why
-        # every rank's handle bytes and whether it has buffers at all: one exchange, so that all ranks go on or give up together
-        mine = np.zeros(2 * hb + 8, dtype=np.uint8)
+        # every rank's handle bytes, the GPU it is on and whether it has buffers at all: one exchange, so that all ranks go on
+        # or give up together
+        mine = np.zeros(2 * hb + 8 + _BUS_ID_BYTES, dtype=np.uint8)
         mine[:hb] = np.frombuffer(bytes(h_field), dtype=np.uint8)
         mine[hb:2 * hb] = np.frombuffer(bytes(h_flags), dtype=np.uint8)
+        if ok:
+            try:
+                bus = C.create_string_buffer(_BUS_ID_BYTES)
+                _lib.check(self.lib.spr_p2p_device_id(bus, _BUS_ID_BYTES), 'spr_p2p_device_id')
+                mine[2 * hb + 8:] = np.frombuffer(bus.raw, dtype=np.uint8)
+            except Exception as exc:                           # noqa: BLE001
+                ok, why = False, f'rank {self.rank}: {exc}'
         mine[2 * hb] = 1 if ok else 0
-        allh = self.eng.to_host(self._all_gather(torch.tensor(mine, device=self.eng.device)))      # (world, 2 hb + 8)
-        if not allh[:, 2 * hb].all():
-            bad = [int(q) for q in np.flatnonzero(allh[:, 2 * hb] == 0)]
-            return False, why or f'ranks {bad} could not allocate exportable buffers'
+        allh = self.eng.to_host(self._all_gather(torch.tensor(mine, device=self.eng.device)))      # (world, 2 hb + 8 + id)
+        if not allh[:, 2 * hb].all():                          # somebody has no buffers: every rank learns why
+            return self._agree(ok, why, 'could not allocate exportable buffers')
         try:
+            for q in self.peers:
+                # BEFORE anything of peer q is mapped: may my GPU write to the GPU q is on?  (A write into mapped memory of a
+                # device without peer access -- or one this process cannot see -- is a memory fault, not an error code.)
+                bus_q = bytes(allh[q, 2 * hb + 8:].astype(np.uint8)).split(b'\0')[0]
+                can = C.c_int32(0)
+                _lib.check(self.lib.spr_p2p_peer_access(C.c_char_p(bus_q), C.byref(can)), 'spr_p2p_peer_access')
+                if not can.value:
+                    raise P2PUnavailable(f"the GPU of rank {q} ({bus_q.decode(errors='replace')}) is not peer-accessible from here")
             for q in self.peers:
                 for lo, table in ((0, self.peer_base), (hb, self.peer_fbase)):
                     hq = (C.c_ubyte * hb)(*allh[q, lo:lo + hb].tolist())
@@ -183,6 +200,24 @@ class P2PFieldGather:
         except Exception as exc:                               # noqa: BLE001
             ok, why = False, f'rank {self.rank}: {exc}'
         return self._selftest(ok, why, kind)
+
+    def _agree(self, ok, why, what):
+        """-> (ok on ALL ranks, reason).  COLLECTIVE: one all-gather of every rank's verdict AND its reason, so that every rank
+        reports why the first failing rank failed instead of only that it did."""
+        torch = self.eng.torch
+        msg = np.zeros(_REASON_BYTES, dtype=np.uint8)
+        msg[0] = 1 if ok else 0
+        if not ok:
+            raw = np.frombuffer((why or what).encode('utf-8', errors='replace')[:_REASON_BYTES - 2], dtype=np.uint8)
+            msg[1:1 + len(raw)] = raw
+        allm = self.eng.to_host(self._all_gather(torch.tensor(msg, device=self.eng.device))).astype(np.uint8)
+        bad = [int(q) for q in np.flatnonzero(allm[:, 0] == 0)]
+        if not bad:
+            return True, ''
+        first = bytes(allm[bad[0], 1:]).split(b'\0')[0].decode('utf-8', errors='replace')
+        if not first.startswith(f'rank {bad[0]}'):
+            first = f'rank {bad[0]}: {first}'
+        return False, first + (f' (ranks {bad} failed)' if len(bad) > 1 else '')
 
     # counter page (int64 words): arrive[b][src] | release[src] | pushed[peer] | self-test[src]
     def _slot(self, kind, idx, b=0):
@@ -214,11 +249,7 @@ class P2PFieldGather:
         cur = torch.cuda.current_stream(eng.device)
 
         def agree(flag, reason):
-            oks = eng.to_host(self._all_gather(torch.tensor([1.0 if flag else 0.0], device=eng.device))).reshape(-1)
-            if oks.all():
-                return True, ''
-            bad = [int(q) for q in np.flatnonzero(oks == 0)]
-            return False, reason or f'{kind} memory: self-test failed on ranks {bad}'
+            return self._agree(flag, reason, f'{kind} memory: self-test failed')
 
         def unblock():
             self._flags[self._slot('test', 0):self._slot('test', 0) + self.world] = 1 << 40

@@ -2085,14 +2085,12 @@ class ROM:
                     ok, why = False, f'rank {rank}: the blocks of ranks {bad} differ from what those ranks sent'
             except RuntimeError as exc:
                 ok, why = False, str(exc)
-        oks = eng.to_host(self._all_gather(t.tensor([1.0 if ok else 0.0], device=eng.device))).reshape(-1)
-        if oks.all():
+        all_ok, why = px._agree(ok, why, 'the exchange failed')      # every rank's verdict and the first failing rank's reason
+        if all_ok:
             px.verified = dict(blocks=int(lay.shape[0]), bytes_per_block=int(n_p * n_loc * 8), check='per-block int64 sums')
             if to_host:
                 return eng.to_host(out).T
             return out if wait else PendingField(out)
-        failed = [int(q) for q in np.flatnonzero(oks == 0)]
-        why = why or f'ranks {failed} reported a failed exchange'
         px.abandon()
         self._p2p_dropped = self.__dict__.pop('_p2p')          # stays allocated: peers have it mapped; never used again
         if (os.environ.get('SPR_GATHER') or self._shard.gather) == 'p2p':

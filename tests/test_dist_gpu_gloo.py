@@ -229,7 +229,38 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         from tests.conftest import load_golden
         eng = HipEngine('cuda:0')
         res = {}
-        if case == 'fallback':
+        if case == 'no_peer_access':
+            # the GPU of a peer is not peer-accessible from one rank (another hive, a device the process cannot see): known
+            # BEFORE anything is mapped, every rank on the collective path, with the reason
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            n_loc = n // world
+            row0 = rank * n_loc
+            real = eng.lib.spr_p2p_peer_access
+            opened = []
+            real_open = eng.lib.spr_p2p_open
+            if rank == world - 1:
+                def no_access(bus, can):
+                    can._obj.value = 0
+                    return 0
+                eng.lib.spr_p2p_peer_access = no_access
+                eng.lib.spr_p2p_open = lambda *a: opened.append(1) or real_open(*a)
+            try:
+                spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+                spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+                X3 = spr.reconstruct(g['Ar_pred3'] * np.sign(np.sum(spr.Ar * g['Ar'], axis=0)))
+            finally:
+                eng.lib.spr_p2p_peer_access = real
+                eng.lib.spr_p2p_open = real_open
+            import ctypes as C
+            bus = C.create_string_buffer(24)
+            assert eng.lib.spr_p2p_device_id(bus, 24) == 0 and len(bus.value) >= 7
+            can = C.c_int32(-1)
+            assert eng.lib.spr_p2p_peer_access(bus, C.byref(can)) == 0 and can.value == 1       # my own device
+            assert eng.lib.spr_p2p_peer_access(C.c_char_p(b'ffff:ff:1f.7'), C.byref(can)) == 0 and can.value == 0
+            res = dict(path=str(spr.gather_path_), X3=X3, opened=len(opened), bus=bus.value.decode())
+        elif case == 'fallback':
             # one rank cannot map its peers (another node, no interprocess handles): EVERY rank must end up on the collective
             # path, with the reason, and the results must not care
             g = load_golden('g3_num8')
@@ -350,7 +381,7 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['fallback', 'timeout', 'first_mismatch', 'first_timeout'])
+@pytest.mark.parametrize('case', ['fallback', 'no_peer_access', 'timeout', 'first_mismatch', 'first_timeout'])
 def test_p2p_exchange_edges(tmp_path, case):
     """round 5: the p2p field exchange when it cannot be had (one rank cannot map its peers -> every rank on the collective path,
     or every rank raising when p2p was demanded), when a peer never pushes (the join kernel's wall-clock exit + check()), and
@@ -360,7 +391,15 @@ def test_p2p_exchange_edges(tmp_path, case):
     world = 2
     mp.spawn(_p2p_edge_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'edge{r}.npz') for r in range(world)]
-    if case == 'fallback':
+    if case == 'no_peer_access':
+        from tests.conftest import load_golden
+        from tests.parity import REL_FRO, rel_fro
+        g = load_golden('g3_num8')
+        for o in outs:
+            assert str(o['path']).startswith('rccl (p2p unavailable') and 'not peer-accessible' in str(o['path']), o['path']
+            assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO
+        assert int(outs[-1]['opened']) == 0                   # the rank without access mapped nothing
+    elif case == 'fallback':
         from tests.conftest import load_golden
         from tests.parity import REL_FRO, rel_fro
         g = load_golden('g3_num8')

@@ -38,7 +38,7 @@ def test_native_library_is_loaded(eng):
     maps = open(f'/proc/{os.getpid()}/maps').read()
     assert 'libspr_hip.so' in maps
     from openmeasure_amd import _lib
-    assert eng.lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 3
+    assert eng.lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 4
 
 
 def test_golden_fixture(golden, eng):

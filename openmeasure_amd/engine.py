@@ -95,10 +95,14 @@ class HipEngine:
         return out
 
     _HOST_STAGE_BYTES = 64 << 20
+    #: results above this size come back in a page-locked tensor of their own (_to_host_big: one DMA at the PCIe rate, the ndarray
+    #: handed out IS that memory, counted against the budget of _pinned_result); below it through the shared pinned stage and a
+    #: host copy -- 1.8 of the 2.7 ms a 32 MB field took to reach the caller at config 2 were that copy into fresh pages
+    _PINNED_MIN_BYTES = 4 << 20
 
     def to_host(self, t, then=None):
         """Device tensor -> fresh host ndarray.  ``then``: called after the copy has been ENQUEUED and before the host
-        blocks on it -- work it launches queues up behind the copy (fit()'s gap filler).  Results up to 64 MiB (statistics, Gram blocks, flags, Theta,
+        blocks on it -- work it launches queues up behind the copy (fit()'s gap filler).  Results up to 4 MiB (statistics, Gram blocks, flags, Theta,
         coefficient vectors) come back through a pinned buffer: a D2H copy into pageable memory in the middle of
         fit() left the compute queue stalled for 10/20/30 ms in every other call at config 3 (tools/fit_probe.py:
         gap between the Gram and projection kernels 3.9 ms with the pinned target, 4-37 ms without)."""
@@ -108,7 +112,7 @@ class HipEngine:
         if (0 < nbytes <= self._DL_KERNEL_BYTES and nbytes % 8 == 0 and t.is_cuda and t.is_contiguous() and t.data_ptr() % 8 == 0
                 and str(t.dtype) in _NP_OF and self._dl_kernel):
             return self._to_host_small(t, nbytes, then)
-        if nbytes == 0 or nbytes > self._HOST_STAGE_BYTES or not t.is_cuda:
+        if nbytes == 0 or nbytes > self._PINNED_MIN_BYTES or not t.is_cuda:
             out = self._to_host_big(t) if (t.is_cuda and nbytes) else t.cpu().numpy()
             if then is not None:
                 then()
@@ -221,7 +225,7 @@ class HipEngine:
         return arr
 
     def _to_host_big(self, t):
-        """Results above 64 MiB -- the (n, n_p) field reconstruct() returns to the caller, sparse_sensing.py:371-375 -- land in
+        """Results above _PINNED_MIN_BYTES (4 MiB) -- the (n, n_p) field reconstruct() returns to the caller, sparse_sensing.py:371-375 -- land in
         a page-locked tensor of their own, one asynchronous copy at the PCIe rate (57 GB/s against 10 GB/s into pageable
         memory, tools/transfer_probe.py); the ndarray handed back is that memory."""
         torch = self.torch
@@ -296,7 +300,7 @@ class HipEngine:
         torch = self.torch
         n, r, ldu = self._check_matrix(Ur)
         n_p = A.shape[0]
-        if n * n_p * 8 <= self._HOST_STAGE_BYTES or rowmean.shape[0] != n:
+        if n * n_p * 8 <= 4 * self._PINNED_MIN_BYTES or rowmean.shape[0] != n:
             return None
         host = self._pinned_result((n_p, n), torch.float64)
         if host is None:

@@ -1707,7 +1707,7 @@ def test_field_unstage_kernel(eng):
 
 
 def test_pinned_result_budget(eng, monkeypatch):
-    """Host results above 64 MiB are page-locked memory; the ones the caller still holds are counted against a budget and a
+    """Host results above 4 MiB are page-locked memory; the ones the caller still holds are counted against a budget and a
     result beyond it falls back to the pageable copy -- same values either way."""
     import torch
     t = torch.arange(10_000_000, dtype=torch.float64, device='cuda')          # 80 MB

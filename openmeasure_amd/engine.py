@@ -47,6 +47,33 @@ class HipEngine:
         self._dl_kernel = os.environ.get('SPR_DL_KERNEL', '1') != '0'      # A/B: small downloads by kernel + polled ticket (default) or by copy + event
         self._stage = None                                   # ring of pinned host staging buffers for small uploads
         self._dstage = None                                  # pinned landing buffer for small downloads
+        # page-locked buffers, the copy threads and the side stream go back while the interpreter and the HIP runtime are
+        # still whole (atexit runs before module teardown): what is left to destructors at process exit runs in no
+        # particular order against the runtime's own shutdown
+        import atexit
+        import weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
+
+    def close(self):
+        """Give back what the engine holds outside PyTorch's device allocator: the page-locked staging buffers, the copy
+        threads of the staged downloads.  Idempotent; the engine can be used again afterwards (buffers are
+        made on demand).  Host arrays handed out earlier (page-locked results) stay valid: they own their memory."""
+        torch = self.torch
+        try:
+            torch.cuda.synchronize(self.device)
+        except RuntimeError:
+            pass
+        pool = self.__dict__.pop('_copy_pool', None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+        self._stage = self._dstage = None
+        for k in ('_dstage2', '_dstage_ev', '_dl', '_reuse', '_side'):
+            self.__dict__.pop(k, None)
+        try:
+            torch._C._host_emptyCache()                       # cached page-locked blocks back to the OS
+        except (AttributeError, RuntimeError):
+            pass
 
     # ---- plumbing ---------------------------------------------------------------------
     def _stream(self):

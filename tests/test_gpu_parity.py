@@ -1731,6 +1731,37 @@ def test_pinned_result_budget(eng, monkeypatch):
     eng.__dict__.pop('_pinned_budget', None)                                  # the next to_host() reads the restored environment
 
 
+def test_engine_close_and_reuse(eng):
+    """HipEngine.close() (also registered with atexit): staging buffers, copy threads and cached page-locked blocks go back;
+    host arrays handed out before stay valid (they own their memory) and the engine makes its buffers again on demand."""
+    import torch
+    t = torch.arange(2_000_000, dtype=torch.float64, device='cuda')           # 16 MB: a page-locked result
+    small = torch.arange(1000, dtype=torch.float64, device='cuda')
+    a = eng.to_host(t)
+    s0 = eng.to_host(small)
+    w = eng.upload_reuse(('test', 0), np.arange(12.0).reshape(3, 4))
+    assert torch.equal(w.cpu(), torch.arange(12.0, dtype=torch.float64).reshape(3, 4))
+    big = torch.randn((2_000_003, 5), dtype=torch.float64, device='cuda')
+    ref = big.cpu().numpy()
+    np.testing.assert_array_equal(eng._to_host_staged(big), ref)               # starts the copy threads
+    eng.close()
+    assert eng.__dict__.get('_copy_pool') is None and eng._dstage is None and eng._stage is None
+    np.testing.assert_array_equal(a, np.arange(2_000_000, dtype=np.float64))   # still readable after the engine let go
+    eng.close()                                                                # idempotent
+    np.testing.assert_array_equal(eng.to_host(t), a)
+    np.testing.assert_array_equal(eng.to_host(small), s0)
+    np.testing.assert_array_equal(eng._to_host_staged(big), ref)
+    w = eng.upload_reuse(('test', 0), np.arange(12.0).reshape(3, 4) + 1)
+    assert torch.equal(w.cpu(), torch.arange(12.0, dtype=torch.float64).reshape(3, 4) + 1)
+    X = synth_host(3000, 2, 24, 8, 0.8, 1e-3, 3)
+    from openmeasure_amd.sparse_sensing import SPR
+    spr = SPR(X, 2, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=6)
+    eng.close()                                                                # between two calls of a fitted object
+    spr.optimal_placement()
+    np.testing.assert_array_equal(spr.sensors_, orc.qr_pivots(orc.fit(X, 2, 'number', 6)['Ur'])[0])
+
+
 def test_big_attributes_stream_to_the_host(eng, monkeypatch):
     """t1: `spr.Ur` / `spr.X0` stay obtainable as host ndarrays at sizes that can neither be page-locked as a whole nor be
     materialised next to X in HBM: staged D2H through two pinned buffers, X0 by row blocks -- same values as the one-shot paths."""

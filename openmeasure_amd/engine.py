@@ -122,14 +122,19 @@ class HipEngine:
         return out
 
     _HOST_STAGE_BYTES = 64 << 20
-    #: results above this size come back in a page-locked tensor of their own (_to_host_big: one DMA at the PCIe rate, the ndarray
-    #: handed out IS that memory, counted against the budget of _pinned_result); below it through the shared pinned stage and a
-    #: host copy -- 1.8 of the 2.7 ms a 32 MB field took to reach the caller at config 2 were that copy into fresh pages
+    #: to_host(result=True) -- what is handed to the CALLER: fields, the basis -- above this size comes back in a page-locked
+    #: tensor of its own (_to_host_big: one DMA at the PCIe rate, the ndarray handed out IS that memory, counted against the
+    #: budget of _pinned_result); below it, and for every internal download up to 64 MiB, through the shared pinned stage and a
+    #: host copy -- 1.8 of the 2.7 ms a 32 MB field took to reach the caller at config 2 were that copy into fresh pages.
+    #: Internal downloads stay on the stage: a page-locked block PyTorch's host allocator has just taken back is only reusable
+    #: once the stream that copied into it has passed the point of its release, so a fit() that takes a new one for its 4.7 MB
+    #: Gram block at every call pins fresh memory whenever the stream is busy (+0.6-1.1 ms per step on config 4's block).
     _PINNED_MIN_BYTES = 4 << 20
 
-    def to_host(self, t, then=None):
+    def to_host(self, t, then=None, result=False):
         """Device tensor -> fresh host ndarray.  ``then``: called after the copy has been ENQUEUED and before the host
-        blocks on it -- work it launches queues up behind the copy (fit()'s gap filler).  Results up to 4 MiB (statistics, Gram blocks, flags, Theta,
+        blocks on it -- work it launches queues up behind the copy (fit()'s gap filler).  ``result``: the array goes to the caller
+        (see _PINNED_MIN_BYTES).  Downloads up to 64 MiB (4 MiB for results: statistics, Gram blocks, flags, Theta,
         coefficient vectors) come back through a pinned buffer: a D2H copy into pageable memory in the middle of
         fit() left the compute queue stalled for 10/20/30 ms in every other call at config 3 (tools/fit_probe.py:
         gap between the Gram and projection kernels 3.9 ms with the pinned target, 4-37 ms without)."""
@@ -139,7 +144,7 @@ class HipEngine:
         if (0 < nbytes <= self._DL_KERNEL_BYTES and nbytes % 8 == 0 and t.is_cuda and t.is_contiguous() and t.data_ptr() % 8 == 0
                 and str(t.dtype) in _NP_OF and self._dl_kernel):
             return self._to_host_small(t, nbytes, then)
-        if nbytes == 0 or nbytes > self._PINNED_MIN_BYTES or not t.is_cuda:
+        if nbytes == 0 or nbytes > (self._PINNED_MIN_BYTES if result else self._HOST_STAGE_BYTES) or not t.is_cuda:
             out = self._to_host_big(t) if (t.is_cuda and nbytes) else t.cpu().numpy()
             if then is not None:
                 then()

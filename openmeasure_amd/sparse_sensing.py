@@ -1002,7 +1002,7 @@ class ROM:
     @property
     def Ur(self):
         """(n_local, r) POD basis rows held by this rank."""
-        return self._lazy('Ur', lambda: np.ascontiguousarray(self._engine().to_host(self._fitted('Ur', 'Ur'))))
+        return self._lazy('Ur', lambda: np.ascontiguousarray(self._engine().to_host(self._fitted('Ur', 'Ur'), result=True)))
 
     @Ur.setter
     def Ur(self, value):
@@ -1856,7 +1856,7 @@ class ROM:
             ones = eng.to_device(np.ones(1))
             Thp = Th if Th.shape[1] % 2 == 0 else eng.torch.nn.functional.pad(Th, (0, 1))[:, :Th.shape[1]]
             out = eng.reconstruct(Thp, 0, Th.shape[0], 1, cnt, ones, A_d, rowscale=scl)
-            return out if not to_host else eng.to_host(out).T
+            return out if not to_host else eng.to_host(out, result=True).T
         Ur_d = self._fitted('Ur', 'Ur')
         self._fitted('rowmean', 'X_cnt')
         n_loc = Ur_d.shape[0]
@@ -1932,7 +1932,7 @@ class ROM:
                     return PendingField(out)
         if not to_host:
             return out if wait else PendingField(out)
-        return eng.to_host(out).T                             # (n, n_p), Fortran-ordered view
+        return eng.to_host(out, result=True).T                             # (n, n_p), Fortran-ordered view
 
     # ------------------------------------------------------------------ the field exchange of sharded objects
     def _gather_select(self, n_p, lay):
@@ -2033,7 +2033,7 @@ class ROM:
         close()
         if not to_host:
             return out
-        host = eng.to_host(out).T
+        host = eng.to_host(out, result=True).T
         px.check()                                            # the host has just synchronised: did the join kernel give up?
         return host
 
@@ -2089,7 +2089,7 @@ class ROM:
         if all_ok:
             px.verified = dict(blocks=int(lay.shape[0]), bytes_per_block=int(n_p * n_loc * 8), check='per-block int64 sums')
             if to_host:
-                return eng.to_host(out).T
+                return eng.to_host(out, result=True).T
             return out if wait else PendingField(out)
         px.abandon()
         self._p2p_dropped = self.__dict__.pop('_p2p')          # stays allocated: peers have it mapped; never used again
@@ -2129,7 +2129,7 @@ class ROM:
                 o, k = int(table[q, 0]), int(table[q, 1])
                 out[:, o:o + k] = stage[q, :, :k]
         if to_host:
-            return eng.to_host(out).T
+            return eng.to_host(out, result=True).T
         return out if wait else PendingField(out)
 
 

@@ -40,7 +40,7 @@ class NumpyEngine:
     def to_device(self, a, dtype=None):
         return torch.as_tensor(np.ascontiguousarray(a)).to(dtype or torch.float64).contiguous()
 
-    def to_host(self, t, then=None):
+    def to_host(self, t, then=None, result=False):
         if then is not None:                                  # the HIP engine calls it between enqueueing the copy and blocking on it
             then()
         return t.detach().numpy()

@@ -5,6 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 out=gpurun_out/r05_final; mkdir -p $out
 run() { name=$1; shift; python3 bench.py "$@" > $out/$name.json 2> $out/$name.err || { echo "$name FAILED"; tail -5 $out/$name.err; }; python3 -c "
 import json;d=json.load(open('$out/$name.json'));print('$name', d['ms_per_step'], d['value'], d['hbm_roofline_frac_step'], {k:round(v['ms'],4) for k,v in d['phases'].items() if k!='peaks'}, d['gaps_ms'], d['placement_ms'])"; }
+run bench_default
 run bench_c2_extra --workload c2 --steps 300 --warmup 30 --extra
 run bench_c2_defer --workload c2 --steps 300 --warmup 30 --defer-reconstruct --no-cpu
 run bench_c1_extra --workload c1 --steps 300 --warmup 30 --extra

@@ -1737,7 +1737,8 @@ def test_engine_close_and_reuse(eng):
     import torch
     t = torch.arange(2_000_000, dtype=torch.float64, device='cuda')           # 16 MB: a page-locked result
     small = torch.arange(1000, dtype=torch.float64, device='cuda')
-    a = eng.to_host(t)
+    a = eng.to_host(t, result=True)
+    assert any(w() is a for w, _ in eng._pinned_live)                          # handed out as page-locked memory of its own
     s0 = eng.to_host(small)
     w = eng.upload_reuse(('test', 0), np.arange(12.0).reshape(3, 4))
     assert torch.equal(w.cpu(), torch.arange(12.0, dtype=torch.float64).reshape(3, 4))
@@ -1748,7 +1749,8 @@ def test_engine_close_and_reuse(eng):
     assert eng.__dict__.get('_copy_pool') is None and eng._dstage is None and eng._stage is None
     np.testing.assert_array_equal(a, np.arange(2_000_000, dtype=np.float64))   # still readable after the engine let go
     eng.close()                                                                # idempotent
-    np.testing.assert_array_equal(eng.to_host(t), a)
+    np.testing.assert_array_equal(eng.to_host(t, result=True), a)
+    np.testing.assert_array_equal(eng.to_host(t), a)                           # an internal download: through the shared stage
     np.testing.assert_array_equal(eng.to_host(small), s0)
     np.testing.assert_array_equal(eng._to_host_staged(big), ref)
     w = eng.upload_reuse(('test', 0), np.arange(12.0).reshape(3, 4) + 1)

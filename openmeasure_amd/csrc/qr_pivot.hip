@@ -538,13 +538,23 @@ __global__ __launch_bounds__(1024) void qr_cand_best_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   Best b; b.init();
   int pos = -1;
-  for (int c = threadIdx.x; c < n_cand; c += 1024) {
-    const double v = cand_res[c]; const int64_t gi = cand_idx[c];
-    if (gi >= 0) {
-      const bool better = v > b.v1 || (v == b.v1 && gi < b.i1);
-      b.push(v, gi);
-      pos = better ? c : pos;
+  for (int c0 = threadIdx.x; c0 < n_cand; c0 += 4 * 1024) {   // four candidates per trip: the loads of a trip are independent
+    double v[4];
+    int64_t gi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 1024 * u;
+      const bool in = c < n_cand;
+      v[u] = in ? cand_res[c] : -2.0;
+      gi[u] = in ? cand_idx[c] : -1;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (gi[u] >= 0) {
+        const bool better = v[u] > b.v1 || (v[u] == b.v1 && gi[u] < b.i1);
+        b.push(v[u], gi[u]);
+        pos = better ? c0 + 1024 * u : pos;
+      }
   }
   for (int o = 32; o > 0; o >>= 1) {  // wave reduce carrying the winner's slot
     const double ov1 = __shfl_xor(b.v1, o, 64);
@@ -588,10 +598,8 @@ __global__ __launch_bounds__(1024) void qr_cand_best_kernel(
 // step kernel's last workgroup spent up to 30 us here at step 63 of a 64-column basis, on a critical path of 64+ launches
 // per placement.  part: 4 * 16 * NJ doubles of LDS.  v holds the candidate row on entry (synchronised), the residual on exit.
 template <int NJ>
-__device__ inline void orth_gs_tile(const double *__restrict__ Q, int r, int step, double *v, double *part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = lane & 15, a = threadIdx.x >> 4;
-  double q[NJ][NJ];
+__device__ inline void orth_tile_load(const double *__restrict__ Q, int r, int step, double (&q)[NJ][NJ]) {
+  const int b = threadIdx.x & 15, a = threadIdx.x >> 4;
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
     const int t = a + 16 * i;
@@ -601,6 +609,12 @@ __device__ inline void orth_gs_tile(const double *__restrict__ Q, int r, int ste
       q[i][j] = (t < step && k < r) ? Q[(int64_t)t * r + k] : 0.0;
     }
   }
+}
+
+template <int NJ>
+__device__ inline void orth_tile_apply(const double (&q)[NJ][NJ], int r, double *v, double *part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = lane & 15;
   for (int pass = 0; pass < 2; ++pass) {
     double vk[NJ], u[NJ];
 #pragma unroll
@@ -630,6 +644,27 @@ __device__ inline void orth_gs_tile(const double *__restrict__ Q, int r, int ste
     }
     __syncthreads();
   }
+}
+
+template <int NJ>
+__device__ inline void orth_gs_tile(const double *__restrict__ Q, int r, int step, double *v, double *part) {
+  double q[NJ][NJ];
+  orth_tile_load<NJ>(Q, r, step, q);
+  orth_tile_apply<NJ>(q, r, v, part);
+}
+
+// the residual in v (r doubles of LDS, complete for every thread) -> the unit direction Q[step]; red: one double per wave
+__device__ inline void orth_finish(const double *v, int r, int step, double *__restrict__ Q, double *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int k = threadIdx.x; k < r; k += QR_THREADS) s += v[k] * v[k];
+  s = group_sum(s, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  double nn = 0.0;
+  for (int w = 0; w < QR_THREADS / 64; ++w) nn += red[w];
+  const double inv = (nn > 0.0) ? 1.0 / sqrt(nn) : 0.0;
+  for (int k = threadIdx.x; k < r; k += QR_THREADS) Q[(int64_t)step * r + k] = v[k] * inv;
 }
 
 // one workgroup: pick the winner among the ranks' records, certify it against tau, orthogonalise,
@@ -684,15 +719,7 @@ __device__ inline void orth_step(const double *__restrict__ recs, int n_rec, con
     }
     __syncthreads();
   }
-  double s = 0.0;
-  for (int k = threadIdx.x; k < r; k += QR_THREADS) s += v[k] * v[k];
-  s = group_sum(s, 64);
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
-  double nn = 0.0;
-  for (int w = 0; w < QR_THREADS / 64; ++w) nn += red[w];
-  const double inv = (nn > 0.0) ? 1.0 / sqrt(nn) : 0.0;
-  for (int k = threadIdx.x; k < r; k += QR_THREADS) Q[(int64_t)step * r + k] = v[k] * inv;
+  orth_finish(v, r, step, Q, red);
 }
 
 
@@ -774,6 +801,7 @@ __global__ __launch_bounds__(QR_THREADS) void qr_step_fused_kernel(
   const double q0 = (k0 < r) ? q[k0] : 0.0;
   const double q1 = (k0 + 1 < r) ? q[k0 + 1] : 0.0;
   const int64_t pv = piv[step];
+  const double tau_pre = (do_next && threadIdx.x == 0) ? tau[0] : 0.0;   // for the certification in the last workgroup's tail
   double pc[3] = {0.0, 0.0, 0.0};
   if (xyz)
     for (int d = 0; d < dim; ++d) pc[d] = xyz[(pv % n_points) * dim + d];
@@ -836,6 +864,13 @@ __global__ __launch_bounds__(QR_THREADS) void qr_step_fused_kernel(
   if (!s_last) return;
   __threadfence();
   // ---- last workgroup: merge the partials, write the record
+  // (the directions the NEXT winner will be orthogonalised against -- rows 0 .. step of Q, all final -- are requested first
+  // where they fit the registers: their L2 round trip runs under the merge)
+  constexpr int NJL = LPR >= 64 ? 8 : LPR >= 32 ? 4 : LPR >= 16 ? 2 : 1;     // r <= 2 LPR <= 16 NJL
+  const bool tile_next = tiled != 0 && do_next != 0;
+  double qt[NJL][NJL];
+  constexpr bool EARLY = NJL <= 4;                           // 64 doubles held over the merge would not fit the registers
+  if (EARLY && tile_next) orth_tile_load<NJL>(Q, r, step + 1, qt);
   b.init(); pos = -1;
   for (int p = threadIdx.x; p < (int)gridDim.x; p += QR_THREADS) {
     const volatile double *pp = partial + 4 * (int64_t)p;
@@ -855,10 +890,28 @@ __global__ __launch_bounds__(QR_THREADS) void qr_step_fused_kernel(
   }
   __syncthreads();
   const int gp = spos[0];
-  for (int k = threadIdx.x; k < r; k += QR_THREADS) rec[3 + k] = (gp >= 0) ? cand_U[(int64_t)gp * ldc + k] : 0.0;
+  for (int k = threadIdx.x; k < r; k += QR_THREADS) {
+    const double val = (gp >= 0) ? cand_U[(int64_t)gp * ldc + k] : 0.0;
+    rec[3 + k] = val;
+    if (tile_next) ov[k] = val;                              // the next step's candidate row, without reading the record back
+  }
   if (!do_next) return;
-  __syncthreads();                                           // the record is complete for every thread of this workgroup
-  orth_step<(LPR >= 64 ? 8 : LPR >= 32 ? 4 : LPR >= 16 ? 2 : 1)>(rec, 1, tau, 1, 0, r, step + 1, Q, piv, gap, okflag, ov, oc, ored, &owin, tiled);
+  if (!tile_next) {
+    __syncthreads();                                         // the record is complete for every thread of this workgroup
+    orth_step<NJL>(rec, 1, tau, 1, 0, r, step + 1, Q, piv, gap, okflag, ov, oc, ored, &owin, tiled);
+    return;
+  }
+  // what orth_step does with ONE record, from the values this workgroup still holds: certify the winner against tau (requested
+  // at the start of the kernel), orthogonalise its row against the directions already in registers, store the new direction
+  if (threadIdx.x == 0) {
+    piv[step + 1] = (int64_t)b.i1;
+    if (gap) gap[step + 1] = (b.v1 > 0.0) ? (b.v1 - b.v2) / b.v1 : 0.0;
+    okflag[step + 1] = (b.v1 > tau_pre) ? 1.0 : 0.0;
+  }
+  if (!EARLY) orth_tile_load<NJL>(Q, r, step + 1, qt);
+  __syncthreads();
+  orth_tile_apply<NJL>(qt, r, ov, oc);
+  orth_finish(ov, r, step + 1, Q, ored);
 }
 
 // the same for rows longer than 128 entries: 64 lanes per row, each walks its column pairs

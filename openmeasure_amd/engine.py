@@ -126,9 +126,10 @@ class HipEngine:
     #: tensor of its own (_to_host_big: one DMA at the PCIe rate, the ndarray handed out IS that memory, counted against the
     #: budget of _pinned_result); below it, and for every internal download up to 64 MiB, through the shared pinned stage and a
     #: host copy -- 1.8 of the 2.7 ms a 32 MB field took to reach the caller at config 2 were that copy into fresh pages.
-    #: Internal downloads stay on the stage: a page-locked block PyTorch's host allocator has just taken back is only reusable
-    #: once the stream that copied into it has passed the point of its release, so a fit() that takes a new one for its 4.7 MB
-    #: Gram block at every call pins fresh memory whenever the stream is busy (+0.6-1.1 ms per step on config 4's block).
+    #: Internal downloads stay on the stage as before: they are not handed out, and a page-locked block PyTorch's host allocator
+    #: has just taken back is only reusable once the stream that copied into it has passed the point of its release -- a hot path
+    #: that took a new block per call would keep pinning fresh memory while the stream is busy.  (The downloads inside a step
+    #: are all below 1 MiB -- the combined Gram matrix is m x m -- and go through spr_download_bytes anyway.)
     _PINNED_MIN_BYTES = 4 << 20
 
     def to_host(self, t, then=None, result=False):

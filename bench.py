@@ -560,6 +560,7 @@ def run_rank(args):
         comm['p2p_copy_streams'] = len(px._pool)
         # the first exchange through the mapped buffers was compared block by block with what the peers sent (ROM._p2p_first_exchange)
         comm['p2p_first_exchange'] = px.verified
+        comm['p2p_memory'] = px.memory                      # 'coarse' (plain device memory) unless the self-test asked for 'uncached'
     # never print a number for a run that computed garbage: spectrum, basis sample and field must be finite
     fld = field if torch.is_tensor(field) else None
     if not (np.all(np.isfinite(spr.S_[:s])) and bool(torch.isfinite(spr._d['Ur'][:4096].double()).all())

@@ -236,11 +236,16 @@ class P2PFieldGather:
         return self.peer_fbase[q] + 8 * self._slot(kind, self.rank, b)
 
     def _selftest(self, ok, why, kind):
-        """Two rounds of what a gather does, with the very calls it uses, under a host-side watch (nothing here can block
-        for ever: a wait that does not complete in SELFTEST_TIMEOUT_S is satisfied locally): every rank pushes a pattern and
-        a counter into every peer's scratch page, joins, READS the page (which leaves its lines in this GPU's caches), and
-        the second round overwrites them with another pattern -- a rank that then still sees the first one has stale lines
-        behind the join, and this kind of memory will not do.  -> (ok on ALL ranks, reason).  COLLECTIVE."""
+        """Two rounds of what a gather does, with the very calls it uses and IN THE ORDER it uses them (pushes on the copy streams
+        first, the wait behind them), under a host-side watch (nothing here can block for ever: a wait that does not complete in
+        SELFTEST_TIMEOUT_S is satisfied locally): every rank pushes a pattern and a counter into every peer's scratch page, joins,
+        READS the page (which leaves its lines in this GPU's caches), and the second round overwrites them with another pattern --
+        a rank that then still sees the first one has stale lines behind the join, and this kind of memory will not do.  The ranks
+        push a little after one another, so the earlier ranks' waits are already polling when the later counters arrive.
+        (The first version of this test enqueued the wait FIRST; a process maps its streams onto a few hardware queues, and
+        whenever the wait's stream shared one with a copy stream the rank's own pushes sat behind its own wait until the
+        time-out -- a spurious failure of the first kind of memory in 10 of 16 set-ups of a three-rank test on one GPU.)
+        -> (ok on ALL ranks, reason).  COLLECTIVE."""
         torch, eng = self.eng.torch, self.eng
         t0 = time.perf_counter()
         if not self.peers:                                     # a one-rank group: nothing to exchange, nothing to test
@@ -255,23 +260,14 @@ class P2PFieldGather:
             self._flags[self._slot('test', 0):self._slot('test', 0) + self.world] = 1 << 40
             torch.cuda.synchronize(eng.device)
 
+        all_ok, reason = agree(ok, why)                        # a rank that could not map its peers: nobody starts
+        if not all_ok:
+            return False, reason
         for rnd in (1, 2):
             value = 7 + rnd
-            if ok:
-                try:
-                    tab = _ptr_array([self._flag(self.fbase, 'test', q) for q in self.peers])
-                    with torch.cuda.stream(side):              # the wait first: it must see values that arrive later
-                        _lib.check(self.lib.spr_p2p_flags_wait(tab, len(self.peers), value, self.SELFTEST_TIMEOUT_S + 5.0,
-                                                               None, side.cuda_stream), 'spr_p2p_flags_wait')
-                except Exception as exc:                       # noqa: BLE001 -- any failure means "not available"
-                    ok, why = False, f'self-test set-up: {exc}'
-            # everybody has its wait enqueued (or has failed) before anybody writes
-            all_ok, reason = agree(ok, why)
-            if not all_ok:
-                if ok:
-                    unblock()
-                return False, reason
+            waiting = False
             try:
+                time.sleep(0.002 * self.rank)
                 pat = torch.full((4,), 1000 * rnd + self.rank, dtype=torch.int64, device=eng.device)
                 ev = torch.cuda.Event()
                 ev.record(cur)
@@ -280,6 +276,11 @@ class P2PFieldGather:
                     _lib.check(self.lib.spr_p2p_copy(self.peer_base[q] + self._scratch + 32 * self.rank, pat.data_ptr(), 32,
                                                      s.cuda_stream), 'spr_p2p_copy')
                     _lib.check(self.lib.spr_p2p_signal(self._peer_flag(q, 'test'), value, s.cuda_stream), 'spr_p2p_signal')
+                tab = _ptr_array([self._flag(self.fbase, 'test', q) for q in self.peers])
+                with torch.cuda.stream(side):
+                    _lib.check(self.lib.spr_p2p_flags_wait(tab, len(self.peers), value, self.SELFTEST_TIMEOUT_S + 5.0,
+                                                           None, side.cuda_stream), 'spr_p2p_flags_wait')
+                waiting = True
                 deadline = time.perf_counter() + self.SELFTEST_TIMEOUT_S
                 while not side.query():
                     if time.perf_counter() > deadline:
@@ -297,12 +298,13 @@ class P2PFieldGather:
                     if rows:
                         ok, why = False, (f'{kind} memory: round {rnd}, the pattern pushed by ranks {rows} is not what a '
                                           'kernel reads behind the join' + (' (stale lines)' if rnd == 2 else ''))
-            except Exception as exc:                           # noqa: BLE001
+            except Exception as exc:                           # noqa: BLE001 -- any failure means "not available"
                 ok, why = False, f'self-test: {exc}'
-                try:
-                    unblock()
-                except Exception:                              # noqa: BLE001
-                    pass
+                if waiting:
+                    try:
+                        unblock()
+                    except Exception:                          # noqa: BLE001
+                        pass
             all_ok, reason = agree(ok, why)
             if not all_ok:
                 return False, reason

@@ -120,6 +120,88 @@ def test_sharded_hip_path_two_ranks_one_gpu(tmp_path, fixture, world, uneven):
         assert int(outs[0]['passes']) >= 1                                  # the second-stage Gram pass ran, sharded
 
 
+def _random_shapes_worker(rank, world, port, seeds, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.engine import HipEngine
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from oracle import spr_oracle as orc
+        from tests.parity import REL_FRO, rel_fro
+        from tests.test_gpu_parity import synth_host
+        eng = HipEngine('cuda:0')
+        done = []
+        for seed in seeds:
+            rng = np.random.default_rng(7000 + seed)
+            F = int(rng.integers(1, 5))
+            m = int(rng.integers(3, 40)) if seed % 3 == 0 else int(rng.integers(40, 261))
+            n_points = max(int(rng.integers(300, 5001)), (m + 2 + F - 1) // F)
+            r = int(rng.integers(1, min(m - 1, 40) + 1))
+            rho = 10 ** (-3 / (r - 1)) if r > 1 else 0.5
+            X = synth_host(n_points, F, m, min(m, 2 * r), rho, 1e-3, 9000 + seed)
+            n = X.shape[0]
+            # blocks cut anywhere -- through features, a block of a handful of rows now and then
+            inner = np.sort(rng.choice(np.arange(1, n), size=world - 1, replace=False))
+            if seed % 4 == 1:
+                inner[0] = int(rng.integers(1, 5))
+                inner = np.sort(np.unique(inner))
+                while len(inner) < world - 1:
+                    inner = np.sort(np.unique(np.append(inner, int(rng.integers(5, n)))))
+            cuts = [0] + inner.tolist() + [n]
+            row0, n_loc = cuts[rank], cuts[rank + 1] - cuts[rank]
+            spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), F, None, shard=RowShard(row0, n), engine=eng)
+            spr.fit(select_modes='number', n_modes=r)
+            C = spr.optimal_placement()
+            w = np.random.default_rng(99).standard_normal(m) / np.sqrt(m)
+            xt = X @ w + X.mean(axis=1) * (1 - w.sum())
+
+            def y_fn(piv):
+                y = np.zeros((len(piv), 3))
+                y[:, 0] = xt[piv]
+                y[:, 2] = piv // n_points
+                return y
+            ref = orc.fit_place_train_predict_reconstruct(X, F, r, y_fn)
+            spr.train(C)
+            a, _ = spr.predict(y_fn(spr.sensors_))
+            import time
+            t_rec = time.perf_counter()
+            xr = spr.reconstruct(a)                                # the first sharded reconstruct: set-up of the exchange + self-test
+            t_rec = time.perf_counter() - t_rec
+            what = (seed, n_points, F, m, r, cuts)
+            assert spr.gather_path_.startswith('p2p'), (spr.gather_path_, what)
+            # plain device memory passes the self-test on this hardware, and no wait of the set-up runs into its time-out (it did,
+            # in 10 of these 16 set-ups, while the self-test enqueued its wait in front of its own pushes)
+            assert spr._p2p.memory == 'coarse' and t_rec < 5.0, (spr._p2p.memory, t_rec, what)
+            np.testing.assert_allclose(spr.Sigma_r, ref['Sigma_r'], rtol=1e-8, err_msg=str(what))
+            gaps = spr.pivot_gap_
+            safe = len(gaps) if gaps.min() > 1e-9 else int(np.argmax(gaps <= 1e-9))
+            np.testing.assert_array_equal(spr.sensors_[:safe], ref['piv'][:safe], err_msg=str(what))
+            if safe == len(gaps):
+                assert rel_fro(xr, ref['X_rec']) <= REL_FRO, what
+            spr.close()
+            done.append(seed)
+        np.savez(os.path.join(out_dir, f'rs{rank}.npz'), done=np.array(done))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_random_shapes_three_ranks_one_gpu(tmp_path):
+    """round 5: 16 seeded random shapes (300 ... 5 000 cells x 1 ... 4 features x 3 ... 260 snapshots, 1 ... 40 modes) row-sharded over three
+    gloo ranks on one GPU, blocks cut anywhere (through features; a block of 1-4 rows every fourth case), the field exchanged through the
+    p2p path: fit -> placement -> train -> predict -> reconstruct on every rank against the oracle on the whole matrix -- spectrum 1e-8,
+    ordered sensors exact up to the first near-tie, field within 1e-6 rel-Frobenius."""
+    import torch.multiprocessing as mp
+    world, seeds = 3, list(range(16))
+    mp.spawn(_random_shapes_worker, args=(world, _free_port(), seeds, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / f'rs{r}.npz')['done'].tolist() == seeds
+
+
 def _synth_worker(rank, world, port, cells, F, m, s_, out_dir):
     sys.path.insert(0, ROOT)
     import torch

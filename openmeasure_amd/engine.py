@@ -53,20 +53,23 @@ class HipEngine:
         import atexit
         import weakref
         ref = weakref.ref(self)
-        atexit.register(lambda: ref() is not None and ref().close())
+        atexit.register(lambda: ref() is not None and ref().close(wait=False))
 
-    def close(self):
+    def close(self, wait=True):
         """Give back what the engine holds outside PyTorch's device allocator: the page-locked staging buffers, the copy
         threads of the staged downloads.  Idempotent; the engine can be used again afterwards (buffers are
-        made on demand).  Host arrays handed out earlier (page-locked results) stay valid: they own their memory."""
+        made on demand).  Host arrays handed out earlier (page-locked results) stay valid: they own their memory.
+        ``wait=False`` (the atexit hook): without the device synchronisation in front -- a process on its way out must not
+        block on a stream that waits for a peer which is gone (the copy streams of the p2p exchange wait for counters)."""
         torch = self.torch
-        try:
-            torch.cuda.synchronize(self.device)
-        except RuntimeError:
-            pass
+        if wait:
+            try:
+                torch.cuda.synchronize(self.device)
+            except RuntimeError:
+                pass
         pool = self.__dict__.pop('_copy_pool', None)
         if pool is not None:
-            pool.shutdown(wait=True)
+            pool.shutdown(wait=wait, cancel_futures=not wait)
         self._stage = self._dstage = None
         for k in ('_dstage2', '_dstage_ev', '_dl', '_reuse', '_side'):
             self.__dict__.pop(k, None)

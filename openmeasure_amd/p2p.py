@@ -398,7 +398,9 @@ class P2PFieldGather:
             side = torch.cuda.Stream(self.eng.device)          # not behind a join kernel that is still polling
             with torch.cuda.stream(side):
                 self._flags.fill_(1 << 40)
-            side.synchronize()
+            deadline = time.perf_counter() + 2.0               # bounded: the fill may share a hardware queue with what it is to release
+            while not side.query() and time.perf_counter() < deadline:
+                time.sleep(0.001)
         self._status_np[:] = 0
 
     # ------------------------------------------------------------------ teardown

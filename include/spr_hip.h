@@ -349,7 +349,7 @@ int spr_field_unstage_blocks_f64(const double *d_stage, int32_t world, int32_t n
  *                                  own (n_p, ldo) copy d_field -- into the same place of every peer's copy: per peer p, on
  *                                  streams[p] (streams may repeat): wait until *d_release_flag[p] >= release_value (a counter
  *                                  in THIS rank's memory that peer p raises when it no longer reads what its copy held; 0 =
- *                                  no wait), n_p copies of n_loc doubles, *d_peer_arrive_flag[p] = arrive_value (a counter in
+ *                                  no wait; a single-wave kernel that gives up after release_timeout_s), n_p copies of n_loc doubles, *d_peer_arrive_flag[p] = arrive_value (a counter in
  *                                  peer p's memory), and, if given, *d_pushed_flag[p] = arrive_value (this rank's own: "the
  *                                  push to p has left").  The caller orders streams[p] behind the kernel that wrote the block.
  *   spr_field_gather_p2p_join      `stream` waits (one kernel) until every one of the n counters -- the peers' arrivals and
@@ -373,8 +373,8 @@ int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t value, double t
 int spr_p2p_copy(void *d_dst, const void *d_src, int64_t n_bytes, void *stream);
 int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc, int32_t n_peers,
                          void *const *d_peer_field, void *const *d_release_flag, uint64_t release_value,
-                         void *const *d_peer_arrive_flag, uint64_t arrive_value, void *const *d_pushed_flag,
-                         void *const *streams);
+                         double release_timeout_s, void *const *d_peer_arrive_flag, uint64_t arrive_value,
+                         void *const *d_pushed_flag, void *const *streams);
 int spr_field_gather_p2p_join(void *const *d_flags, int32_t n_flags, uint64_t arrive_value, double timeout_s, void *d_status,
                               void *stream);
 int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream);

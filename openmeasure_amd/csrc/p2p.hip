@@ -207,20 +207,27 @@ extern "C" int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t valu
 
 extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc,
                                     int32_t n_peers, void *const *d_peer_field, void *const *d_release_flag,
-                                    uint64_t release_value, void *const *d_peer_arrive_flag, uint64_t arrive_value,
-                                    void *const *d_pushed_flag, void *const *streams) {
+                                    uint64_t release_value, double release_timeout_s, void *const *d_peer_arrive_flag,
+                                    uint64_t arrive_value, void *const *d_pushed_flag, void *const *streams) {
   SPR_REQUIRE(d_field && n_p >= 1 && first >= 0 && n_loc >= 0 && ldo >= first + n_loc, SPR_E_INVALID,
               "spr_field_gather_p2p: n_p=%d first=%lld n_loc=%lld ldo=%lld", n_p, (long long)first, (long long)n_loc,
               (long long)ldo);
   SPR_REQUIRE(n_peers >= 1 && d_peer_field && d_peer_arrive_flag && streams, SPR_E_INVALID,
               "spr_field_gather_p2p: n_peers=%d (>= 1) / NULL peer table", n_peers);
-  SPR_REQUIRE(release_value == 0 || d_release_flag, SPR_E_INVALID, "spr_field_gather_p2p: release flags missing");
+  SPR_REQUIRE(release_value == 0 || (d_release_flag && release_timeout_s > 0.0 && release_timeout_s <= 3600.0), SPR_E_INVALID,
+              "spr_field_gather_p2p: release flags missing / release_timeout_s=%g outside (0, 3600]", release_timeout_s);
   const hipMemcpyKind kind = p2p_kind();
   for (int p = 0; p < n_peers; ++p) {
     hipStream_t st = static_cast<hipStream_t>(streams[p]);
     SPR_REQUIRE(d_peer_field[p] && d_peer_arrive_flag[p], SPR_E_INVALID, "spr_field_gather_p2p: peer %d has a NULL pointer", p);
-    if (release_value)   // the peer must have let go of what this buffer held (it raises the slot when it enters its own gather)
-      SPR_HIP_TRY(hipStreamWaitValue64(st, d_release_flag[p], release_value, hipStreamWaitValueGte, ~0ull));
+    if (release_value) {
+      // the peer must have let go of what this buffer held (it raises the slot when it enters its own gather).  The wait is the
+      // library's own single-wave kernel, not hipStreamWaitValue64: that one polls without an exit, and a copy stream left
+      // behind a peer that has died would spin until the process is killed -- every wave must reach its exit.  After
+      // release_timeout_s the copy goes ahead (the peer is gone; the join of this gather reports it).
+      void *one[1] = {d_release_flag[p]};
+      if (int rc = spr_p2p_flags_wait(one, 1, release_value, release_timeout_s, nullptr, st)) return rc;
+    }
     if (n_loc > 0) {
       double *dst = static_cast<double *>(d_peer_field[p]);
       for (int v = 0; v < n_p; ++v)   // contiguous pieces: one row of the (n_p, ldo) field each

@@ -344,7 +344,7 @@ class P2PFieldGather:
             _lib.check(self.lib.spr_field_gather_p2p(
                 field, n_total, n_p, int(first), int(n_loc), len(self.peers),
                 _ptr_array([self.peer_base[q] + b * self.field_bytes for q in self.peers]),
-                _ptr_array([self._flag(self.fbase, 'release', q) for q in self.peers]), release_value,
+                _ptr_array([self._flag(self.fbase, 'release', q) for q in self.peers]), release_value, self.JOIN_TIMEOUT_S,
                 _ptr_array([self._peer_flag(q, 'arrive', b) for q in self.peers]), self.k + 1,
                 _ptr_array([self._flag(self.fbase, 'pushed', q) for q in self.peers]),
                 _ptr_array([s.cuda_stream for s in self.streams])), 'spr_field_gather_p2p')

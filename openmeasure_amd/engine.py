@@ -828,10 +828,13 @@ class HipEngine:
         if r > _lib.SPR_MAX_R_WIDE:
             raise NotImplementedError(f'placement: r={r} modes exceed the built range (1..{_lib.SPR_MAX_R_WIDE})')
         t = self.torch
+        # what the host reads after every batch of steps -- the steps' certification flags, the local record, tau -- lies in ONE
+        # buffer: one small download per batch, no concatenation kernel in front of it
+        flat = self.zeros((n_steps + r + 3 + 1,))
         st = dict(Ur=Ur, n=n, r=r, ldu=ldu, row0=row0,
-                  nrm=self.empty((n,)), rec=self.empty((r + 3,)), tau=self.empty((1,)),
+                  nrm=self.empty((n,)), rec=flat[n_steps:n_steps + r + 3], tau=flat[n_steps + r + 3:],
                   Q=self.zeros((n_steps, r)), piv=self.zeros((n_steps,), dtype=t.int64),
-                  gap=self.zeros((n_steps,)), ok=self.zeros((n_steps,)),
+                  gap=self.zeros((n_steps,)), ok=flat[:n_steps], flat=flat,
                   ws=self._workspace('qr', self.lib.spr_qr_workspace_r(n, r)))
         if norms is not None:
             if tuple(norms.shape) != (n,) or norms.dtype != t.float64:

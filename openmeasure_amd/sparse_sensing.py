@@ -587,8 +587,13 @@ def _pivot_loop_pooled(eng, st, s, stats, all_gather=None):
             taus = all_gather(st['tau'])
             for t in range(nb):                                  # steps on the candidate set, no host sync
                 eng.qr_step(st, j + t, all_gather(st['rec']), taus, first=(t == 0 and first_exact))
-        chk = eng.to_host(torch.cat([st['ok'][j:j + nb], st['rec'][:1], st['tau']]))   # one sync per batch
-        ok, best_next, tau = chk[:nb], chk[nb], chk[nb + 1]
+        if 'flat' in st:                                         # flags | record | tau in one buffer: one sync per batch, no cat
+            chk = eng.to_host(st['flat'])
+            n_all = st['ok'].shape[0]
+            ok, best_next, tau = chk[j:j + nb], chk[n_all], chk[-1]
+        else:
+            chk = eng.to_host(torch.cat([st['ok'][j:j + nb], st['rec'][:1], st['tau']]))   # one sync per batch
+            ok, best_next, tau = chk[:nb], chk[nb], chk[nb + 1]
         k = nb if ok.all() else int(np.argmin(ok))               # certified prefix
         if k < 1 and first_exact:
             raise RuntimeError('optimal_placement: first step after a sweep was not certified')

@@ -105,6 +105,13 @@ int spr_host_tridiag_vectors(const double *h_d, const double *h_e, int32_t m, co
  * 2 when the vectors miss their orthonormality checks (close eigenvalues): the caller then takes dstein / dsyevd.  < 0: SPR_E_*. */
 int spr_host_eig_top(const double *h_G, int32_t m, int32_t r, double *h_lam, double *h_V, void *fn_dsytrd, void *fn_dsterf,
                      void *fn_dormtr);
+/* The same idea for the SVD that ends fit()'s conditioning refinement pass (np.linalg.svd of an m x m factor, sparse_sensing.py
+ * _refine_spectrum; reference: the accuracy of np.linalg.svd(X0), :272): ALL singular values (h_S, descending) and the r leading
+ * RIGHT singular vectors (h_V, m x r row-major) of the row-major m x m matrix h_M -- dgebrd, dbdsdc (values only), the batched
+ * inverse iteration on the Golub-Kahan form of the bidiagonal matrix, dormbr; LAPACK again through the caller's function
+ * pointers.  0 ok, 1 LAPACK failed, 2 the vectors failed their orthonormality checks (take dgesdd). */
+int spr_host_svd_top(const double *h_M, int32_t m, int32_t r, double *h_S, double *h_V, void *fn_dgebrd, void *fn_dbdsdc,
+                     void *fn_dormbr);
 
 /* ---- K1 + K3a : fused row mean, per-feature statistics, per-feature Gram -----------
  * Replaces np.average(x, axis=1) (:112), np.std(x) (:115), the materialised

@@ -39,6 +39,7 @@ PROTOTYPES = {
     'spr_download_bytes': (C.c_int, [_p, _p, _i64, _p, _u64, _p]),
     'spr_host_tridiag_vectors': (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32]),
     'spr_host_eig_top': (C.c_int, [_p, _i32, _i32, _p, _p, _p, _p, _p]),
+    'spr_host_svd_top': (C.c_int, [_p, _i32, _i32, _p, _p, _p, _p, _p]),
     'spr_stats_gram_workspace': (_sz, [_i32, _i32]),
     'spr_stats_gram_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),
     'spr_stats_gram_finalize_f64': (C.c_int, [_i64, _i32, _i64, _i64, _i32, _p, _sz, _p, _p, _i32, _i32, _p]),

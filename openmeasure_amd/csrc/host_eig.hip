@@ -256,3 +256,88 @@ extern "C" int spr_host_eig_top(const double *h_G, int32_t m, int32_t r, double 
   free(buf);
   return rc;
 }
+
+
+// ---- the r leading RIGHT singular vectors and all singular values of a square matrix ------------------------------------------
+// fit()'s conditioning refinement (sparse_sensing.py, _refine_spectrum) ends with the SVD of an m x m factor M of which only the
+// singular values and the r retained right singular vectors are used; LAPACK's dgesdd computes all 2 m^2 vector entries (6.1 of the
+// 7 host milliseconds of a refinement pass at m = 256).  Here: dgebrd (M^T = Q B P^T in LAPACK's column-major reading of the
+// row-major M), dbdsdc for the singular values of the bidiagonal B alone, the r leading LEFT vectors of B by the batched inverse
+// iteration above on B's Golub-Kahan form -- the 2m x 2m tridiagonal matrix with zero diagonal and off-diagonal d1, e1, d2, e2, ...,
+// whose eigenvector for +sigma is (v1, u1, v2, u2, ...) / sqrt(2): it inherits the relative accuracy of the small singular values,
+// which B^T B would lose -- and dormbr for Q times those r vectors: left vectors of M^T = right vectors of M.  Same checks as
+// spr_host_eig_top (orthonormality 1e-8 before the symmetric correction, 1e-12 after); status 2 tells the caller to take dgesdd.
+namespace {
+typedef void (*dgebrd_fn)(int *, int *, double *, int *, double *, double *, double *, double *, double *, int *, int *);
+typedef void (*dbdsdc_fn)(char *, char *, int *, double *, double *, double *, int *, double *, int *, double *, int *, double *,
+                          int *, int *);
+typedef void (*dormbr_fn)(char *, char *, char *, int *, int *, int *, double *, int *, double *, double *, int *, double *, int *,
+                          int *);
+}  // namespace
+
+extern "C" int spr_host_svd_top(const double *h_M, int32_t m, int32_t r, double *h_S, double *h_V, void *fn_dgebrd,
+                                void *fn_dbdsdc, void *fn_dormbr) {
+  SPR_REQUIRE(h_M && h_S && h_V && fn_dgebrd && fn_dbdsdc && fn_dormbr, SPR_E_INVALID, "spr_host_svd_top: NULL pointer");
+  SPR_REQUIRE(m >= 2 && r >= 1 && r <= m && m <= 4096, SPR_E_INVALID, "spr_host_svd_top: bad shape m=%d r=%d", m, r);
+  const size_t mm = (size_t)m * m, mr = (size_t)m * r, m2 = 2 * (size_t)m;
+  int lwork = m * 128;
+  const size_t n_dbl = mm + 6 * (size_t)m + (size_t)lwork + 2 * m2 + m2 * r + 2 * mr + 2 * (size_t)r * r + (5 * m2 * r + 3 * (size_t)r) + 8;
+  double *buf = static_cast<double *>(malloc(sizeof(double) * n_dbl + sizeof(int) * 8 * (size_t)m));
+  SPR_REQUIRE(buf != nullptr, SPR_E_WORKSPACE, "spr_host_svd_top: out of host memory");
+  double *A = buf, *d = A + mm, *e = d + m, *tauq = e + m, *taup = tauq + m, *sv = taup + m, *se = sv + m, *work = se + m;
+  double *dT = work + lwork, *eT = dT + m2, *Z = eT + m2, *Ub = Z + m2 * r, *Uc = Ub + mr, *E = Uc + mr, *E2 = E + (size_t)r * r;
+  double *vwork = E2 + (size_t)r * r;
+  int *iwork = reinterpret_cast<int *>(vwork + (5 * m2 * r + 3 * (size_t)r) + 8);
+  memcpy(A, h_M, sizeof(double) * mm);                       // row-major M = column-major M^T
+  int mi = m, ri = r, info = 0, one = 1;
+  reinterpret_cast<dgebrd_fn>(fn_dgebrd)(&mi, &mi, A, &mi, d, e, tauq, taup, work, &lwork, &info);
+  int rc = 0;
+  if (info == 0) {
+    memcpy(sv, d, sizeof(double) * m);
+    memcpy(se, e, sizeof(double) * (m - 1));
+    char U = 'U', N = 'N';
+    double dummy = 0.0;
+    int idummy = 0;
+    // singular values only: workspace 4 m doubles, 8 m integers
+    reinterpret_cast<dbdsdc_fn>(fn_dbdsdc)(&U, &N, &mi, sv, se, &dummy, &one, &dummy, &one, &dummy, &idummy, work, iwork, &info);
+  }
+  if (info != 0) { free(buf); return 1; }
+  for (int i = 0; i < m; ++i) h_S[i] = sv[i];                  // dbdsdc leaves them in decreasing order
+  // Golub-Kahan form of the (upper) bidiagonal B: zero diagonal, off-diagonal d1, e1, d2, e2, ..., d_m
+  for (size_t i = 0; i < m2; ++i) dT[i] = 0.0;
+  for (int k = 0; k < m; ++k) {
+    eT[2 * k] = d[k];
+    if (k < m - 1) eT[2 * k + 1] = e[k];
+  }
+  tridiag_vectors_core(dT, eT, (int)m2, sv, r, Z, 4, vwork);   // column j <-> +sigma_j, j = 0 .. r-1 (the r largest)
+  // left vectors of B: the entries 1, 3, 5, ... of the Golub-Kahan vector, normalised (row-major m x r)
+  for (int j = 0; j < r; ++j) {
+    double nn = 0.0;
+    for (int k = 0; k < m; ++k) { const double v = Z[(size_t)(2 * k + 1) * r + j]; nn += v * v; }
+    const double inv = nn > 0.0 ? 1.0 / sqrt(nn) : 0.0;
+    for (int k = 0; k < m; ++k) Ub[(size_t)k * r + j] = Z[(size_t)(2 * k + 1) * r + j] * inv;
+  }
+  double defect = gram_defect(Ub, m, r, E);
+  if (!(defect <= 1e-8)) rc = 2;
+  if (rc == 0) {
+    for (int k = 0; k < m; ++k) {                             // Ub (I - E / 2), column-major for dormbr
+      const double *zk = Ub + (size_t)k * r;
+      for (int j = 0; j < r; ++j) {
+        double acc = zk[j];
+        for (int i = 0; i < r; ++i) acc -= 0.5 * zk[i] * E[(size_t)i * r + j];
+        Uc[(size_t)j * m + k] = acc;
+      }
+    }
+    char Qc = 'Q', L = 'L', N = 'N';
+    reinterpret_cast<dormbr_fn>(fn_dormbr)(&Qc, &L, &N, &mi, &ri, &mi, A, &mi, tauq, Uc, &mi, work, &lwork, &info);
+    if (info != 0) rc = 1;
+  }
+  if (rc == 0) {
+    for (int k = 0; k < m; ++k)
+      for (int j = 0; j < r; ++j) h_V[(size_t)k * r + j] = Uc[(size_t)j * m + k];
+    defect = gram_defect(h_V, m, r, E2);
+    if (!(defect <= 1e-12)) rc = 2;
+  }
+  free(buf);
+  return rc;
+}

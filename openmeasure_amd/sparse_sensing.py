@@ -481,6 +481,63 @@ def _lapack_pointers():
     return _LAPACK_PTRS
 
 
+_LAPACK_SVD_PTRS = None
+
+
+def _lapack_svd_pointers():
+    """dgebrd / dbdsdc / dormbr of SciPy's LAPACK, as in _lapack_pointers; False when they cannot be had."""
+    global _LAPACK_SVD_PTRS
+    if _LAPACK_SVD_PTRS is None:
+        try:
+            import ctypes
+            from scipy.linalg import cython_lapack
+            get_name = ctypes.pythonapi.PyCapsule_GetName
+            get_name.restype, get_name.argtypes = ctypes.c_char_p, [ctypes.py_object]
+            get_ptr = ctypes.pythonapi.PyCapsule_GetPointer
+            get_ptr.restype, get_ptr.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+            out = []
+            for name in ('dgebrd', 'dbdsdc', 'dormbr'):
+                cap = cython_lapack.__pyx_capi__[name]
+                ptr = get_ptr(cap, get_name(cap))
+                if not ptr:
+                    raise ValueError(name)
+                out.append(ptr)
+            _LAPACK_SVD_PTRS = tuple(out)
+        except Exception:                                  # noqa: BLE001 -- any SciPy without these capsules: np.linalg.svd
+            _LAPACK_SVD_PTRS = False
+    return _LAPACK_SVD_PTRS
+
+
+_SVD_TOP_MIN_M = 96      # below: the full dgesdd is a fraction of a millisecond
+
+
+def _svd_top_native(M, r):
+    """All singular values and the r leading RIGHT singular vectors of the square matrix M in one host call of the library
+    (spr_host_svd_top: dgebrd, dbdsdc for the values, batched inverse iteration on the Golub-Kahan form, dormbr) -- what the
+    refinement pass uses of np.linalg.svd(M), at 0.6 of its time for r = m / 4.  -> (S descending (m,), V (m, r)) or None (no
+    library / no pointers / r too close to m / the vectors failed their checks: the caller takes np.linalg.svd)."""
+    m = M.shape[0]
+    if M.shape != (m, m) or m < _SVD_TOP_MIN_M or 2 * r > m:
+        return None
+    ptrs = _lapack_svd_pointers()
+    if not ptrs:
+        return None
+    try:
+        from . import _lib
+        lib = _lib.load()
+    except (RuntimeError, OSError, AttributeError):
+        return None
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    if not np.all(np.isfinite(M)):
+        return None
+    S, V = np.empty(m), np.empty((m, r))
+    with _one_blas_thread():
+        rc = lib.spr_host_svd_top(M.ctypes.data, m, r, S.ctypes.data, V.ctypes.data, *ptrs)
+    if rc != 0 or not (np.all(np.isfinite(V)) and np.all(np.isfinite(S))):
+        return None
+    return S, V
+
+
 def _eig_top_native(G, r):
     """The top-r route in ONE host call of the library (spr_host_eig_top: dsytrd, dsterf, the batched inverse iterations and
     dormtr back to back, LAPACK reached through SciPy's function pointers): at small m the route is mostly call overhead -- m = 64,
@@ -1564,7 +1621,7 @@ class ROM:
         k = int(pack[1])
         return pack[2:2 + m].copy(), pack[2 + m:2 + m + m * k].reshape(m, k).copy()
 
-    def _refine_spectrum(self, S, V, r, Xd, row0, n_points, n_features, inv_scale_d, rowmean_d, center):
+    def _refine_spectrum(self, S, V, r, Xd, row0, n_points, n_features, inv_scale_d, rowmean_d, center, rank_of=None):
         """Conditioning safeguard of the Gram route (hard part 1).
 
         The eigenvectors of G = X0^T X0 carry an error eps * (sigma_1/sigma_i)^2, which LAPACK's SVD of X0 itself
@@ -1576,12 +1633,15 @@ class ROM:
         orthonormal, and the SVD of the m x m matrix M gives the singular values and right singular vectors of X0.
         Repeated (at most _GRAM_REFINE_MAX_PASSES passes) until the retained block of H is well conditioned;
         raises LinAlgError if it never is -- never returns silently degraded sensors.
+        ``rank_of``: exp_variance -> number of modes the caller will keep (so that the last pass may compute only that many
+        right singular vectors; columns r .. m of the V returned are zero then).
         Returns (S, V, exp_variance, passes)."""
         eng = self._engine()
         n_loc, m = Xd.shape
         eps = np.finfo(float).eps
-        # row blocks of the f64 scratch matrix Y: up to 8 GiB (a quarter of what is free), so that a pass over 9M rows is 3
-        # projection + Gram launch pairs instead of 9 (each pair has its ramp and tail)
+        # row blocks of the f64 scratch matrix Y: up to 8 GiB (a quarter of what is free), equal in size, so that a pass over 9M
+        # rows is 3 projection + Gram launch pairs instead of 9 (each pair has its ramp and tail; one 18 GB block measured no
+        # better than three of 6 GB, and its allocation now and then cost 5 ms)
         budget = 1 << 31
         try:
             free = eng.torch.cuda.mem_get_info(eng.device)[0] if hasattr(eng, 'device') and eng.device.type == 'cuda' else 0
@@ -1589,6 +1649,9 @@ class ROM:
         except (RuntimeError, AttributeError):
             pass
         block = int(max(1 << 16, min(n_loc, budget // (8 * (m + (m & 1))))))
+        n_blocks = -(-n_loc // block)
+        block = -(-n_loc // n_blocks)                         # equal blocks: no short last pair of launches (ramp and tail for little work)
+        block = min(n_loc, -(-block // 16) * 16)
         Y = eng.empty((min(block, n_loc), m + (m & 1)))
         passes = 0
         import time
@@ -1619,13 +1682,25 @@ class ROM:
                 Rc, info = lapack.dpotrf(H, lower=0, clean=1)
                 if info == 0 and np.all(np.isfinite(Rc)) and Rc.diagonal().min() > 1e-7 * Rc.diagonal().max():
                     t_c = time.perf_counter()
-                    M = (Rc * d[None, :]) @ V.T
+                    B = Rc * d[None, :]
                 else:
                     lamH, Z = _eigh_small(H)
                     t_c = time.perf_counter()
-                    M = (np.sqrt(np.maximum(lamH, 0.0))[:, None] * Z.T) * d[None, :] @ V.T
+                    B = (np.sqrt(np.maximum(lamH, 0.0))[:, None] * Z.T) * d[None, :]
+                # M = B V^T, V orthogonal: the singular values of M are B's, its right singular vectors V times B's
                 t_d = time.perf_counter()
-                _, S_new, Vt = np.linalg.svd(M)
+                # of this SVD only the singular values and the r retained right vectors are used once the pass has converged
+                # (the usual case): the one-call route computes exactly those (0.65 of dgesdd's time at m = 256, r = 64);
+                # rows r .. m of Vt stay zero then.  A pass that has NOT converged needs all of V for the next one (below).
+                # (not when the ranks take rank 0's factors: the route must not depend on a rank-local outcome there)
+                part = None if self._broadcasts_basis() else _svd_top_native(B, r)
+                if part is not None:
+                    S_new = part[0]
+                    Vt = np.zeros((m, m))
+                    Vt[:r] = (V @ part[1]).T                    # m x m x r instead of forming M (m x m x m)
+                else:
+                    M = B @ V.T
+                    _, S_new, Vt = np.linalg.svd(M)
             t_e = time.perf_counter()
             prof['eigh_ms'] = prof.get('eigh_ms', 0.0) + 1e3 * (t_c - t_b)
             prof['M_ms'] = prof.get('M_ms', 0.0) + 1e3 * (t_d - t_c)
@@ -1637,12 +1712,24 @@ class ROM:
             # in the reference as well and are left out of the verdict.
             keep = np.flatnonzero(S_new[:r] > 1e-12 * S_new[0])
             dn = np.sqrt(np.maximum(np.diag(H), np.finfo(float).tiny))
-            with _one_blas_thread():
-                ev = np.linalg.eigvalsh((H / dn[:, None] / dn[None, :])[np.ix_(keep, keep)])
-            cond_r = ev[-1] / max(ev[0], np.finfo(float).tiny)
+            Hk = (H[np.ix_(keep, keep)] / dn[keep, None]) / dn[None, keep]     # unit diagonal
+            rho = float(np.max(np.sum(np.abs(Hk), axis=1) - np.abs(np.diag(Hk)))) if len(keep) else 0.0
+            if rho < 0.5 and np.all(np.isfinite(Hk)):
+                # Gershgorin: the eigenvalues of the retained block lie in [1 - rho, 1 + rho] -- condition below 3 without solving
+                # for them (the usual case: off-diagonals of 1e-3)
+                cond_r = (1.0 + rho) / (1.0 - rho)
+            else:
+                with _one_blas_thread():
+                    ev = np.linalg.eigvalsh(Hk)
+                cond_r = ev[-1] / max(ev[0], np.finfo(float).tiny)
+            converged = cond_r < 4.0                           # |off-diagonal| of the retained block well below 1
+            if part is not None and (not converged or (rank_of is not None and rank_of(self._expvar(S_new * S_new)) > r)):
+                # all of V is needed after all: another pass follows, or the refined spectrum asks for more modes than were kept
+                with _one_blas_thread():
+                    _, S_new, Vt = np.linalg.svd(B @ V.T)
             S, V = S_new, _sign_fix(Vt.T.copy())
             prof['host_ms'] += 1e3 * (time.perf_counter() - t_b)
-            if cond_r < 4.0:                                   # |off-diagonal| of the retained block well below 1
+            if converged:
                 break
             if passes >= _GRAM_REFINE_MAX_PASSES:
                 raise np.linalg.LinAlgError(
@@ -1672,7 +1759,8 @@ class ROM:
             import time
             t_ref = time.perf_counter()
             S, V, exp_variance, self.gram_refine_passes_ = self._refine_spectrum(
-                S, V, r, Xd, self._row0, self.n_points, self.n_features, inv_scale_d, self._d.get('rowmean'), center)
+                S, V, r, Xd, self._row0, self.n_points, self.n_features, inv_scale_d, self._d.get('rowmean'), center,
+                rank_of=rank_of)
             r = self._select_rank(exp_variance, m, select_modes, n_modes)
             self.refine_ms_ = 1e3 * (time.perf_counter() - t_ref)      # host wall time of the refinement (it synchronises)
             self._trace.mark('refine')
@@ -1722,7 +1810,8 @@ class ROM:
             r = self._select_rank(exp_variance, m, select_modes, n_modes)
             floor = S[0] * np.sqrt(m * np.finfo(float).eps)
             if S[r - 1] * _GRAM_KAPPA_REFINE < S[0]:
-                S, V, exp_variance, _ = self._refine_spectrum(S, V, r, X0d, 0, X0d.shape[0], 1, ones, None, False)
+                S, V, exp_variance, _ = self._refine_spectrum(S, V, r, X0d, 0, X0d.shape[0], 1, ones, None, False,
+                                                              rank_of=lambda ev: self._select_rank(ev, m, select_modes, n_modes))
                 r = self._select_rank(exp_variance, m, select_modes, n_modes)
                 floor = S[0] * m * np.finfo(float).eps
             W = V[:, :r] / np.maximum(S[:r], floor if floor > 0 else 1.0)

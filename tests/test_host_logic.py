@@ -52,6 +52,59 @@ def test_conditioning_guard_through_host_logic(decades):   # SURVEY 7 hard part 
         run_conditioning_guard(NumpyEngine(), decades, _synth, f32=True)
 
 
+@pytest.mark.parametrize('decades', [5, 6, 7])
+def test_conditioning_guard_wide_matrix_takes_the_top_r_svd(decades, monkeypatch):
+    """m >= 96 with r <= m / 2: the refinement pass ends with spr_host_svd_top (all singular values, the r retained right vectors)
+    instead of the full dgesdd -- same sensors, spectrum and basis as the oracle; and the same with the route switched off."""
+    from openmeasure_amd import sparse_sensing as ss
+    calls = []
+    real = ss._svd_top_native
+    monkeypatch.setattr(ss, '_svd_top_native', lambda M, r: calls.append(M.shape) or real(M, r))
+    spr = run_conditioning_guard(NumpyEngine(), decades, _synth, shape=(500, 2, 160, 24))
+    assert spr.gram_refine_passes_ >= 1 and calls and calls[0] == (160, 160)
+    monkeypatch.setattr(ss, '_svd_top_native', lambda M, r: None)
+    run_conditioning_guard(NumpyEngine(), decades, _synth, shape=(500, 2, 160, 24))
+
+
+@pytest.mark.parametrize('m,r,decades', [(128, 32, 5.0), (256, 64, 6.1), (300, 40, 8.0), (96, 48, 4.0), (200, 1, 3.0)])
+def test_svd_top_native_against_lapack(m, r, decades):
+    """spr_host_svd_top on the factor a refinement pass hands it (R diag(d) V^T, R the Cholesky factor of a matrix near I): all
+    singular values to the relative accuracy of LAPACK's own, the r leading right singular vectors up to sign, orthonormal."""
+    from openmeasure_amd.sparse_sensing import _svd_top_native
+    rng = np.random.default_rng(m + r)
+    V, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    d = np.concatenate([np.logspace(0, -decades, r), 10 ** (-decades - 0.5) * (1 + 0.1 * rng.random(m - r))])
+    E = 1e-3 * rng.standard_normal((m, m))
+    R = np.linalg.cholesky(np.eye(m) + 0.5 * (E + E.T)).T
+    M = (R * d[None, :]) @ V.T
+    out = _svd_top_native(M, r)
+    assert out is not None
+    S, Vr = out
+    _, S_ref, Vt = np.linalg.svd(M)
+    np.testing.assert_allclose(S[:r], S_ref[:r], rtol=1e-11)
+    np.testing.assert_allclose(S, S_ref, rtol=0, atol=1e-13 * S_ref[0])           # the noise floor: to LAPACK's ABSOLUTE accuracy
+    assert np.abs(Vr.T @ Vr - np.eye(r)).max() <= 1e-12
+    gap = np.min(np.abs(np.diff(S_ref[:r + 1]))) / S_ref[0] if r < m else 1.0
+    assert np.max(1.0 - np.abs(np.sum(Vr * Vt[:r].T, axis=0))) <= 1e-13 / max(gap, 1e-3) ** 2 + 1e-12
+
+
+def test_svd_top_native_declines():
+    """None (the caller takes np.linalg.svd) for small matrices, r above m / 2, non-finite input -- and for a cluster of equal
+    singular values among the r leading ones, where inverse iteration without re-orthogonalisation cannot separate the vectors."""
+    from openmeasure_amd.sparse_sensing import _svd_top_native
+    rng = np.random.default_rng(3)
+    assert _svd_top_native(rng.standard_normal((40, 40)), 8) is None
+    assert _svd_top_native(rng.standard_normal((128, 128)), 65) is None
+    bad = rng.standard_normal((128, 128))
+    bad[3, 4] = np.nan
+    assert _svd_top_native(bad, 8) is None
+    Q1, _ = np.linalg.qr(rng.standard_normal((128, 128)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((128, 128)))
+    s = np.logspace(0, -3, 128)
+    s[4:8] = s[4]                                                                  # a four-fold singular value
+    assert _svd_top_native((Q1 * s) @ Q2.T, 16) is None
+
+
 @pytest.mark.parametrize('n_points,F,m,r', [(400, 3, 12, 4), (300, 2, 41, 14)])
 def test_f32_storage_through_host_logic(n_points, F, m, r):      # float32 X: stored as given, arithmetic in f64
     run_f32_storage(NumpyEngine(), n_points, F, m, r, 21, _synth)

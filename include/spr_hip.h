@@ -35,6 +35,7 @@
  *                             RCCL's kernel, which cannot share one with the Gram / projection workgroups)
  *   SPR_QR_EPOCH_ILP=0|2      spr_qr_epoch_sweep_*: direction tiles one after the other in full sweeps too | side by side in pool
  *                             sweeps as well (default 1: full sweeps of bases up to 64 columns side by side)
+ *   SPR_WS_WG_PER_CU=k        spr_project_*: workgroups per CU of the W-stationary kernel at m = 64 (1..4, default 2)
  *   SPR_QR_ORTH_TILE=0        spr_qr_step_f64 / spr_qr_steps_f64: the Gram-Schmidt passes of a step as chains of loads instead of
  *                             the register-tiled form (A/B only)
  *   SPR_P2P_BLIT=1            spr_p2p_copy / spr_field_gather_p2p: blit kernels instead of the SDMA engines

@@ -311,7 +311,24 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         from tests.conftest import load_golden
         eng = HipEngine('cuda:0')
         res = {}
-        if case == 'no_peer_access':
+        if case == 'uncached':
+            # the second kind of memory the set-up can fall to when plain device memory shows stale lines behind the join
+            # (SPR_P2P_MEMORY=uncached goes straight to it): same fields
+            os.environ['SPR_P2P_MEMORY'] = 'uncached'
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            n_loc = n // world
+            row0 = rank * n_loc
+            spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+            spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+            sgn = np.sign(np.sum(spr.Ar * g['Ar'], axis=0))
+            X3 = spr.reconstruct(g['Ar_pred3'] * sgn)
+            X3b = spr.reconstruct(g['Ar_pred3'] * sgn)
+            res = dict(path=str(spr.gather_path_), memory=str(spr._p2p.memory), X3=X3, same=bool(np.array_equal(X3, X3b)))
+            spr.close()
+            os.environ.pop('SPR_P2P_MEMORY')
+        elif case == 'no_peer_access':
             # the GPU of a peer is not peer-accessible from one rank (another hive, a device the process cannot see): known
             # BEFORE anything is mapped, every rank on the collective path, with the reason
             g = load_golden('g3_num8')
@@ -463,7 +480,7 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['fallback', 'no_peer_access', 'timeout', 'first_mismatch', 'first_timeout'])
+@pytest.mark.parametrize('case', ['fallback', 'no_peer_access', 'uncached', 'timeout', 'first_mismatch', 'first_timeout'])
 def test_p2p_exchange_edges(tmp_path, case):
     """round 5: the p2p field exchange when it cannot be had (one rank cannot map its peers -> every rank on the collective path,
     or every rank raising when p2p was demanded), when a peer never pushes (the join kernel's wall-clock exit + check()), and
@@ -473,7 +490,14 @@ def test_p2p_exchange_edges(tmp_path, case):
     world = 2
     mp.spawn(_p2p_edge_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'edge{r}.npz') for r in range(world)]
-    if case == 'no_peer_access':
+    if case == 'uncached':
+        from tests.conftest import load_golden
+        from tests.parity import REL_FRO, rel_fro
+        g = load_golden('g3_num8')
+        for o in outs:
+            assert str(o['path']).startswith('p2p') and str(o['memory']) == 'uncached' and bool(o['same']), (o['path'], o['memory'])
+            assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO
+    elif case == 'no_peer_access':
         from tests.conftest import load_golden
         from tests.parity import REL_FRO, rel_fro
         g = load_golden('g3_num8')

@@ -311,7 +311,35 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         from tests.conftest import load_golden
         eng = HipEngine('cuda:0')
         res = {}
-        if case == 'uncached':
+        if case.startswith('knob:'):
+            # the switches of the exchange (double buffering, the number of copy streams, blit kernels instead of the SDMA engines):
+            # gathers left in flight and joined behind the next fit(), against the collective path, bit for bit
+            key, val = case[5:].split('=')
+            os.environ[key] = val
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            row0 = rank * (n // world)
+            n_loc = n - row0 if rank == world - 1 else n // world      # three ranks: 8000 rows do not divide
+            spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n, gather='rccl'),
+                      engine=eng)
+            spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+            A3 = g['Ar_pred3'] * np.sign(np.sum(spr.Ar * g['Ar'], axis=0))
+            As = [(A3 * (1.0 + 0.25 * it))[: (1 if it % 2 else 3)] for it in range(5)]
+            wants = [spr.reconstruct(A).T.copy() for A in As]
+            spr.use_gather('p2p')
+            prev, ok = None, True
+            for it, A in enumerate(As):
+                spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+                if prev is not None:
+                    ok = ok and np.array_equal(prev.wait().cpu().numpy(), wants[it - 1])
+                prev = spr.reconstruct(A, to_host=False, wait=False)
+            ok = ok and np.array_equal(prev.wait().cpu().numpy(), wants[-1])
+            px = spr._p2p
+            res = dict(path=str(spr.gather_path_), ok=bool(ok), n_buf=px.n_buf, n_streams=len(px._pool))
+            spr.close()
+            os.environ.pop(key)
+        elif case == 'uncached':
             # the second kind of memory the set-up can fall to when plain device memory shows stale lines behind the join
             # (SPR_P2P_MEMORY=uncached goes straight to it): same fields
             os.environ['SPR_P2P_MEMORY'] = 'uncached'
@@ -480,17 +508,23 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['fallback', 'no_peer_access', 'uncached', 'timeout', 'first_mismatch', 'first_timeout'])
+@pytest.mark.parametrize('case', ['fallback', 'no_peer_access', 'uncached', 'knob:SPR_P2P_BUFFERS=2', 'knob:SPR_P2P_STREAMS=1',
+                                  'knob:SPR_P2P_BLIT=1', 'timeout', 'first_mismatch', 'first_timeout'])
 def test_p2p_exchange_edges(tmp_path, case):
     """round 5: the p2p field exchange when it cannot be had (one rank cannot map its peers -> every rank on the collective path,
     or every rank raising when p2p was demanded), when a peer never pushes (the join kernel's wall-clock exit + check()), and
     when the first full-size exchange through new buffers delivers a wrong block or none (checked per block; all ranks drop to
     the collective path together, or raise together when p2p was demanded)."""
     import torch.multiprocessing as mp
-    world = 2
+    world = 3 if case.startswith('knob:SPR_P2P_STREAMS') else 2
     mp.spawn(_p2p_edge_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'edge{r}.npz') for r in range(world)]
-    if case == 'uncached':
+    if case.startswith('knob:'):
+        for o in outs:
+            assert str(o['path']).startswith('p2p') and bool(o['ok']), (o['path'], o['ok'])
+            assert int(o['n_buf']) == (2 if 'BUFFERS=2' in case else 1)
+            assert int(o['n_streams']) == 1                    # one peer (two ranks), or two peers dealt to the one stream asked for
+    elif case == 'uncached':
         from tests.conftest import load_golden
         from tests.parity import REL_FRO, rel_fro
         g = load_golden('g3_num8')

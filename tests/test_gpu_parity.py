@@ -1731,6 +1731,24 @@ def test_pinned_result_budget(eng, monkeypatch):
     eng.__dict__.pop('_pinned_budget', None)                                  # the next to_host() reads the restored environment
 
 
+@pytest.mark.parametrize('switch', ['SPR_PROJECT_WS=0', 'SPR_QR_FUSED_STEPS=0', 'SPR_QR_ORTH_TILE=0', 'SPR_QR_EPOCH_ILP=0',
+                                    'SPR_QR_EPOCH_ILP=2', 'SPR_QR_DIRECT=0', 'SPR_RECONSTRUCT_DIRECT=0', 'SPR_RECONSTRUCT_DIRECT=3',
+                                    'SPR_DL_KERNEL=0', 'SPR_PROJECT_STREAM=1', 'SPR_WS_WG_PER_CU=4'])
+def test_ab_switches_keep_parity(switch):
+    """The A/B switches of the library and of the Python layer (include/spr_hip.h) select kernel forms that the default path does not
+    take at these shapes; the library reads them once per process, so each runs tests/_switch_check.py in a process of its own: the
+    whole path on five shapes against the oracle, sensors exact."""
+    import subprocess
+    import sys
+    key, val = switch.split('=')
+    env = dict(os.environ)
+    env[key] = val
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', '_switch_check.py')], env=env, cwd=root, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and 'SWITCH_CHECK_OK' in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
 def test_engine_close_and_reuse(eng):
     """HipEngine.close() (also registered with atexit): staging buffers, copy threads and cached page-locked blocks go back;
     host arrays handed out before stay valid (they own their memory) and the engine makes its buffers again on demand."""

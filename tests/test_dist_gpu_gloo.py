@@ -144,6 +144,9 @@ def _random_shapes_worker(rank, world, port, seeds, out_dir):
             r = int(rng.integers(1, min(m - 1, 40) + 1))
             rho = 10 ** (-3 / (r - 1)) if r > 1 else 0.5
             X = synth_host(n_points, F, m, min(m, 2 * r), rho, 1e-3, 9000 + seed)
+            f32 = seed % 5 == 2                                    # float32 STORAGE of the snapshots (arithmetic and basis stay f64)
+            Xin = X.astype(np.float32) if f32 else X
+            X = Xin.astype(np.float64)                             # what the oracle sees: the stored values
             n = X.shape[0]
             # blocks cut anywhere -- through features, a block of a handful of rows now and then
             inner = np.sort(rng.choice(np.arange(1, n), size=world - 1, replace=False))
@@ -154,7 +157,7 @@ def _random_shapes_worker(rank, world, port, seeds, out_dir):
                     inner = np.sort(np.unique(np.append(inner, int(rng.integers(5, n)))))
             cuts = [0] + inner.tolist() + [n]
             row0, n_loc = cuts[rank], cuts[rank + 1] - cuts[rank]
-            spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), F, None, shard=RowShard(row0, n), engine=eng)
+            spr = SPR(np.ascontiguousarray(Xin[row0:row0 + n_loc]), F, None, shard=RowShard(row0, n), engine=eng)
             spr.fit(select_modes='number', n_modes=r)
             C = spr.optimal_placement()
             w = np.random.default_rng(99).standard_normal(m) / np.sqrt(m)
@@ -192,7 +195,7 @@ def _random_shapes_worker(rank, world, port, seeds, out_dir):
 
 def test_sharded_random_shapes_three_ranks_one_gpu(tmp_path):
     """round 5: 16 seeded random shapes (300 ... 5 000 cells x 1 ... 4 features x 3 ... 260 snapshots, 1 ... 40 modes) row-sharded over three
-    gloo ranks on one GPU, blocks cut anywhere (through features; a block of 1-4 rows every fourth case), the field exchanged through the
+    gloo ranks on one GPU, blocks cut anywhere (through features; a block of 1-4 rows every fourth case), float32 storage every fifth, the field exchanged through the
     p2p path: fit -> placement -> train -> predict -> reconstruct on every rank against the oracle on the whole matrix -- spectrum 1e-8,
     ordered sensors exact up to the first near-tie, field within 1e-6 rel-Frobenius."""
     import torch.multiprocessing as mp

@@ -302,19 +302,26 @@ def parse_args(argv=None):
     ap.add_argument('--share-rank', type=int, default=0, help='which rank of --share-of')
     ap.add_argument('--gather', default=os.environ.get('SPR_BENCH_GATHER', 'auto'), choices=('auto', 'p2p', 'rccl'),
                     help="field exchange of the headline loop (RowShard.gather); with 'auto' the other path is timed as well")
-    ap.add_argument('--headline-gather', default='faster', choices=('faster', 'library', 'other'),
+    ap.add_argument('--headline-gather', default='library', choices=('library', 'faster', 'other'),
                     help="N > 1 with --gather auto, where both exchanges are timed: which one the line's value comes from -- the "
-                         "faster of the two (default; p2p unless the all-gather is more than 1 %% faster), the library's own choice, "
+                         "library's own choice (default: RowShard(gather='auto') times both at its first exchange and keeps the "
+                         "faster, ROM._gather_trial -- what a user of the library gets), the faster of the two as timed by this run, "
                          "or the other one (to exercise that branch)")
     ap.add_argument('--p2p-loopback', type=int, default=0, metavar='L',
                     help='developer aid, with --share-of: the p2p field exchange with L imaginary peers inside this GPU (the '
                          "rank issues the L pushes of its block an (L+1)-rank exchange would, both ends in its own HBM); the "
                          'line says so')
     ap.add_argument('--defer-reconstruct', action='store_true',
-                    help="switch ROM.defer_reconstruct on (opt-in): the step's reconstruct kernel -- and, sharded, the push of its "
-                         "block -- is enqueued in the host gap of the NEXT step's fit() instead of behind this step's projection; "
-                         'every step still runs inside the timed region (the last one is flushed before the closing barrier); the '
-                         'line says so')
+                    help="(the library's default since round 6; kept so that older command lines still run) ROM.defer_reconstruct: "
+                         "in the pipelined loop the step's reconstruct kernel -- and, sharded, the push of its block -- is enqueued "
+                         "in the host gap of the NEXT step's fit() instead of behind this step's projection; every step still runs "
+                         'inside the timed region (the last one is flushed before the closing barrier)')
+    ap.add_argument('--no-defer-reconstruct', action='store_true',
+                    help='switch ROM.defer_reconstruct off (A/B): every reconstruct launches behind its own projection')
+    ap.add_argument('--ballast-gb', type=float, default=0.0, metavar='G',
+                    help="developer aid (N = 8 rehearsal on one GPU): allocate G GB of HBM before the first fit() and hold them to "
+                         "the end -- what an N-rank run adds to one rank's footprint (the persistent copy of the gathered field, "
+                         "RCCL's staging and buffers) on top of what --share-of / --p2p-loopback already allocate; the line says so")
     ap.add_argument('--gap-filler', action='store_true',
                     help='switch ROM.gap_filler on (opt-in: fit() re-queues its Gram kernel on part of X into the host gap to '
                          'hold the clock; the line then says so and counts the rows)')
@@ -423,8 +430,15 @@ def run_rank(args):
         spr.placement_norms = args.placement_norms == 'on'
     if args.gap_filler:
         spr.gap_filler = True
-    if args.defer_reconstruct:
+    if args.no_defer_reconstruct:
+        spr.defer_reconstruct = False
+    elif args.defer_reconstruct:
         spr.defer_reconstruct = True
+    ballast = None
+    if args.ballast_gb > 0:
+        ballast = torch.empty(int(args.ballast_gb * 1e9), dtype=torch.uint8, device=eng.device)
+        ballast[::1 << 20].zero_()                          # touched: really resident
+        log(f'[rank {rank}] ballast: {ballast.numel() / 1e9:.2f} GB held next to the shard')
     wd = Watchdog(float(os.environ.get('SPR_BENCH_WATCHDOG_S', '300')), rank,
                   lambda: dict(collective_brackets={k: len(v) for k, v in (spr.comm_timing or {}).items()},
                                last_collective=getattr(spr, 'last_comm_', None), gather_path=getattr(spr, 'gather_path_', None)))
@@ -506,9 +520,19 @@ def run_rank(args):
         return dt, dt_own, timers, comm, field
 
     # N > 1: the field exchange of the headline loop is RowShard(gather=...) as resolved at the first sharded reconstruct()
-    # ('auto': p2p when its collective self-test passes); the OTHER path is then timed with the same loops, so one run says
+    # ('auto': p2p when its collective self-test passes AND the library's own first-exchange trial does not find the all-gather
+    # faster, ROM._gather_trial); the OTHER path is then timed with the same loops when the HBM left allows it, so one run says
     # what each costs, pipelined and joined inside the step
     path_results = {}
+
+    def hbm_free_all_ranks():
+        """bytes a new allocation could still get on the tightest rank: free HBM + what torch's allocator holds cached"""
+        free = torch.cuda.mem_get_info(eng.device)[0] + torch.cuda.memory_reserved(eng.device) - torch.cuda.memory_allocated(eng.device)
+        tt = torch.tensor([float(free)], dtype=torch.float64, device=eng.device)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return float(tt.item())
+
     if dist_on:
         wd.beat('first sharded reconstruct (gather path set-up)')
         done(spr.reconstruct(a_d, to_host=False, wait=True))
@@ -516,23 +540,43 @@ def run_rank(args):
         head_why = spr.gather_path_
         others = []
         if args.gather == 'auto':
-            others = ['rccl'] if head_path == 'p2p' else []
+            # p2p in the headline: the all-gather is the other one; the all-gather chosen by the library's trial with the p2p buffers
+            # still mapped: p2p is
+            others = ['rccl'] if head_path == 'p2p' else (['p2p'] if '_p2p' in spr.__dict__ else [])
     else:
         head_path, head_why, others = None, None, []
 
-    dt, dt_own, timers, comm_main, field = timed_loop(args.sync_gather)
+    # N = 1: the headline is the SYNCHRONOUS form (every step's field complete before the next step starts: comparable with rounds
+    # 1-5); the pipelined form -- reconstruct(to_host=False, wait=False), deferred into the next fit()'s host gap, the library's
+    # default for that call -- is timed right behind it and reported as ms_per_step_pipelined
+    head_sync = args.sync_gather or not dist_on
+    dt, dt_own, timers, comm_main, field = timed_loop(head_sync)
     dt_sync, comm_sync = None, {}
+    dt_pipe = None
     if dist_on and not args.sync_gather:
         # the same K steps once more with the exchange joined inside every step: what the pipelining hides, and the
         # duration of the exchange itself (its bracket closes behind the join)
         dt_sync, _, _, comm_sync, _ = timed_loop(True)
+    elif not dist_on:
+        dt_pipe, _, _, _, _ = timed_loop(False)
     if dist_on:
         path_results[head_path] = dict(ms_per_step=round(1e3 * dt / args.steps, 4),
                                        ms_per_step_sync_gather=round(1e3 * (dt_sync if dt_sync is not None else dt) / args.steps, 4),
                                        allreduce_ms=comm_main.get('allreduce'),
                                        gather_ms=(comm_sync or comm_main).get('gather'),
                                        gather_exposed_ms=comm_main.get('gather_exposed'), why=head_why)
+        raw_other = None
         for other in others:
+            # HBM first (config 5 at N = 8 leaves a few GB): the all-gather wants its staging (world x block) and the block, plus
+            # what RCCL allocates for itself; the p2p buffers exist already when p2p is the other one
+            need = ((world + 1) * n_loc * 8 + (2 << 30)) if other == 'rccl' else 0
+            free = hbm_free_all_ranks()
+            if free < need:
+                path_results[other] = dict(skipped=f'not timed: the {other} leg needs about {need / 1e9:.1f} GB more HBM per rank '
+                                                   f'(staging of the gathered field + RCCL buffers), {free / 1e9:.1f} GB are left on the '
+                                                   'tightest rank')
+                log(f'[rank {rank}] {other} leg skipped: {path_results[other]["skipped"]}')
+                continue
             wd.beat(f'switch to gather path {other}')
             spr.use_gather(other)
             done(spr.reconstruct(a_d, to_host=False, wait=True))
@@ -542,28 +586,27 @@ def run_rank(args):
                                        ms_per_step_sync_gather=round(1e3 * dt_os / args.steps, 4),
                                        allreduce_ms=comm_o.get('allreduce'), gather_ms=comm_os.get('gather'),
                                        gather_exposed_ms=comm_o.get('gather_exposed'), why=spr.gather_path_)
-            raw_other = (dt_o, comm_o, dt_os, comm_os, spr.gather_path_)
-        if others:
-            # 'auto' is the library's choice BEFORE anything was timed; here both exchanges have been timed with the same loops (dt
-            # is the maximum over the ranks: the same number on every rank), so the line reports the faster one -- the
-            # other stays in comm.paths.  p2p keeps the headline unless the all-gather is more than 1 % faster.
-            other = others[-1]
+            raw_other = (dt_o, comm_o, dt_os, comm_os, spr.gather_path_, other)
+        if raw_other is not None:
+            # both exchanges have been timed with the same loops (dt is the maximum over the ranks: the same number on every rank).
+            # --headline-gather library (default): the line's value is the path the library chose; faster / other: A/B aids
+            other = raw_other[5]
             take_other = {'faster': raw_other[0] < 0.99 * dt, 'library': False, 'other': True}[args.headline_gather]
             if take_other:
-                head_why = (f'{raw_other[4]} -- chosen over p2p by this run (--headline-gather {args.headline_gather}): '
+                head_why = (f'{raw_other[4]} -- chosen over {head_path} by this run (--headline-gather {args.headline_gather}): '
                             f'{1e3 * raw_other[0] / args.steps:.3f} against {1e3 * dt / args.steps:.3f} ms per step')
-                wd.beat(f'headline loop once more on the faster path ({other})')
+                wd.beat(f'headline loop once more on the other path ({other})')
                 dt, dt_own, timers, comm_main, field = timed_loop(args.sync_gather)     # kernel timers / timeline of THAT path
                 dt_sync, comm_sync = raw_other[2], raw_other[3]
                 head_path = other
                 path_results[other]['ms_per_step'] = round(1e3 * dt / args.steps, 4)
             else:
                 wd.beat('back to the headline gather path')
-                spr.use_gather(args.gather)
+                spr.use_gather(head_path)
                 field = done(spr.reconstruct(a_d, to_host=False, wait=True))
         for v in path_results.values():
             for k_ in ('allreduce_ms', 'gather_ms', 'gather_exposed_ms'):
-                if v[k_] is not None:
+                if v.get(k_) is not None:
                     v[k_] = round(v[k_], 4)
     ms_per_step = 1e3 * dt / args.steps
     # collectives, from event pairs on the stream each one is ordered on (ROM.comm_timing): the ONE all-reduce of fit(), the
@@ -603,7 +646,8 @@ def run_rank(args):
             for i, k in enumerate(('stats_gram', 'project', 'reconstruct'))}
     # what lies BETWEEN the three kernels on the compute stream (same events): the host gap of fit() (download, eigen-solve,
     # upload), the join / release of the field exchange in front of reconstruct, and reconstruct -> the next step's Gram pass
-    if args.defer_reconstruct and not args.sync_gather:
+    deferred = spr._defers() and not head_sync
+    if deferred:
         # the reconstruct kernel of step k sits between the Gram kernel and the projection of step k + 1 (its event pair is the
         # one armed in step k + 1)
         gaps_ms = dict(gram_to_reconstruct=mean_ms([ev_ms(tm[0][1], tm[2][0]) for tm in timers[1:]]),
@@ -886,9 +930,26 @@ def run_rank(args):
         }
         out['rank_timeline_ms'] = {k_: (None if v != v else round(v, 4)) for k_, v in mine.items()}
         out['gaps_ms'] = {k_: (None if (v is None or v != v) else round(v, 4)) for k_, v in gaps_ms.items()}
-        out['reconstruct_launch'] = ("deferred (--defer-reconstruct): step k's reconstruct kernel is enqueued in the host gap of step "
-                                     "k + 1's fit(); the last one is flushed inside the timed region" if args.defer_reconstruct
-                                     else "behind the step's own projection")
+        out['reconstruct_launch'] = ("deferred (ROM.defer_reconstruct, the library's default for reconstruct(to_host=False, wait=False)): "
+                                     "step k's reconstruct kernel is enqueued in the host gap of step k + 1's fit(); the last one is "
+                                     "flushed inside the timed region" if deferred else "behind the step's own projection")
+        if dt_pipe is not None:
+            # N = 1: the same K steps with reconstruct(to_host=False, wait=False) -- the asynchronous form, deferred into the next
+            # fit()'s host gap unless --no-defer-reconstruct -- every step inside the timed region, the last one flushed in it
+            out['ms_per_step_pipelined'] = round(1e3 * dt_pipe / args.steps, 4)
+            out['value_pipelined'] = round(x_bytes / (dt_pipe / args.steps) / 1e9, 2)
+            out['pipelined_loop'] = ('reconstruct(to_host=False, wait=False): ' + ('launch deferred into the next fit()\'s host gap '
+                                     '(ROM.defer_reconstruct, default)' if spr._defers() else 'launched behind its own projection'))
+        if ballast is not None:
+            out['ballast_GB'] = round(ballast.numel() / 1e9, 2)
+        free_b, total_b = torch.cuda.mem_get_info(eng.device)
+        px_ = spr.__dict__.get('_p2p')
+        out['hbm'] = dict(total_GB=round(total_b / 1e9, 2), free_at_end_GB=round(free_b / 1e9, 2),
+                          torch_peak_allocated_GB=round(torch.cuda.max_memory_allocated() / 1e9, 2),
+                          torch_peak_reserved_GB=round(torch.cuda.max_memory_reserved() / 1e9, 2),
+                          p2p_buffers_GB=round(getattr(px_, 'total_bytes', 0) / 1e9, 2) if px_ is not None and px_.base else 0.0,
+                          note='free/total: hipMemGetInfo on this rank at the end of the run (everything of the process and of RCCL); the p2p '
+                               'buffers come from hipMalloc, outside torch\'s allocator')
         out['compute_stream'] = 'own (non-default) stream' if own_stream else 'default stream'
         out['hw_queues'] = os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)')
         out['gap_filler'] = dict(on=bool(spr.gap_filler), rows_per_fit=(int(np.mean(fill_rows)) if fill_rows else 0),

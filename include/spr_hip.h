@@ -71,11 +71,12 @@ extern "C" {
 #define SPR_MAX_R_WIDE 1024  /* ... the widest basis the placement / solve kernels accept (r <= m in the reference, :336) */
 
 /* Bumped whenever an entry point changes its argument list or meaning (round 3 -> 4: spr_qr_steps_f64 gained
- * first_exact, new entry points arrived; 4 -> 5: the CU-free field exchange spr_p2p_* / spr_field_gather_p2p*,
- * spr_field_unstage_blocks_f64).  A binding written for another value must refuse to
+ * first_exact, new entry points arrived; round 5, still 4: the CU-free field exchange spr_p2p_* / spr_field_gather_p2p*,
+ * spr_field_unstage_blocks_f64; 4 -> 5 (round 6): spr_field_gather_p2p gained d_status and the poison bit, the communicator
+ * entry points spr_comm_* arrived).  A binding written for another value must refuse to
  * call into this library: openmeasure_amd/_lib.py compares spr_abi_version() with the value its prototypes were
  * written for. */
-#define SPR_ABI_VERSION 4
+#define SPR_ABI_VERSION 5
 int spr_abi_version(void);
 const char *spr_last_error(void);
 /* number of compute units of the current device (used to size persistent grids) */
@@ -350,16 +351,25 @@ int spr_field_unstage_blocks_f64(const double *d_stage, int32_t world, int32_t n
  *                                  buffer (own or mapped); used on the copy streams.
  *   spr_p2p_flags_set / _wait      ONE single-wave kernel that raises / awaits n <= 128 counters (host table of device
  *                                  pointers, passed to the kernel by value): what the compute stream uses.  The wait gives
- *                                  up after timeout_s seconds of the device's wall clock and leaves (index + 1, value seen)
- *                                  in the two words at d_status (NULL: nowhere) -- every wave reaches its exit.
+ *                                  up after timeout_s seconds of the device's wall clock -- or at once on a counter that
+ *                                  carries the poison bit, spr_p2p_poison_bit() = 1 << 62: "this exchange is broken" -- and
+ *                                  leaves (index + 1, value seen) in the two words at d_status (NULL: nowhere) -- every
+ *                                  wave reaches its exit.
  *   spr_p2p_copy                   one device-to-device copy through the SDMA engines (hipMemcpyDeviceToDeviceNoCU).
  *   spr_field_gather_p2p           this rank's block of the field -- columns [first, first + n_loc) of the n_p rows of its
  *                                  own (n_p, ldo) copy d_field -- into the same place of every peer's copy: per peer p, on
- *                                  streams[p] (streams may repeat): wait until *d_release_flag[p] >= release_value (a counter
- *                                  in THIS rank's memory that peer p raises when it no longer reads what its copy held; 0 =
- *                                  no wait; a single-wave kernel that gives up after release_timeout_s), n_p copies of n_loc doubles, *d_peer_arrive_flag[p] = arrive_value (a counter in
- *                                  peer p's memory), and, if given, *d_pushed_flag[p] = arrive_value (this rank's own: "the
- *                                  push to p has left").  The caller orders streams[p] behind the kernel that wrote the block.
+ *                                  streams[p] (streams may repeat; the peers of one stream are served together: one wait
+ *                                  kernel, their copies, one kernel for their counters): wait until *d_release_flag[p] >=
+ *                                  release_value (a counter in THIS rank's memory that peer p raises when it no longer reads
+ *                                  what its copy held; 0 = no wait; a single-wave kernel that gives up after
+ *                                  release_timeout_s), n_p copies of n_loc doubles, *d_peer_arrive_flag[p] = arrive_value (a
+ *                                  counter in peer p's memory), and, if given, *d_pushed_flag[p] = arrive_value (this rank's
+ *                                  own: "the push to p has left").  A release wait that gives up leaves (p + 1, value seen) in
+ *                                  the two words at d_status (page-locked host or device memory the kernels can reach; NULL:
+ *                                  nowhere) and -- an SDMA copy cannot be taken back -- every arrival counter raised while
+ *                                  *d_status != 0 carries the poison bit: the peer's join of this gather and this rank's own
+ *                                  both fail, nobody is handed a field that was overwritten while it may still have been read.
+ *                                  The caller orders streams[p] behind the kernel that wrote the block.
  *   spr_field_gather_p2p_join      `stream` waits (one kernel) until every one of the n counters -- the peers' arrivals and
  *                                  this rank's own pushed counters -- has reached arrive_value.
  *   spr_field_gather_p2p_release   *d_peer_release_flag[p] = value for every peer (one kernel), behind everything enqueued
@@ -379,10 +389,11 @@ int spr_p2p_wait(void *d_flag, uint64_t value, void *stream);
 int spr_p2p_flags_set(void *const *d_flags, int32_t n, uint64_t value, void *stream);
 int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t value, double timeout_s, void *d_status, void *stream);
 int spr_p2p_copy(void *d_dst, const void *d_src, int64_t n_bytes, void *stream);
+uint64_t spr_p2p_poison_bit(void);
 int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc, int32_t n_peers,
                          void *const *d_peer_field, void *const *d_release_flag, uint64_t release_value,
                          double release_timeout_s, void *const *d_peer_arrive_flag, uint64_t arrive_value,
-                         void *const *d_pushed_flag, void *const *streams);
+                         void *const *d_pushed_flag, void *const *streams, void *d_status);
 int spr_field_gather_p2p_join(void *const *d_flags, int32_t n_flags, uint64_t arrive_value, double timeout_s, void *d_status,
                               void *stream);
 int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream);

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SPR_HIP_LIBRARY: load another build of the same library (the ASan host build of `make asan`, tests only)
 LIB_PATH = os.environ.get('SPR_HIP_LIBRARY') or os.path.join(_HERE, 'libspr_hip.so')
 
-SPR_ABI_VERSION = 4          # include/spr_hip.h: the value these prototypes were written for
+SPR_ABI_VERSION = 5          # include/spr_hip.h: the value these prototypes were written for
 SPR_MAX_M = 256
 SPR_MAX_M_WIDE = 512
 SPR_MAX_R = 128
@@ -83,7 +83,8 @@ PROTOTYPES = {
     'spr_p2p_flags_set': (C.c_int, [_p, _i32, _u64, _p]),
     'spr_p2p_flags_wait': (C.c_int, [_p, _i32, _u64, _dbl, _p, _p]),
     'spr_p2p_copy': (C.c_int, [_p, _p, _i64, _p]),
-    'spr_field_gather_p2p': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p, _u64, _dbl, _p, _u64, _p, _p]),
+    'spr_p2p_poison_bit': (_u64, []),
+    'spr_field_gather_p2p': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p, _u64, _dbl, _p, _u64, _p, _p, _p]),
     'spr_field_gather_p2p_join': (C.c_int, [_p, _i32, _u64, _dbl, _p, _p]),
     'spr_field_gather_p2p_release': (C.c_int, [_p, _i32, _u64, _p]),
     'spr_qr_workspace': (_sz, [_i64]),

@@ -22,6 +22,7 @@
 // copy as a blit kernel takes 15 ms next to that kernel; write/wait values work on IPC-mapped device memory.
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "common.hpp"
 
@@ -34,6 +35,20 @@ hipMemcpyKind p2p_kind() {
     blit = (e && atoi(e) == 1) ? 1 : 0;
   }
   return blit ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToDeviceNoCU;
+}
+// SPR_P2P_PROBE=1: spr_field_gather_p2p prints the host time of each of its runtime calls (tools/p2p_push_probe.py)
+bool p2p_probe() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("SPR_P2P_PROBE");
+    on = (e && atoi(e) == 1) ? 1 : 0;
+  }
+  return on == 1;
+}
+double host_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 }  // namespace
 
@@ -139,35 +154,50 @@ extern "C" int spr_p2p_copy(void *d_dst, const void *d_src, int64_t n_bytes, voi
 // (profiles/r05_p2p_gap_experiments.txt).  On the COMPUTE stream the exchange therefore uses ONE kernel per release and ONE per
 // join, over a table of counters passed by value; completion of this rank's own pushes is a counter as well (written on the
 // copy stream behind the copies), so the compute stream never waits for an event of another queue.
+//
+// POISON (round 6).  Counters only ever grow and every wait is "counter >= value", so one bit far above any gather count says
+// "the exchange this counter belongs to is broken": a wait that reads it fails at once (status words, like a time-out), and a
+// push whose wait for the peer's release failed raises the arrival counters it owes WITH that bit -- the peer's join and the
+// pusher's own join of that gather then both fail instead of handing out a field that was overwritten while it may still have
+// been read, or one assembled around a block nobody vouches for.
 namespace {
 constexpr int kMaxFlags = 128;
+constexpr unsigned long long kPoison = 1ull << 62;
 struct FlagTable {
   unsigned long long *p[kMaxFlags];
+  unsigned short id[kMaxFlags];      // what a failing lane reports as its index (a sub-table keeps the caller's numbering)
 };
 
-__global__ __launch_bounds__(128) void p2p_flags_set_kernel(FlagTable t, int n, unsigned long long value) {
+// *t.p[i] = value for all i -- OR value | POISON when the word at `gate` (NULL: no gate) is non-zero: the status word a failed
+// release wait of this push has left (see spr_field_gather_p2p).
+__global__ __launch_bounds__(128) void p2p_flags_set_kernel(FlagTable t, int n, unsigned long long value,
+                                                            const unsigned long long *__restrict__ gate) {
+  unsigned long long v = value;
+  if (gate && __hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) v |= kPoison;
   for (int i = threadIdx.x; i < n; i += blockDim.x)
-    __hip_atomic_store(t.p[i], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(t.p[i], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Every lane polls one counter until it has reached `value`.  Exit condition every wave reaches: `timeout_ticks` of the
-// 100 MHz wall clock; a lane that gives up leaves (its index + 1) in status[0] and the value it saw in status[1] -- the
-// host reads the two words where it synchronises anyway and raises.
+// 100 MHz wall clock, or a poisoned counter; a lane that gives up leaves (its index + 1) in status[0] and the value it saw in
+// status[1] (bit 62 set: poisoned, otherwise timed out) -- the host reads the two words where it synchronises anyway and raises.
 __global__ __launch_bounds__(128) void p2p_flags_wait_kernel(FlagTable t, int n, unsigned long long value,
                                                              unsigned long long timeout_ticks,
                                                              unsigned long long *__restrict__ status) {
   const unsigned long long t0 = wall_clock64();
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     unsigned long long seen;
-    while ((seen = __hip_atomic_load(t.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < value) {
-      if (wall_clock64() - t0 > timeout_ticks) {
-        if (status) {
-          __hip_atomic_store(status + 1, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(status, (unsigned long long)(i + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        break;
-      }
+    bool bad = false;
+    for (;;) {
+      seen = __hip_atomic_load(t.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seen & kPoison) { bad = true; break; }
+      if (seen >= value) break;
+      if (wall_clock64() - t0 > timeout_ticks) { bad = true; break; }
       __builtin_amdgcn_s_sleep(8);
+    }
+    if (bad && status) {
+      __hip_atomic_store(status + 1, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(status, (unsigned long long)(t.id[i] + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: what the counters announce is visible to what runs next
@@ -178,18 +208,32 @@ int fill_table(FlagTable &t, void *const *ptrs, int n, const char *who) {
   for (int i = 0; i < n; ++i) {
     SPR_REQUIRE(ptrs[i] && (uintptr_t)ptrs[i] % 8 == 0, SPR_E_INVALID, "%s: counter %d is NULL or unaligned", who, i);
     t.p[i] = static_cast<unsigned long long *>(ptrs[i]);
+    t.id[i] = (unsigned short)i;
   }
+  return SPR_OK;
+}
+
+int launch_wait(const FlagTable &t, int n, uint64_t value, double timeout_s, void *d_status, hipStream_t st) {
+  hipLaunchKernelGGL(p2p_flags_wait_kernel, dim3(1), dim3(n > 64 ? 128 : 64), 0, st, t, n, (unsigned long long)value,
+                     (unsigned long long)(timeout_s * 1e8), static_cast<unsigned long long *>(d_status));
+  SPR_LAUNCH_CHECK();
+  return SPR_OK;
+}
+
+int launch_set(const FlagTable &t, int n, uint64_t value, const void *d_gate, hipStream_t st) {
+  hipLaunchKernelGGL(p2p_flags_set_kernel, dim3(1), dim3(n > 64 ? 128 : 64), 0, st, t, n, (unsigned long long)value,
+                     static_cast<const unsigned long long *>(d_gate));
+  SPR_LAUNCH_CHECK();
   return SPR_OK;
 }
 }  // namespace
 
+extern "C" uint64_t spr_p2p_poison_bit(void) { return kPoison; }
+
 extern "C" int spr_p2p_flags_set(void *const *d_flags, int32_t n, uint64_t value, void *stream) {
   FlagTable t;
   if (int rc = fill_table(t, d_flags, n, "spr_p2p_flags_set")) return rc;
-  hipLaunchKernelGGL(p2p_flags_set_kernel, dim3(1), dim3(n > 64 ? 128 : 64), 0, static_cast<hipStream_t>(stream), t, (int)n,
-                     (unsigned long long)value);
-  SPR_LAUNCH_CHECK();
-  return SPR_OK;
+  return launch_set(t, n, value, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t value, double timeout_s, void *d_status,
@@ -198,44 +242,87 @@ extern "C" int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t valu
   if (int rc = fill_table(t, d_flags, n, "spr_p2p_flags_wait")) return rc;
   SPR_REQUIRE(timeout_s > 0.0 && timeout_s <= 3600.0, SPR_E_INVALID, "spr_p2p_flags_wait: timeout_s=%g (0, 3600]", timeout_s);
   SPR_REQUIRE(d_status == nullptr || (uintptr_t)d_status % 8 == 0, SPR_E_INVALID, "spr_p2p_flags_wait: unaligned status");
-  hipLaunchKernelGGL(p2p_flags_wait_kernel, dim3(1), dim3(n > 64 ? 128 : 64), 0, static_cast<hipStream_t>(stream), t, (int)n,
-                     (unsigned long long)value, (unsigned long long)(timeout_s * 1e8),
-                     static_cast<unsigned long long *>(d_status));
-  SPR_LAUNCH_CHECK();
-  return SPR_OK;
+  return launch_wait(t, n, value, timeout_s, d_status, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc,
                                     int32_t n_peers, void *const *d_peer_field, void *const *d_release_flag,
                                     uint64_t release_value, double release_timeout_s, void *const *d_peer_arrive_flag,
-                                    uint64_t arrive_value, void *const *d_pushed_flag, void *const *streams) {
+                                    uint64_t arrive_value, void *const *d_pushed_flag, void *const *streams, void *d_status) {
   SPR_REQUIRE(d_field && n_p >= 1 && first >= 0 && n_loc >= 0 && ldo >= first + n_loc, SPR_E_INVALID,
               "spr_field_gather_p2p: n_p=%d first=%lld n_loc=%lld ldo=%lld", n_p, (long long)first, (long long)n_loc,
               (long long)ldo);
-  SPR_REQUIRE(n_peers >= 1 && d_peer_field && d_peer_arrive_flag && streams, SPR_E_INVALID,
-              "spr_field_gather_p2p: n_peers=%d (>= 1) / NULL peer table", n_peers);
+  SPR_REQUIRE(n_peers >= 1 && 2 * n_peers <= kMaxFlags && d_peer_field && d_peer_arrive_flag && streams, SPR_E_INVALID,
+              "spr_field_gather_p2p: n_peers=%d (1..%d) / NULL peer table", n_peers, kMaxFlags / 2);
   SPR_REQUIRE(release_value == 0 || (d_release_flag && release_timeout_s > 0.0 && release_timeout_s <= 3600.0), SPR_E_INVALID,
               "spr_field_gather_p2p: release flags missing / release_timeout_s=%g outside (0, 3600]", release_timeout_s);
-  const hipMemcpyKind kind = p2p_kind();
+  SPR_REQUIRE(d_status == nullptr || (uintptr_t)d_status % 8 == 0, SPR_E_INVALID, "spr_field_gather_p2p: unaligned status");
   for (int p = 0; p < n_peers; ++p) {
-    hipStream_t st = static_cast<hipStream_t>(streams[p]);
-    SPR_REQUIRE(d_peer_field[p] && d_peer_arrive_flag[p], SPR_E_INVALID, "spr_field_gather_p2p: peer %d has a NULL pointer", p);
-    if (release_value) {
-      // the peer must have let go of what this buffer held (it raises the slot when it enters its own gather).  The wait is the
-      // library's own single-wave kernel, not hipStreamWaitValue64: that one polls without an exit, and a copy stream left
-      // behind a peer that has died would spin until the process is killed -- every wave must reach its exit.  After
-      // release_timeout_s the copy goes ahead (the peer is gone; the join of this gather reports it).
-      void *one[1] = {d_release_flag[p]};
-      if (int rc = spr_p2p_flags_wait(one, 1, release_value, release_timeout_s, nullptr, st)) return rc;
+    SPR_REQUIRE(d_peer_field[p] && d_peer_arrive_flag[p] && (uintptr_t)d_peer_arrive_flag[p] % 8 == 0, SPR_E_INVALID,
+                "spr_field_gather_p2p: peer %d has a NULL / unaligned pointer", p);
+    SPR_REQUIRE(!release_value || (d_release_flag[p] && (uintptr_t)d_release_flag[p] % 8 == 0), SPR_E_INVALID,
+                "spr_field_gather_p2p: release counter %d is NULL or unaligned", p);
+    SPR_REQUIRE(!d_pushed_flag || !d_pushed_flag[p] || (uintptr_t)d_pushed_flag[p] % 8 == 0, SPR_E_INVALID,
+                "spr_field_gather_p2p: pushed counter %d is unaligned", p);
+  }
+  const hipMemcpyKind kind = p2p_kind();
+  const bool probe = p2p_probe();
+  double t_prev = probe ? host_us() : 0.0;
+  auto lap = [&](const char *what, int p) {
+    if (!probe) return;
+    const double t = host_us();
+    fprintf(stderr, "[p2p probe] %-8s peer %2d  %8.1f us\n", what, p, t - t_prev);
+    t_prev = t;
+  };
+  // The peers of ONE copy stream are served together: one wait kernel for their releases, their copies, one kernel that raises
+  // their arrival (and this rank's pushed) counters -- 2 launches per stream instead of 3 per peer (7 peers on 3 streams:
+  // 6 + 7 n_p calls instead of 21 + 7 n_p; 0.34 ms of host time per gather before).  A peer's arrival is announced when the
+  // stream's last copy has landed; the join needs every block anyway.
+  bool done[kMaxFlags] = {false};
+  for (int p0 = 0; p0 < n_peers; ++p0) {
+    if (done[p0]) continue;
+    hipStream_t st = static_cast<hipStream_t>(streams[p0]);
+    FlagTable rel, arr;
+    int n_rel = 0, n_arr = 0;
+    for (int p = p0; p < n_peers; ++p) {
+      if (done[p] || static_cast<hipStream_t>(streams[p]) != st) continue;
+      if (release_value) {
+        rel.p[n_rel] = static_cast<unsigned long long *>(d_release_flag[p]);
+        rel.id[n_rel++] = (unsigned short)p;
+      }
+      arr.p[n_arr] = static_cast<unsigned long long *>(d_peer_arrive_flag[p]);
+      arr.id[n_arr++] = (unsigned short)p;
+      if (d_pushed_flag && d_pushed_flag[p]) {   // "my push to peer p has left": a counter of THIS rank, raised behind the copies
+        arr.p[n_arr] = static_cast<unsigned long long *>(d_pushed_flag[p]);
+        arr.id[n_arr++] = (unsigned short)p;
+      }
     }
-    if (n_loc > 0) {
-      double *dst = static_cast<double *>(d_peer_field[p]);
-      for (int v = 0; v < n_p; ++v)   // contiguous pieces: one row of the (n_p, ldo) field each
-        SPR_HIP_TRY(hipMemcpyAsync(dst + (int64_t)v * ldo + first, d_field + (int64_t)v * ldo + first, (size_t)n_loc * 8, kind, st));
+    if (n_rel) {
+      // the peers must have let go of what their buffer held (each raises its slot when it enters its own gather).  The wait
+      // is the library's own single-wave kernel, not hipStreamWaitValue64: that one polls without an exit, and a copy stream
+      // left behind a peer that has died would spin until the process is killed -- every wave must reach its exit.  A wait
+      // that gives up (release_timeout_s, or a poisoned counter) leaves (peer index + 1, value seen) at d_status; the copies
+      // below cannot be taken back (an SDMA command is unconditional), but the arrival counters behind them are then raised
+      // WITH the poison bit: neither the peer's join nor this rank's own can succeed -- both raise, no field is handed out.
+      if (int rc = launch_wait(rel, n_rel, release_value, release_timeout_s, d_status, st)) return rc;
+      lap("wait", p0);
     }
-    SPR_HIP_TRY(hipStreamWriteValue64(st, d_peer_arrive_flag[p], arrive_value, 0));
-    if (d_pushed_flag && d_pushed_flag[p])   // "my push to peer p has left": a counter of THIS rank, raised behind the copies
-      SPR_HIP_TRY(hipStreamWriteValue64(st, d_pushed_flag[p], arrive_value, 0));
+    for (int p = p0; p < n_peers; ++p) {
+      if (done[p] || static_cast<hipStream_t>(streams[p]) != st) continue;
+      done[p] = true;
+      if (n_loc > 0) {
+        double *dst = static_cast<double *>(d_peer_field[p]);
+        if (n_p == 1 || ldo == n_loc) {          // one contiguous piece
+          SPR_HIP_TRY(hipMemcpyAsync(dst + first, d_field + first, (size_t)n_loc * 8 * (ldo == n_loc ? n_p : 1), kind, st));
+        } else {
+          for (int v = 0; v < n_p; ++v)          // contiguous pieces: one row of the (n_p, ldo) field each
+            SPR_HIP_TRY(hipMemcpyAsync(dst + (int64_t)v * ldo + first, d_field + (int64_t)v * ldo + first, (size_t)n_loc * 8, kind, st));
+        }
+        lap("copy", p);
+      }
+    }
+    if (int rc = launch_set(arr, n_arr, arrive_value, d_status, st)) return rc;
+    lap("arrive", p0);
   }
   return SPR_OK;
 }

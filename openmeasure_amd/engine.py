@@ -46,7 +46,6 @@ class HipEngine:
         self._force_stream = os.environ.get('SPR_PROJECT_STREAM') == '1'   # A/B runs: streamed-W projection for every shape
         self._dl_kernel = os.environ.get('SPR_DL_KERNEL', '1') != '0'      # A/B: small downloads by kernel + polled ticket (default) or by copy + event
         self._stage = None                                   # ring of pinned host staging buffers for small uploads
-        self._dstage = None                                  # pinned landing buffer for small downloads
         # page-locked buffers, the copy threads and the side stream go back while the interpreter and the HIP runtime are
         # still whole (atexit runs before module teardown): what is left to destructors at process exit runs in no
         # particular order against the runtime's own shutdown
@@ -70,8 +69,8 @@ class HipEngine:
         pool = self.__dict__.pop('_copy_pool', None)
         if pool is not None:
             pool.shutdown(wait=wait, cancel_futures=not wait)
-        self._stage = self._dstage = None
-        for k in ('_dstage2', '_dstage_ev', '_dl', '_reuse', '_side'):
+        self._stage = None
+        for k in ('_dstage2', '_dstage_slots', '_dl', '_reuse', '_side'):
             self.__dict__.pop(k, None)
         try:
             torch._C._host_emptyCache()                       # cached page-locked blocks back to the OS
@@ -153,17 +152,30 @@ class HipEngine:
             if then is not None:
                 then()
             return out
-        if self._dstage is None or self._dstage.numel() < nbytes:
-            self._dstage = None
-            self._dstage = torch.empty(max(1 << 20, -(-nbytes // (1 << 20)) << 20), dtype=torch.uint8, pin_memory=True)
-            self._dstage_ev = torch.cuda.Event()
-        buf = self._dstage[:nbytes].view(t.dtype).view(t.shape)
+        # one landing buffer PER NESTING DEPTH: `then` may itself download (a deferred reconstruct launched from fit()'s host
+        # gap runs collective set-up with its own to_host() calls) -- a nested call must not land in the buffer, or behind the
+        # event, this call is about to read
+        depth = self._dl_depth
+        slots = self.__dict__.setdefault('_dstage_slots', {})
+        ent = slots.get(depth)
+        if ent is None or ent[0].numel() < nbytes:
+            slots[depth] = None
+            ent = slots[depth] = (torch.empty(max(1 << 20, -(-nbytes // (1 << 20)) << 20), dtype=torch.uint8, pin_memory=True),
+                                  torch.cuda.Event())
+        stage, ev = ent
+        buf = stage[:nbytes].view(t.dtype).view(t.shape)
         buf.copy_(t, non_blocking=True)
-        self._dstage_ev.record(torch.cuda.current_stream(self.device))
+        ev.record(torch.cuda.current_stream(self.device))
         if then is not None:
-            then()
-        self._dstage_ev.synchronize()
+            self._dl_depth = depth + 1
+            try:
+                then()
+            finally:
+                self._dl_depth = depth
+        ev.synchronize()
         return buf.numpy().copy()
+
+    _dl_depth = 0                       # how many to_host() calls are inside their `then` hook right now
 
     _DL_KERNEL_BYTES = 1 << 20          # downloads up to this size go through spr_download_bytes
     _DL_SPIN_S = 2e-3                   # the host polls the ticket this long before it blocks on the event instead
@@ -176,12 +188,17 @@ class HipEngine:
         (a 93 ms Gram pass is not worth a spinning core)."""
         import time
         torch = self.torch
-        dl = getattr(self, '_dl', None)
+        # one buffer + ticket PER NESTING DEPTH (see to_host): a download issued from inside `then` takes the next slot, so the
+        # payload and the ticket this call polls are its own
+        depth = self._dl_depth
+        slots = self.__dict__.setdefault('_dl', {})
+        dl = slots.get(depth)
         if dl is None:
             buf = torch.empty(self._DL_KERNEL_BYTES + 64, dtype=torch.uint8, pin_memory=True)
             arr = buf.numpy()
-            dl = self._dl = dict(buf=buf, data=arr[:self._DL_KERNEL_BYTES], ticket=arr[self._DL_KERNEL_BYTES:self._DL_KERNEL_BYTES + 8].view(np.uint64),
-                                 seq=0, ev=torch.cuda.Event())
+            dl = slots[depth] = dict(buf=buf, data=arr[:self._DL_KERNEL_BYTES],
+                                     ticket=arr[self._DL_KERNEL_BYTES:self._DL_KERNEL_BYTES + 8].view(np.uint64), seq=0,
+                                     ev=torch.cuda.Event())
             dl['ticket'][0] = 0
         dl['seq'] += 1
         seq = dl['seq']
@@ -190,7 +207,11 @@ class HipEngine:
                                                seq, st.cuda_stream), 'spr_download_bytes')
         dl['ev'].record(st)
         if then is not None:
-            then()
+            self._dl_depth = depth + 1
+            try:
+                then()
+            finally:
+                self._dl_depth = depth
         ticket = dl['ticket']
         t_end = time.perf_counter() + self._DL_SPIN_S
         while ticket[0] != seq:

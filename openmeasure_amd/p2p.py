@@ -25,6 +25,16 @@ gather is a collective call; b = k % n_buf, n_buf = 1 unless asked otherwise):
             queue is waited for: behind SDMA copies such waits cost 0.9 ms per step (profiles/r05_p2p_gap_experiments.txt).
 The field handed out is a VIEW of buffer b: it stays valid until this rank enters its next gather.  (A second buffer only lets
 the peers' COPY streams run a step ahead of a slow rank; no compute stream ever waits for a push, so one buffer is the default.)
+
+Failure (round 6: no silent path to a torn field).  Every wait has a wall-clock exit and leaves (counter, value seen) in
+page-locked status words this object reads at every gather (check()).  A join that gives up: RuntimeError naming the counter.  A
+push whose wait for the peer's RELEASE gives up (the peer has not entered gather k within RELEASE_TIMEOUT_S: it may still be
+reading what its buffer holds) cannot take its copies back -- an SDMA command is unconditional -- so the arrival counters it owes
+are raised WITH the poison bit (spr_p2p_poison_bit): the peer's join of that gather and the pusher's own both fail, both ranks
+raise, nobody is handed the field.  RELEASE_TIMEOUT_S (default 3 x the join's) is longer than JOIN_TIMEOUT_S on purpose: a peer
+that is merely slow makes the pusher's JOIN give up first (the pusher raises; the peer's buffer is never touched while it reads),
+and only a peer silent for RELEASE_TIMEOUT_S can be written over -- with the poison behind the copy.  Both are settable:
+SPR_P2P_JOIN_TIMEOUT_S (default 600 s, torch.distributed's own default for a collective) and SPR_P2P_RELEASE_TIMEOUT_S.
 """
 from __future__ import annotations
 
@@ -40,7 +50,9 @@ _FLAG_BYTES = 4096
 _SCRATCH_BYTES = 4096
 _REASON_BYTES = 200                  # a rank's verdict and the reason it gives, all-gathered (_agree)
 _BUS_ID_BYTES = 24                   # "0000:c1:00.0" and its terminator, with room
-_MAX_WORLD = 100                     # 5 counter arrays of `world` uint64 in the 4 KB counter page
+# 5 counter arrays of `world` uint64 in the 4 KB counter page (world <= 102) AND a join table of 2 (world - 1) counters in one
+# kernel argument of 128 pointers (csrc/p2p.hip kMaxFlags): beyond it the join would be refused mid-gather
+_MAX_WORLD = 65
 _KINDS = {'coarse': 0, 'fine': 1, 'uncached': 2}
 
 
@@ -64,7 +76,8 @@ class P2PFieldGather:
     """One per sharded ROM object; every method that says COLLECTIVE must be called by all ranks."""
 
     SELFTEST_TIMEOUT_S = 10.0
-    JOIN_TIMEOUT_S = 120.0           # the join kernel gives up after this long (status words; see check())
+    JOIN_TIMEOUT_S = 600.0           # the join kernel gives up after this long (status words; see check()); SPR_P2P_JOIN_TIMEOUT_S
+    RELEASE_TIMEOUT_S = None         # a push waits this long for the peer's release; None: 3 x the join's; SPR_P2P_RELEASE_TIMEOUT_S
     FIRST_TIMEOUT_S = 20.0           # ... and after this long in the first exchange through new buffers (ROM._p2p_first_exchange)
 
     def __init__(self, eng, world, rank, all_gather, double_buffer=False, loopback=0):
@@ -76,7 +89,14 @@ class P2PFieldGather:
         if self.loopback:
             world = 1 + self.loopback
         if world > _MAX_WORLD:
-            raise P2PUnavailable(f'{world} ranks exceed the {_MAX_WORLD} the counter page holds')
+            raise P2PUnavailable(f'{world} ranks exceed the {_MAX_WORLD} one join kernel can wait for')
+        for attr, key in (('JOIN_TIMEOUT_S', 'SPR_P2P_JOIN_TIMEOUT_S'), ('RELEASE_TIMEOUT_S', 'SPR_P2P_RELEASE_TIMEOUT_S')):
+            env = os.environ.get(key)
+            if env:
+                v = float(env)
+                if not 0.0 < v <= 3600.0:
+                    raise ValueError(f'{key}={env}: seconds in (0, 3600]')
+                setattr(self, attr, v)
         self.eng, self.world, self.rank = eng, int(world), int(rank)
         self.lib = eng.lib
         self._all_gather = all_gather                          # tensor -> (world, *shape) tensor, COLLECTIVE
@@ -99,14 +119,18 @@ class P2PFieldGather:
         self._pool = [torch.cuda.Stream(eng.device) for _ in range(n_streams if self.peers else 0)]
         self.streams = [self._pool[i % n_streams] for i in range(len(self.peers))]
         self.selftest_report = None
+        self._ever_allocated = False                           # ensure() has allocated before (identical on all ranks: it is collective)
         # None until the first full-size exchange through these buffers has been compared, block by block, with what the peers
         # say they sent (sparse_sensing.py, ROM._p2p_first_exchange); then a short report
         self.verified = None
-        self.host_ms = dict(begin=0.0, push=0.0, join=0.0, calls=0)   # host wall time spent issuing (bench.py reports the means)
+        self.host_ms = dict(begin=0.0, push=0.0, push_order=0.0, push_call=0.0, join=0.0, calls=0)   # host wall time spent issuing (bench.py reports the means)
         # where a join kernel that gives up leaves (counter index + 1, value seen): page-locked HOST memory the kernel writes
         # directly, so that check() is a plain memory read -- no copy, no synchronisation -- and can run at every gather
-        self._status = torch.zeros(2, dtype=torch.int64).pin_memory()
+        # ... words 0-1: the join; words 2-3: a push whose wait for a peer's release gave up (and the gate of the poison, p2p.hip)
+        self._status = torch.zeros(4, dtype=torch.int64).pin_memory()
         self._status_np = self._status.numpy()
+        self._poison = int(self.lib.spr_p2p_poison_bit())
+        self._tabs = {}                                        # pointer tables of the calls, built once per allocation
 
     # ------------------------------------------------------------------ set-up (COLLECTIVE)
     def ensure(self, n_p, n_total):
@@ -125,8 +149,11 @@ class P2PFieldGather:
             raise ValueError("SPR_P2P_MEMORY: 'coarse' or 'uncached'")
         kinds = [want] if want else ['coarse', 'uncached']
         why = ''
-        for kind in kinds:
-            self.close()
+        for i, kind in enumerate(kinds):
+            # COLLECTIVE teardown of what an earlier allocation / attempt left: the ranks must meet here whether or not THIS rank
+            # has anything to free (an allocation that failed on some ranks only -- ADVICE r05 -- would otherwise leave those
+            # ranks one collective ahead of the others); every rank takes this branch with the same (i, had buffers before) history
+            self.close(collective=True, rendezvous=(i > 0 or self._ever_allocated))
             ok, why = self._allocate(need, kind)
             if ok:
                 self.shape = (n_p, n_total)
@@ -140,6 +167,8 @@ class P2PFieldGather:
     def _allocate(self, need, kind):
         """-> (ok on ALL ranks, reason).  COLLECTIVE."""
         torch = self.eng.torch
+        self._ever_allocated = True
+        self._tabs = {}
         self.field_bytes = need
         copies = self.n_buf * (1 + self.loopback)
         total = copies * need + _SCRATCH_BYTES
@@ -149,7 +178,14 @@ class P2PFieldGather:
         ok, why = True, ''
         try:
             base, fbase = C.c_void_p(), C.c_void_p()
-            _lib.check(self.lib.spr_p2p_alloc(total, _KINDS[kind], C.byref(base), h_field), 'spr_p2p_alloc')
+            rc = self.lib.spr_p2p_alloc(total, _KINDS[kind], C.byref(base), h_field)
+            if rc != 0:
+                # the buffers come from hipMalloc, outside PyTorch's allocator, which keeps what its tensors have freed: give
+                # that back to the runtime and ask once more (config 5 at N = 8 leaves a few GB next to the shard and the basis)
+                torch.cuda.synchronize(self.eng.device)
+                torch.cuda.empty_cache()
+                rc = self.lib.spr_p2p_alloc(total, _KINDS[kind], C.byref(base), h_field)
+            _lib.check(rc, 'spr_p2p_alloc')
             self.base, self.total_bytes = int(base.value), total
             _lib.check(self.lib.spr_p2p_alloc(_FLAG_BYTES, _KINDS['fine'], C.byref(fbase), h_flags), 'spr_p2p_alloc')
             self.fbase = int(fbase.value)
@@ -312,6 +348,15 @@ class P2PFieldGather:
         return True, ''
 
     # ------------------------------------------------------------------ one gather
+    def _table(self, key, make):
+        t = self._tabs.get(key)
+        if t is None:
+            t = self._tabs[key] = make()
+        return t
+
+    def release_timeout_s(self):
+        return float(self.RELEASE_TIMEOUT_S) if self.RELEASE_TIMEOUT_S else min(3600.0, 3.0 * float(self.JOIN_TIMEOUT_S))
+
     def begin(self):
         """Enter gather k (COLLECTIVE): tell the peers which of my copies they may overwrite, and hand out the tensor the
         reconstruct kernel writes this rank's block into -- the (n_p, n_total) view of buffer k % n_buf."""
@@ -320,7 +365,7 @@ class P2PFieldGather:
         self.check()
         st = torch.cuda.current_stream(eng.device).cuda_stream
         if self.peers:
-            tab = _ptr_array([self._peer_flag(q, 'release') for q in self.peers])
+            tab = self._table('release', lambda: _ptr_array([self._peer_flag(q, 'release') for q in self.peers]))
             _lib.check(self.lib.spr_field_gather_p2p_release(tab, len(self.peers), self.k, st), 'spr_field_gather_p2p_release')
         b = self.k % self.n_buf
         n_p, n_total = self.shape
@@ -335,19 +380,27 @@ class P2PFieldGather:
         b = self.k % self.n_buf
         n_p, n_total = self.shape
         if self.peers:
+            # (a fresh event per push: re-recording ONE event while its previous record is still awaited by the copy streams
+            #  cost 0.5-1.0 ms of host time per push in the step loop, profiles/r06_p2p_push_host.txt)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(eng.device))
             for s in self._pool:
                 s.wait_event(ev)
+            t_call = time.perf_counter()
+            self.host_ms['push_order'] += 1e3 * (t_call - t_host)
             field = self.base + b * self.field_bytes
             release_value = max(self.k - self.n_buf + 1, 0)
-            _lib.check(self.lib.spr_field_gather_p2p(
-                field, n_total, n_p, int(first), int(n_loc), len(self.peers),
+            tabs = self._table(('push', b), lambda: (
                 _ptr_array([self.peer_base[q] + b * self.field_bytes for q in self.peers]),
-                _ptr_array([self._flag(self.fbase, 'release', q) for q in self.peers]), release_value, self.JOIN_TIMEOUT_S,
-                _ptr_array([self._peer_flag(q, 'arrive', b) for q in self.peers]), self.k + 1,
+                _ptr_array([self._flag(self.fbase, 'release', q) for q in self.peers]),
+                _ptr_array([self._peer_flag(q, 'arrive', b) for q in self.peers]),
                 _ptr_array([self._flag(self.fbase, 'pushed', q) for q in self.peers]),
-                _ptr_array([s.cuda_stream for s in self.streams])), 'spr_field_gather_p2p')
+                _ptr_array([s.cuda_stream for s in self.streams])))
+            _lib.check(self.lib.spr_field_gather_p2p(
+                field, n_total, n_p, int(first), int(n_loc), len(self.peers), tabs[0], tabs[1], release_value,
+                self.release_timeout_s(), tabs[2], self.k + 1, tabs[3], tabs[4], self._status.data_ptr() + 16),
+                'spr_field_gather_p2p')
+            self.host_ms['push_call'] += 1e3 * (time.perf_counter() - t_call)
         joined_k = self.k
         self.k += 1
         self.host_ms['push'] += 1e3 * (time.perf_counter() - t_host)
@@ -360,8 +413,8 @@ class P2PFieldGather:
         t_host = time.perf_counter()
         b = k % self.n_buf
         if self.peers:
-            tab = _ptr_array([self._flag(self.fbase, 'arrive', q, b) for q in self.peers]
-                             + [self._flag(self.fbase, 'pushed', q) for q in self.peers])
+            tab = self._table(('join', b), lambda: _ptr_array([self._flag(self.fbase, 'arrive', q, b) for q in self.peers]
+                                                              + [self._flag(self.fbase, 'pushed', q) for q in self.peers]))
             _lib.check(self.lib.spr_field_gather_p2p_join(tab, 2 * len(self.peers), k + 1, self.JOIN_TIMEOUT_S,
                                                           self._status.data_ptr(),
                                                           torch.cuda.current_stream(eng.device).cuda_stream),
@@ -369,19 +422,46 @@ class P2PFieldGather:
         self.host_ms['join'] += 1e3 * (time.perf_counter() - t_host)
 
     def check(self):
-        """Did a join kernel give up (a peer that never pushed)?  A read of two words of page-locked host memory the kernel
-        writes on its way out: free, so begin() calls it at every gather -- a dead peer surfaces as a RuntimeError naming the
-        missing counter at the latest one gather after the join that waited for it, instead of as a stale field."""
+        """Did a wait give up?  A read of four words of page-locked host memory the kernels write on their way out: free, so
+        begin() calls it at every gather -- a dead peer surfaces as a RuntimeError naming the missing counter at the latest one
+        gather after the join that waited for it, instead of as a stale field.  Three causes, all RuntimeError:
+          * the join timed out on arrive[q] (the block of rank q never came) or pushed[q] (my own push to q never left);
+          * the join read a POISONED counter: the rank that raised it had given up waiting for a release and pushed anyway
+            (arrive[q]: rank q did, into MY copy while I had not released it -- what I was handed before may have been
+            overwritten under my readers; pushed[q]: I did, into rank q's);
+          * a push of mine gave up waiting for release[q] (words 2-3): rank q had not entered the gather within
+            RELEASE_TIMEOUT_S -- the copy went ahead (it cannot be taken back) with the poison behind it."""
         st = self._status_np
+        if not (st[0] or st[2]):
+            return
+        n = len(self.peers)
+        msgs = []
+        if st[2]:
+            q = self.peers[min(int(st[2]) - 1, n - 1)]
+            seen = int(st[3])
+            msgs.append(f'a push of rank {self.rank} gave up waiting for counter release[{q}] (rank {q} letting go of its copy '
+                        f'of the field; at {seen & ~self._poison}{", poisoned" if seen & self._poison else ""}) after '
+                        f'{self.release_timeout_s():.0f} s: the block was copied all the same (an SDMA command cannot be taken '
+                        f'back) and the arrival counters behind it were raised with the poison bit -- the join of this gather '
+                        f'fails on rank {q} and here')
         if st[0]:
             i = int(st[0]) - 1
-            n = len(self.peers)
-            who, what = (self.peers[i], 'the block of rank') if i < n else (self.peers[i - n], 'my own push to rank')
             seen = int(st[1])
-            st[:] = 0
-            raise RuntimeError(f'p2p field exchange: rank {self.rank} gave up waiting for {what} {who} after '
-                               f'{self.JOIN_TIMEOUT_S:.0f} s (counter at {seen}, gather {self.k - 1}); the field handed out by '
-                               'that join is incomplete')
+            q = self.peers[i] if i < n else self.peers[min(i - n, n - 1)]
+            name = f'arrive[{q}]' if i < n else f'pushed[{q}]'
+            if seen & self._poison:
+                what = (f'rank {q} pushed its block without my release (it had given up waiting for it): the field I was reading '
+                        'may have been overwritten' if i < n else
+                        f'my own push to rank {q} went ahead without its release')
+                msgs.append(f'the join of rank {self.rank} read a POISONED counter {name} ({what})')
+            else:
+                what = f'the block of rank {q}' if i < n else f'my own push to rank {q}'
+                msgs.append(f'rank {self.rank} gave up waiting for counter {name} ({what}) after {self.JOIN_TIMEOUT_S:.0f} s '
+                            f'(counter at {seen})')
+        k = self.k - 1
+        st[:] = 0
+        raise RuntimeError('p2p field exchange, gather ' + str(k) + ': ' + '; '.join(msgs) + '; the field handed out by that '
+                           'join is incomplete and this exchange object must not be used again')
 
     def arrived(self, k):
         """Host-side look at the arrival counters of gather k (one small D2H copy): which peers' blocks are still missing."""
@@ -390,27 +470,34 @@ class P2PFieldGather:
         return [q for q in self.peers if fl[q] < k + 1]
 
     def abandon(self):
-        """After a failed exchange: raise every counter of MY page far beyond any gather count, so that the waits my copy
-        streams and my join kernels still hold (all of them poll my page) drain instead of sitting in the queues until the
-        process ends.  The buffers stay allocated and mapped -- peers may still be writing -- and the object is not used again."""
+        """After a failed exchange: raise every counter of MY page far beyond any gather count AND poison it, so that the waits my
+        copy streams and my join kernels still hold (all of them poll my page) drain at once instead of sitting in the queues
+        until the process ends -- as FAILED waits: whatever my copy streams still push carries the poison to the peers.  The
+        buffers stay allocated and mapped -- peers may still be writing -- and the object is not used again."""
         torch = self.eng.torch
         if self._flags is not None:
             side = torch.cuda.Stream(self.eng.device)          # not behind a join kernel that is still polling
             with torch.cuda.stream(side):
-                self._flags.fill_(1 << 40)
+                self._flags.fill_((1 << 40) | self._poison)
             deadline = time.perf_counter() + 2.0               # bounded: the fill may share a hardware queue with what it is to release
             while not side.query() and time.perf_counter() < deadline:
                 time.sleep(0.001)
         self._status_np[:] = 0
 
     # ------------------------------------------------------------------ teardown
-    def close(self, collective=True):
+    def close(self, collective=True, rendezvous=None):
         """Unmap the peers' buffers and free mine.  With ``collective`` every rank first drains its streams and the ranks
-        meet (an all-gather of one number) between unmapping and freeing, so nobody frees what a peer still has mapped."""
-        if self.base is None and self.fbase is None:
+        meet (an all-gather of one number) between unmapping and freeing, so nobody frees what a peer still has mapped.
+        ``rendezvous``: whether the ranks meet -- None: when this rank holds buffers (a user's close() of a set-up exchange:
+        every rank does); True / False: decided by the caller from what ALL ranks know (ensure(): a rank whose own allocation
+        failed must still meet the others)."""
+        have = self.base is not None or self.fbase is not None
+        meet = collective and self.world > 1 and not self.loopback and (have if rendezvous is None else bool(rendezvous))
+        if not have and not meet:
             return
         torch = self.eng.torch
-        torch.cuda.synchronize(self.eng.device)
+        if have:
+            torch.cuda.synchronize(self.eng.device)
         if not self.loopback:
             for table in (self.peer_base, self.peer_fbase):
                 for q, p in list(table.items()):
@@ -419,7 +506,8 @@ class P2PFieldGather:
                     except Exception:                          # noqa: BLE001 -- teardown
                         pass
         self.peer_base, self.peer_fbase = {}, {}
-        if collective and self.world > 1 and not self.loopback:
+        self._tabs = {}
+        if meet:
             try:
                 self._all_gather(torch.zeros(1, device=self.eng.device))
             except Exception:                                  # noqa: BLE001 -- the group may be gone at interpreter exit

@@ -273,7 +273,7 @@ class OneHotRows:
 class PendingField:
     """Result of ``reconstruct(..., to_host=False, wait=False)``: the (n_p, n) field in HBM whose exchange between the
     ranks may still be in flight (RCCL's all-gather on its communication stream, or the SDMA pushes of the p2p path) -- or,
-    with ``ROM.defer_reconstruct``, whose kernel has not even been launched yet (``launch``: it runs in the host gap of the
+    with ``ROM.defer_reconstruct`` (the default), whose kernel has not even been launched yet (``launch``: it runs in the host gap of the
     object's next fit(), or here).  ``wait()`` makes the current stream wait for it and returns the tensor; nothing else may
     read the tensor before that.
     ``needs_cus``: the exchange runs a device kernel (RCCL) and competes with the caller's kernels for compute units."""
@@ -870,15 +870,18 @@ class ROM:
     #: histories queue fillers of different length in front of their projections (unmeasured on more than one GPU).
     gap_filler = False
 
-    #: Deferred reconstruct (OPT-IN).  Between the Gram pass and the projection of fit() the device idles while the host
-    #: eigen-solves (0.3 ms of a 1.5 ms step at BASELINE config 2, 1.8 ms of 22 on one rank's block of config 4 at N = 8).  With
-    #: this on, ``reconstruct(a, to_host=False, wait=False)`` -- the asynchronous form, which promises the field only behind
-    #: ``PendingField.wait()`` -- does not launch: the kernel (and, sharded, the push of the block to the peers) is enqueued
-    #: in the host gap of the object's NEXT fit(), before that fit's projection overwrites the basis (the launch works on the
-    #: basis, centre and scale of the fit it was called after), or by ``wait()`` / any other method of the object,
-    #: whichever comes first.  Same results; a loop fit -> reconstruct -> fit -> ... fills its gaps with useful work instead of
-    #: discarded work (gap_filler).  bench.py --defer-reconstruct.
-    defer_reconstruct = False
+    #: Deferred reconstruct (default since round 6; ``rom.defer_reconstruct = False`` or SPR_DEFER_RECONSTRUCT=0 switch it off).
+    #: Between the Gram pass and the projection of fit() the device idles while the host eigen-solves (0.3 ms of a 1.5 ms step at
+    #: BASELINE config 2, 1.8 ms of 22 on one rank's block of config 4 at N = 8).  ``reconstruct(a, to_host=False, wait=False)``
+    #: -- the asynchronous form, which promises the field only behind ``PendingField.wait()`` -- therefore does not launch: the
+    #: kernel (and, sharded, the push of the block to the peers) is enqueued in the host gap of the object's NEXT fit(), before
+    #: that fit's projection overwrites the basis (the launch holds the basis, centre and scale tensors of the fit it was called
+    #: after), or by ``wait()`` / any other method of the object, whichever comes first.  Same results, bit for bit
+    #: (tools/step_stress.py, tools/p2p_stress.py run with it on); a loop fit -> reconstruct -> fit -> ... fills its gaps with
+    #: useful work: config 2 1.49-1.52 -> 1.27-1.31 ms per step, one rank's block of config 4 22.3 -> 20.8-21.3 ms, config 3
+    #: 158.1 -> 155.6 (profiles/r05_defer_reconstruct_ab.txt).  Every other form of reconstruct() -- the reference's host array,
+    #: ``wait=True`` -- launches at once, as before.
+    defer_reconstruct = True
 
     def _flush_deferred(self):
         """Launch the reconstruct a previous reconstruct(wait=False) deferred (defer_reconstruct); -> True if there was one"""
@@ -1935,7 +1938,8 @@ class ROM:
         column-major) and skips the PCIe copy.  With ``wait=False`` as well, a PendingField comes back
         right after the all-gather of the field has been ENQUEUED, so the gather (720 MB per rank at config 4)
         runs on the communication stream under whatever the caller launches next -- e.g. the MFMA-bound Gram
-        pass of the next fit(); call ``.wait()`` before reading it."""
+        pass of the next fit(); call ``.wait()`` before reading it.  (With ``defer_reconstruct``, the default, that form only
+        RECORDS its launch: see the attribute.)"""
         eng = self._engine()
         self._flush_deferred()                                # an earlier deferred launch keeps its place in the order
         Ar = np.asarray(Ar, dtype=np.float64) if not hasattr(Ar, 'is_cuda') else Ar
@@ -1953,48 +1957,46 @@ class ROM:
             return out if not to_host else eng.to_host(out, result=True).T
         Ur_d = self._fitted('Ur', 'Ur')
         self._fitted('rowmean', 'X_cnt')
+        # the basis, centre and scale this object holds NOW: what the launch works on, whenever it is enqueued
+        state = (Ur_d, self._d['rowmean'], self._d['scale'])
+        if self._defers() and not to_host and not wait:
+            # defer_reconstruct: record the launch instead (the captured tensors stay alive with it)
+            n_loc, n_p = Ur_d.shape[0], A_d.shape[0]
+            total = int(self._shard_layout(n_loc)[:, 1].sum()) if self._dist() else n_loc
+            pf = self._deferred = PendingField(None, launch=lambda: self._reconstruct_now(A_d, state, False, False),
+                                               shape=(n_p, total), needs_cus=False)
+            return pf
+        return self._reconstruct_now(A_d, state, to_host, wait)
+
+    def _defers(self):
+        import os
+        env = os.environ.get('SPR_DEFER_RECONSTRUCT')
+        return (self.defer_reconstruct or env == '1') and env != '0'
+
+    def _reconstruct_now(self, A_d, state, to_host, wait, path=None):
+        """Enqueue the reconstruct kernel (and, sharded, the exchange of the field) on ``state`` = (Ur, rowmean, scale) device
+        tensors.  ``path``: 'p2p' / 'rccl' for this call only (the first-exchange trial), None: the object's choice."""
+        eng = self._engine()
+        Ur_d, rowmean_d, scale_d = state
         n_loc = Ur_d.shape[0]
         n_p = A_d.shape[0]
         world = self._world()
-        if self.defer_reconstruct and not to_host and not wait and not self.__dict__.get('_in_deferred', False):
-            # defer_reconstruct: record the launch instead -- on the basis, centre and scale this object holds NOW
-            state = {k: self._d[k] for k in ('Ur', 'rowmean', 'scale')}
-
-            def launch():
-                now = {k: dict.get(self._d, k) for k in state}       # what the object holds by then (a newer fit's, possibly)
-                self._d.update(state)
-                self._in_deferred = True
-                try:
-                    return self.reconstruct(A_d, to_host=False, wait=False)
-                finally:
-                    self._in_deferred = False
-                    for k, v in now.items():
-                        if v is None:
-                            dict.pop(self._d, k, None)
-                        else:
-                            self._d[k] = v
-            total = int(self._shard_layout(n_loc)[:, 1].sum()) if self._dist() else n_loc
-            pf = self._deferred = PendingField(None, launch=launch, shape=(n_p, total), needs_cus=False)
-            return pf
         if not self._dist():
             if to_host and hasattr(eng, 'reconstruct_to_host'):
                 # the reference's contract (:371-375): a host ndarray.  Big fields go out in row chunks whose copies run
                 # under the next chunk's kernel, into page-locked memory (engine.reconstruct_to_host)
-                host = eng.reconstruct_to_host(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
-                                               self._d['scale'], A_d)
+                host = eng.reconstruct_to_host(Ur_d, self._row0, self.n_points, self.n_features, rowmean_d, scale_d, A_d)
                 if host is not None:
                     return host.T
-            out = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
-                                  self._d['scale'], A_d)
+            out = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, rowmean_d, scale_d, A_d)
         else:
             import torch.distributed as dist
             lay = self._shard_layout(n_loc)
-            if self._gather_select(n_p, lay) == 'p2p':
-                return self._reconstruct_p2p(Ur_d, A_d, lay, to_host, wait)
+            if (path or self._gather_select(n_p, lay)) == 'p2p':
+                return self._reconstruct_p2p(A_d, state, lay, to_host, wait)
             if np.any(lay[:, 1] != n_loc):
-                return self._gather_unequal(Ur_d, A_d, lay, to_host, wait)
-            loc = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'],
-                                  self._d['scale'], A_d)
+                return self._gather_unequal(A_d, state, lay, to_host, wait)
+            loc = eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, rowmean_d, scale_d, A_d)
             # ONE all-gather for all n_p columns: rank q's (n_p, n_loc) block lands at stage[q]; for one column that is
             # the field itself, for several the columns are put side by side afterwards -- on the way to the host when
             # the caller wants a host array (block copies, no pass over the field on the device), by
@@ -2032,7 +2034,8 @@ class ROM:
     def _gather_select(self, n_p, lay):
         """'p2p' or 'rccl' for this object's field exchange (RowShard.gather / SPR_GATHER), decided at the first sharded
         reconstruct() -- by all ranks together: the p2p set-up ends with a collective self-test whose verdict every rank
-        shares, so no rank can take one path while its peers take the other.  ``gather_path_`` says what was chosen and why."""
+        shares, so no rank can take one path while its peers take the other; with 'auto' the first full-size exchange then
+        times both paths under a Gram pass and keeps the faster (_gather_trial).  ``gather_path_`` says what was chosen and why."""
         sel = self.__dict__.get('_gather_sel')
         if sel is not None:
             return sel
@@ -2093,13 +2096,14 @@ class ROM:
         self._shard.gather = path
         self.__dict__.pop('_gather_sel', None)
 
-    def _reconstruct_p2p(self, Ur_d, A_d, lay, to_host, wait):
+    def _reconstruct_p2p(self, A_d, state, lay, to_host, wait):
         """reconstruct() over the p2p exchange: the kernel writes this rank's block straight into its persistent copy of
         the (n_p, n) field, the SDMA engines push the block into every peer's copy (any block sizes, no padding, no pass
         over the field afterwards).  The tensor returned is a view of that copy: valid until the next sharded
         reconstruct() of this object."""
         eng = self._engine()
         px = self._p2p
+        Ur_d, rowmean_d, scale_d = state
         n_loc, n_p = Ur_d.shape[0], A_d.shape[0]
         first, total = int(lay[0, 0]), int(lay[:, 1].sum())
         pf = self.__dict__.get('_pending_field')
@@ -2109,10 +2113,10 @@ class ROM:
             pf.wait()
         px.ensure(n_p, total)                                 # a larger field than before: new buffers (collective)
         if px.verified is None and px.peers and not px.loopback:
-            return self._p2p_first_exchange(Ur_d, A_d, lay, to_host, wait)
+            return self._p2p_first_exchange(A_d, state, lay, to_host, wait)
         out = px.begin()
         off = self._row0 - first
-        eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'], self._d['scale'], A_d,
+        eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, rowmean_d, scale_d, A_d,
                         out=out[:, off:off + n_loc])
         close = self._comm_bracket('gather')                  # issue -> join, when the join happens inside this call
         import time
@@ -2131,19 +2135,21 @@ class ROM:
         px.check()                                            # the host has just synchronised: did the join kernel give up?
         return host
 
-    def _p2p_first_exchange(self, Ur_d, A_d, lay, to_host, wait):
+    def _p2p_first_exchange(self, A_d, state, lay, to_host, wait):
         """The FIRST exchange through freshly mapped buffers (COLLECTIVE, once per allocation): the set-up's self-test moved
         32-byte patterns; this is the first time whole blocks cross the links, so the result is checked before anybody uses it.
         Every rank sums the bit patterns of its own block (int64, wrap-around: exact), the sums are all-gathered, and every rank
         compares them with the same sums over the blocks it RECEIVED; the join waits FIRST_TIMEOUT_S at most.  All ranks share
         the verdict.  On failure -- a HIP error in a push, a block that never arrives, a block that differs -- ``gather='auto'``
         drops to the collective all-gather for the rest of this object's life (``gather_path_`` says why) and this call returns
-        that path's field; ``gather='p2p'`` raises on every rank."""
+        that path's field; ``gather='p2p'`` raises on every rank.  On success ``gather='auto'`` goes on to time both exchanges
+        (_gather_trial) and keeps the faster."""
         import os
         import sys
         eng = self._engine()
         t = eng.torch
         px = self._p2p
+        Ur_d, rowmean_d, scale_d = state
         n_loc, n_p = Ur_d.shape[0], A_d.shape[0]
         first = int(lay[0, 0])
         off = self._row0 - first
@@ -2158,7 +2164,7 @@ class ROM:
         px.JOIN_TIMEOUT_S = min(keep, px.FIRST_TIMEOUT_S)
         try:
             out = px.begin()
-            eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'], self._d['scale'], A_d,
+            eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, rowmean_d, scale_d, A_d,
                             out=out[:, off:off + n_loc])
             import time
             self.last_comm_ = ('field exchange (p2p, first: verified)', (n_p, int(lay[:, 1].sum())), time.time())
@@ -2180,34 +2186,117 @@ class ROM:
             except RuntimeError as exc:
                 ok, why = False, str(exc)
         all_ok, why = px._agree(ok, why, 'the exchange failed')      # every rank's verdict and the first failing rank's reason
+        want = os.environ.get('SPR_GATHER') or self._shard.gather
         if all_ok:
             px.verified = dict(blocks=int(lay.shape[0]), bytes_per_block=int(n_p * n_loc * 8), check='per-block int64 sums')
+            if want == 'auto' and os.environ.get('SPR_GATHER_TRIAL', '1') != '0' and 'gather_trial_' not in self.__dict__:
+                if self._gather_trial(A_d, state) == 'rccl':
+                    return self._reconstruct_now(A_d, state, to_host, wait)
+                return self._reconstruct_p2p(A_d, state, lay, to_host, wait)        # (the trial's gathers reused the buffer)
             if to_host:
                 return eng.to_host(out, result=True).T
             return out if wait else PendingField(out)
         px.abandon()
         self._p2p_dropped = self.__dict__.pop('_p2p')          # stays allocated: peers have it mapped; never used again
-        if (os.environ.get('SPR_GATHER') or self._shard.gather) == 'p2p':
+        if want == 'p2p':
             self.__dict__.pop('_gather_sel', None)
             raise RuntimeError(f"RowShard(gather='p2p'): the first full-size exchange failed -- {why}")
         self._gather_sel = 'rccl'
         self.gather_path_ = f'rccl (p2p failed its first full-size exchange: {why})'
         if rank == 0:
             print(f'[openmeasure_amd] field exchange falls back to the RCCL all-gather: {why}', file=sys.stderr)
-        return self.reconstruct(A_d, to_host=to_host, wait=wait)
+        return self._reconstruct_now(A_d, state, to_host, wait)
 
-    def _gather_unequal(self, Ur_d, A_d, lay, to_host, wait):
+    _GATHER_TRIAL_REPS = 2
+    _GATHER_TRIAL_MARGIN = 0.97     # the all-gather takes over only when it is at least 3 % faster (p2p leaves the CUs alone)
+
+    def _gather_trial(self, A_d, state):
+        """``gather='auto'``, once per object, behind the verified first exchange (COLLECTIVE): WHICH exchange is faster HERE is
+        a property of the node (links, SDMA engines, RCCL's protocol for this size) that nothing but a measurement can tell -- so
+        the library measures what its callers do with a field exchange: leave it in flight under the next pass over X.  Per path,
+        _GATHER_TRIAL_REPS times: reconstruct kernel + exchange enqueued unjoined, one Gram pass over the local rows queued behind
+        it on the compute stream (the real kernel on the real shard, results discarded -- the stand-in for the next fit()), join,
+        device sync; wall time.  A joined exchange alone would favour whichever path has the higher raw rate and miss that RCCL's
+        kernel cannot share a compute unit with the Gram workgroups while the SDMA pushes do not need one.  Every rank takes the
+        best of its repetitions, the maxima over the ranks decide (one all-gather: every rank sees the same two numbers), p2p
+        keeps the exchange unless the all-gather is _GATHER_TRIAL_MARGIN faster.  ``gather_trial_`` / ``gather_path_`` carry both
+        times.  SPR_GATHER_TRIAL=0 skips it (p2p whenever it is available, as before round 6).  -> 'p2p' | 'rccl'."""
+        import sys
+        import time
+        eng = self._engine()
+        torch = eng.torch
+        Xd = self._Xd()
+        can_fill = hasattr(eng, 'gram_filler')
+
+        def sync_all():
+            self._all_gather(eng.zeros((1,)))                 # the ranks meet: every repetition starts together
+            torch.cuda.synchronize(eng.device)
+
+        def once(path):
+            sync_all()
+            t0 = time.perf_counter()
+            pf = self._reconstruct_now(A_d, state, False, False, path=path)
+            if can_fill:
+                eng.gram_filler(Xd, Xd.shape[0], self._row0, self.n_points, self.n_features)
+            if isinstance(pf, PendingField):
+                pf.wait()
+            torch.cuda.synchronize(eng.device)
+            return time.perf_counter() - t0
+
+        # HBM first: the all-gather leg stages the gathered field (world blocks) next to the block itself and RCCL allocates
+        # buffers of its own at its first call of this size; a shard that fills the GPU (config 5 at N = 8: 9 GB left) must not
+        # find out by running out of memory in one rank.  Decided together from the tightest rank.
+        if hasattr(eng, 'device') and eng.device.type == 'cuda':
+            lay = self._shard_layout(state[0].shape[0])
+            need = (lay.shape[0] + 1) * int(lay[:, 1].max()) * A_d.shape[0] * 8 + (2 << 30)
+            free = (torch.cuda.mem_get_info(eng.device)[0] + torch.cuda.memory_reserved(eng.device)
+                    - torch.cuda.memory_allocated(eng.device))
+            free = float(eng.to_host(self._all_gather(eng.to_device(np.array([float(free)])))).min())
+            if free < need:
+                self.gather_trial_ = dict(chosen='p2p', skipped=f'the all-gather leg needs about {need / 1e9:.1f} GB per rank, '
+                                                                f'{free / 1e9:.1f} GB are left on the tightest rank')
+                self.gather_path_ = ('p2p (SDMA pushes into peer-mapped buffers, no compute units; first-exchange trial skipped: '
+                                     + self.gather_trial_['skipped'] + ')')
+                return 'p2p'
+        saved = self.comm_timing
+        self.comm_timing = None                               # the trial's brackets are not the caller's
+        try:
+            once('rccl')                                      # the communicator's first all-gather of this size: not timed
+            best = {'p2p': np.inf, 'rccl': np.inf}
+            for _ in range(self._GATHER_TRIAL_REPS):
+                for path in ('p2p', 'rccl'):
+                    best[path] = min(best[path], once(path))
+        finally:
+            self.comm_timing = saved
+        mine = eng.to_device(np.array([best['p2p'], best['rccl']]))
+        worst = eng.to_host(self._all_gather(mine)).max(axis=0)
+        t_p2p, t_rccl = float(worst[0]), float(worst[1])
+        sel = 'rccl' if t_rccl < self._GATHER_TRIAL_MARGIN * t_p2p else 'p2p'
+        self.gather_trial_ = dict(p2p_ms=round(1e3 * t_p2p, 4), rccl_ms=round(1e3 * t_rccl, 4), chosen=sel,
+                                  what='reconstruct + exchange left in flight under one Gram pass over the local rows, joined '
+                                       'behind it; best of %d per rank, maximum over the ranks' % self._GATHER_TRIAL_REPS)
+        said = f'exchange under a Gram pass {1e3 * t_p2p:.3f} ms over p2p, {1e3 * t_rccl:.3f} ms over the all-gather'
+        if sel == 'p2p':
+            self.gather_path_ = f'p2p (SDMA pushes into peer-mapped buffers, no compute units; first-exchange trial: {said})'
+        else:
+            self.gather_path_ = f'rccl (first-exchange trial: {said}; the p2p buffers stay mapped, use_gather("p2p") switches back)'
+            if self._shard.rank == 0:
+                print(f'[openmeasure_amd] field exchange: the RCCL all-gather is faster on this node ({said})', file=sys.stderr)
+        self._gather_sel = sel
+        return sel
+
+    def _gather_unequal(self, A_d, state, lay, to_host, wait):
         """RCCL field all-gather for row blocks of different sizes: every rank contributes its (n_p, n_loc) block padded to
         the largest block (the all-gather wants equal counts; the reconstruct kernel writes into the padded block directly),
         and spr_field_unstage_blocks_f64 packs the blocks side by side afterwards -- one pass over the field, which the
         equal-shard path and the p2p exchange do not need."""
         import torch.distributed as dist
         eng = self._engine()
+        Ur_d, rowmean_d, scale_d = state
         n_p, n_loc = A_d.shape[0], Ur_d.shape[0]
         world, n_max = lay.shape[0], int(lay[:, 1].max())
         mine = eng.zeros((n_p, n_max))
-        eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, self._d['rowmean'], self._d['scale'], A_d,
-                        out=mine[:, :n_loc])
+        eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, rowmean_d, scale_d, A_d, out=mine[:, :n_loc])
         stage = eng.empty((world, n_p, n_max))
         close = self._comm_bracket('gather')
         dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self._shard.group)

@@ -296,6 +296,10 @@ def main():
     X = synth(2000, 4, 24, 24, 10 ** (-3 / 15), 1e-4, 303)
     run_case(sps, 'g3_num8', X, 4, 'number', 8, 304)
     run_case(sps, 'g3_num16', X, 4, 'number', 16, 305)
+    # G7 (round 6): 9 features like BASELINE configs 3 / 4 -- 1000 cells x 9 x 16 snapshots, r = 6.  Eight equal row blocks
+    # are 1125 rows each: every interior block boundary falls INSIDE a feature (multiples of 1125 against multiples of 1000)
+    X = synth(1000, 9, 16, 16, 0.75, 1e-3, 1707)
+    run_case(sps, 'g7_f9_num6', X, 9, 'number', 6, 1708)
     # odd m / odd r / ragged: 333 cells x 3 x 7 snapshots, r = 5
     X = synth(333, 3, 7, 7, 0.6, 1e-3, 404)
     run_case(sps, 'g4_num5', X, 3, 'number', 5, 405)

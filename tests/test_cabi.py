@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_loader_and_error_text():
     lib = _lib.load()
-    assert lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 4
+    assert lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 5
     # argument validation happens before any device work: a NULL matrix is rejected on a CPU-only box
     rc = lib.spr_reconstruct_f64(None, 10, 4, 4, 0, 10, 1, None, None, None, None, 1, None, 10, None)
     assert rc == -1

@@ -41,6 +41,8 @@ def _worker(rank, world, port, fixture, out_dir, uneven=False):
         row0, n_loc = cuts[rank], cuts[rank + 1] - cuts[rank]
         spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n),
                   engine=HipEngine('cuda:0'))
+        assert spr.defer_reconstruct                                         # the default since round 6 ...
+        spr.defer_reconstruct = False                                        # ... off for the first part: launches behind their own fit
         spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'], n_modes=g['n_modes'])
         C = spr.optimal_placement()
         spr.train(C)
@@ -50,6 +52,10 @@ def _worker(rank, world, port, fixture, out_dir, uneven=False):
         np.testing.assert_array_equal(x1.cpu().numpy()[0], X3[:, 0])
         # round 5: the CU-free exchange (IPC peer-mapped copies of the field, SDMA pushes) against the collective one, bit for bit
         assert spr.gather_path_.startswith('p2p'), spr.gather_path_            # 'auto' took it: the self-test passed on all ranks
+        # ... and the library's first-exchange trial timed both paths under a Gram pass (over gloo the all-gather is staged
+        # through the host: p2p wins); every rank holds the same two numbers
+        tr = spr.gather_trial_
+        assert tr['chosen'] == 'p2p' and tr['p2p_ms'] > 0 and tr['rccl_ms'] > 0 and 'first-exchange trial' in spr.gather_path_, tr
         spr.use_gather('rccl')
         X3_c = spr.reconstruct(A3)
         assert spr.gather_path_.startswith('rccl')
@@ -86,13 +92,12 @@ def _worker(rank, world, port, fixture, out_dir, uneven=False):
             prev = spr.reconstruct(A, to_host=False, wait=False)
             assert not prev.launched
         np.testing.assert_array_equal(prev.wait().cpu().numpy(), wants[3])
-        spr.defer_reconstruct = False
         spr.close()                                                        # collective: unmap, meet, free
         assert '_p2p' not in spr.__dict__
         np.testing.assert_array_equal(spr.reconstruct(A3), X3)             # ... and the exchange is set up anew on demand
         assert spr.gather_path_.startswith('p2p')
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), piv=spr.sensors_, Sigma=spr.Sigma_r, X3=X3, A3=A3, Ar=spr.Ar,
-                 passes=spr.gram_refine_passes_)
+                 passes=spr.gram_refine_passes_, trial=np.array([tr['p2p_ms'], tr['rccl_ms']]))
     finally:
         dist.destroy_process_group()
 
@@ -467,6 +472,77 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
                 spr3.close()
             finally:
                 P2PFieldGather.push = real_push
+        elif case == 'first_deferred':
+            # the object's FIRST sharded reconstruct is a deferred one -- its launch, inside the host gap of the
+            # next fit() (the `then` hook of the Gram download), runs the whole collective set-up of the exchange: handle
+            # all-gathers, self-test, the verified first exchange, the trial of both paths, each with downloads of its own.  The
+            # download the hook belongs to must still hand fit() ITS payload: same spectrum, basis and field as an object that
+            # set its exchange up outside any fit().
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            n_loc = n // world
+            row0 = rank * n_loc
+            Xl = np.ascontiguousarray(X[row0:row0 + n_loc])
+            ref = SPR(Xl, g['n_features'], None, shard=RowShard(row0, n, gather='rccl'), engine=eng)
+            ref.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+            A3 = g['Ar_pred3'] * np.sign(np.sum(ref.Ar * g['Ar'], axis=0))
+            want = ref.reconstruct(A3)
+            spr = SPR(Xl, g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+            assert spr.defer_reconstruct
+            spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+            pf = spr.reconstruct(A3, to_host=False, wait=False)
+            assert not pf.launched and '_p2p' not in spr.__dict__             # nothing set up yet
+            depth_seen = []
+            real_th = eng._to_host_small
+
+            def spy(t, nbytes, then):
+                depth_seen.append(eng._dl_depth)
+                return real_th(t, nbytes, then)
+            eng._to_host_small = spy
+            try:
+                spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])      # the launch + the whole set-up run in this fit's gap
+            finally:
+                eng._to_host_small = real_th
+            assert pf.launched and '_p2p' in spr.__dict__
+            got = pf.wait().cpu().numpy().T
+            res = dict(path=str(spr.gather_path_), nested=int(max(depth_seen)), field_same=bool(np.array_equal(got, want)),
+                       sigma_same=bool(np.array_equal(spr.Sigma_r, ref.Sigma_r)), Ur_same=bool(np.array_equal(spr.Ur, ref.Ur)),
+                       X3=got, again=bool(np.array_equal(spr.reconstruct(A3), want)))
+            spr.close()
+        elif case == 'stalled_release':
+            # round 6: a rank that is SLOW, not dead -- it sits between two gathers (still reading the field
+            # it was handed) for longer than the pusher's release timeout.  The pusher's copy cannot be taken back, so the arrival
+            # counters behind it carry the poison bit: the pusher's own join AND the late rank's join of that gather both fail,
+            # both ranks raise a RuntimeError that names the counter, nobody is handed the field.
+            import time
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            n_loc = n // world
+            row0 = rank * n_loc
+            spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n, gather='p2p'),
+                      engine=eng)
+            spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+            A3 = g['Ar_pred3'] * np.sign(np.sum(spr.Ar * g['Ar'], axis=0))
+            X3 = spr.reconstruct(A3)                            # gather 0: the verified first exchange
+            px = spr._p2p
+            assert px.release_timeout_s() == 3.0 * px.JOIN_TIMEOUT_S       # the default order: the join gives up first
+            px.JOIN_TIMEOUT_S, px.RELEASE_TIMEOUT_S = 3.0, 1.0              # ... here the release wait is the one to expire
+            dist.barrier()
+            t0 = time.perf_counter()
+            if rank == 1:
+                time.sleep(6.0)                                 # still "reading" field 0: has not entered gather 1
+            try:
+                got = spr.reconstruct(A3)
+                res['raised'] = 'no error'
+                res['field_ok'] = bool(np.array_equal(got, X3))
+            except RuntimeError as exc:
+                res['raised'] = str(exc)
+            res['seconds'] = time.perf_counter() - t0
+            res['X3'] = X3
+            dist.barrier()
+            spr.close()
         else:
             # the join kernel's exit: a peer that never pushes.  Rank 0 pushes and joins with a short timeout; the kernel gives
             # up, leaves the missing counter in the status words, check() names the peer.  Nothing hangs.
@@ -512,7 +588,7 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
 
 
 @pytest.mark.parametrize('case', ['fallback', 'no_peer_access', 'uncached', 'knob:SPR_P2P_BUFFERS=2', 'knob:SPR_P2P_STREAMS=1',
-                                  'knob:SPR_P2P_BLIT=1', 'timeout', 'first_mismatch', 'first_timeout'])
+                                  'knob:SPR_P2P_BLIT=1', 'timeout', 'first_mismatch', 'first_timeout', 'stalled_release', 'first_deferred'])
 def test_p2p_exchange_edges(tmp_path, case):
     """round 5: the p2p field exchange when it cannot be had (one rank cannot map its peers -> every rank on the collective path,
     or every rank raising when p2p was demanded), when a peer never pushes (the join kernel's wall-clock exit + check()), and
@@ -559,8 +635,29 @@ def test_p2p_exchange_edges(tmp_path, case):
             assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO and bool(o['same']) and bool(o['dropped'])
             assert str(o['forced']).startswith("RuntimeError: RowShard(gather='p2p'): the first full-size exchange failed"), o['forced']
             assert str(o['path3']).startswith('p2p') and 'per-block int64 sums' in str(o['verified']) and bool(o['same3'])
+    elif case == 'first_deferred':
+        from tests.conftest import load_golden
+        from tests.parity import REL_FRO, rel_fro
+        g = load_golden('g3_num8')
+        for o in outs:
+            assert str(o['path']).startswith('p2p') and int(o['nested']) >= 1, (o['path'], o['nested'])   # downloads DID nest
+            assert bool(o['sigma_same']) and bool(o['Ur_same']) and bool(o['field_same']) and bool(o['again'])
+            assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO
+    elif case == 'stalled_release':
+        from tests.conftest import load_golden
+        from tests.parity import REL_FRO, rel_fro
+        g = load_golden('g3_num8')
+        a, b = (str(o['raised']) for o in outs)
+        for o in outs:
+            assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO    # the gather before the stall was fine on both
+            assert str(o['raised']) != 'no error', 'a field was handed out'
+        # the pusher: its release wait named, its own join poisoned (pushed[1]) or timed out on the late rank's block (arrive[1])
+        assert 'release[1]' in a and 'gave up waiting' in a and ('pushed[1]' in a or 'arrive[1]' in a), a
+        # the late rank: the poison the pusher left in ITS page
+        assert 'POISONED counter arrive[0]' in b and 'without my release' in b, b
+        assert float(outs[0]['seconds']) < 10.0 and float(outs[1]['seconds']) < 12.0      # bounded: nothing waited for ever
     else:
         assert 400.0 <= float(outs[0]['join_ms']) <= 5000.0, outs[0]['join_ms']       # gave up after ~0.5 s, did not hang
-        assert 'gave up waiting for the block of rank 1' in str(outs[0]['check']), outs[0]['check']
+        assert 'arrive[1]' in str(outs[0]['check']) and 'the block of rank 1' in str(outs[0]['check']), outs[0]['check']
         for o in outs:
             assert o['late'].tolist() == [1.0, 1.0, 2.0], o['late']                   # both blocks in both copies in the end

@@ -38,7 +38,7 @@ def test_native_library_is_loaded(eng):
     maps = open(f'/proc/{os.getpid()}/maps').read()
     assert 'libspr_hip.so' in maps
     from openmeasure_amd import _lib
-    assert eng.lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 4
+    assert eng.lib.spr_abi_version() == _lib.SPR_ABI_VERSION == 5
 
 
 def test_golden_fixture(golden, eng):
@@ -1153,6 +1153,58 @@ def test_properties_at_scale(eng):
     assert len(set(p1.tolist())) == r and spr.pivot_gap_.min() > 1e-9
 
 
+def _full_vs_oracle(eng, Xd, F, s):
+    """The HIP path on the device matrix Xd against the oracle on the same values downloaded: ordered sensors equal to dgeqp3's
+    pivots of the oracle's basis, retained singular values to 1e-8, the reconstructed field within the north_star's 1e-6
+    relative Frobenius (same coefficient vector, signs aligned)."""
+    from openmeasure_amd.sparse_sensing import SPR, DeviceMatrix
+    X = eng.to_host(Xd)
+    xr_cpu, st = orc.fit_reconstruct_timed(X, F, s)
+    piv_cpu, _ = orc.qr_pivots(st['Ur'])
+    spr = SPR(DeviceMatrix(Xd), F, None, engine=eng)
+    spr.fit(select_modes='number', n_modes=s)
+    assert spr.r == s == st['r']
+    np.testing.assert_allclose(spr.Sigma_r, st['Sigma_r'], rtol=1e-8)
+    spr.optimal_placement()
+    np.testing.assert_array_equal(spr.sensors_, piv_cpu)                       # exact and ordered
+    sg = np.sign(np.sum(spr.Ur * st['Ur'], axis=0))                             # same coefficients need the same column signs
+    xr = spr.reconstruct(st['Ar'][0] * sg)
+    err = rel_fro(xr[:, 0], xr_cpu.reshape(-1))
+    assert err <= REL_FRO, err
+    return dict(field_rel_fro=err, sigma_rel=float(np.max(np.abs(spr.Sigma_r - st['Sigma_r']) / st['Sigma_r'])),
+                min_pivot_gap=float(spr.pivot_gap_.min()))
+
+
+def test_config2_full_size_vs_oracle(eng):
+    """BASELINE config 2 at FULL size against the oracle (until round 6 this comparison only existed in
+    builder-run bench lines): 1M cells x 4 features x 64 snapshots generated on the device by the bench's generator and seed,
+    32 modes / sensors; the oracle's SVD of the 4M x 64 matrix takes some 15 s of host LAPACK."""
+    from openmeasure_amd.synth import make_R
+    n_points, F, m, s = 1_000_000, 4, 64, 32
+    R = eng.to_device(make_R(m, s, seed=1234))
+    Xd = eng.synth(n_points * F, m, 0, n_points, R, 1e-3, 1234)
+    got = _full_vs_oracle(eng, Xd, F, s)
+    assert got['min_pivot_gap'] > 1e-9
+    print('config 2, full size, HIP vs oracle:', got)
+
+
+def test_config3_sample_vs_oracle(eng):
+    """BASELINE config 3's oracle sample -- the first 100 000 cells of each of the 9 features of the 10M-cell matrix, the very
+    rows bench.py's cpu_baseline / parity leg cuts out of the resident shard -- generated here row block by row block with the
+    same counter-based generator (its values depend on the GLOBAL row only), 256 snapshots, 64 modes / sensors."""
+    import torch
+    from openmeasure_amd.synth import make_R
+    n_points, cc, F, m, s = 10_000_000, 100_000, 9, 256, 64
+    R = eng.to_device(make_R(m, s, seed=1234))
+    Xd = torch.cat([eng.synth(cc, m, f * n_points, n_points, R, 1e-3, 1234) for f in range(F)])
+    # the generator is what bench.py holds: a block generated on its own equals the same rows cut out of a larger one
+    whole = eng.synth(3 * cc, m, 2 * n_points - cc, n_points, R, 1e-3, 1234)      # rows straddling the boundary of features 1 | 2
+    assert torch.equal(whole[cc:2 * cc], Xd[2 * cc:3 * cc])
+    del whole
+    got = _full_vs_oracle(eng, Xd, F, s)
+    print('config 3, 100 000-cell sample, HIP vs oracle:', got)
+
+
 def test_properties_at_config3_scale(eng):
     """BASELINE config 3 at FULL size (10M cells x 9 features x 256 snapshots = 184 GB, 64 modes), generated on the
     device: orthonormal basis, energy identity, best-rank-r residual of a reconstructed training column, sensors
@@ -1764,7 +1816,7 @@ def test_engine_close_and_reuse(eng):
     ref = big.cpu().numpy()
     np.testing.assert_array_equal(eng._to_host_staged(big), ref)               # starts the copy threads
     eng.close()
-    assert eng.__dict__.get('_copy_pool') is None and eng._dstage is None and eng._stage is None
+    assert eng.__dict__.get('_copy_pool') is None and '_dstage_slots' not in eng.__dict__ and eng._stage is None
     np.testing.assert_array_equal(a, np.arange(2_000_000, dtype=np.float64))   # still readable after the engine let go
     eng.close()                                                                # idempotent
     np.testing.assert_array_equal(eng.to_host(t, result=True), a)
@@ -1863,7 +1915,7 @@ def test_small_downloads_by_kernel_and_ticket(eng, monkeypatch):
         np.testing.assert_array_equal(got, a)
         got[...] = 0                                                           # a fresh array every time, not the staging buffer
         np.testing.assert_array_equal(eng.to_host(t), a)
-    assert len(called) == len(cases) and eng._dl['seq'] >= 2 * len(cases)
+    assert len(called) == len(cases) and eng._dl[0]['seq'] >= 2 * len(cases)
     # a strided view and an odd byte count take the other path and still come back right
     t = torch.as_tensor(cases[0]).to(eng.device)
     np.testing.assert_array_equal(eng.to_host(t[:, ::2]), cases[0][:, ::2])
@@ -1879,6 +1931,52 @@ def test_small_downloads_by_kernel_and_ticket(eng, monkeypatch):
     assert d2.data_ptr() == d1.data_ptr()                                      # the same device buffer, new contents
     np.testing.assert_array_equal(eng.to_host(d2), W2)
     np.testing.assert_array_equal(eng.to_host(eng.upload_reuse(('W', 1), W1[:10])), W1[:10])   # another shape: a new buffer
+
+
+def test_downloads_nest(eng):
+    """A download issued from inside another download's `then` hook (fit()'s host gap launching a deferred reconstruct whose
+    collective set-up downloads handles and verdicts -- ADVICE r05) gets a buffer, ticket and event of its own: both calls return
+    their own payload, on the kernel + ticket path and on the copy + event path, two levels deep, sizes that differ."""
+    import torch
+    from openmeasure_amd.engine import HipEngine
+    rng = np.random.default_rng(11)
+    for e in (eng, HipEngine('cuda:0')):
+        if e is not eng:
+            e._dl_kernel = False                                               # the copy + event path (shared pinned stage)
+        A, B, Cc = rng.standard_normal((256, 256)), rng.standard_normal((40,)), rng.standard_normal((3, 7, 8))
+        big = rng.standard_normal((600_000,))                                  # 4.8 MB: the staged path on both engines
+        tA, tB, tC, tbig = (torch.as_tensor(x).to(e.device) for x in (A, B, Cc, big))
+        inner = {}
+
+        def level2():
+            inner['C'] = e.to_host(tC)
+            inner['big2'] = e.to_host(tbig[:300_001])
+
+        def level1():
+            inner['B'] = e.to_host(tB, then=level2)
+            inner['B2'] = e.to_host(tB * 2)                                    # the same depth used twice in one hook
+
+        for _ in range(3):
+            inner.clear()
+            gotA = e.to_host(tA, then=level1)
+            np.testing.assert_array_equal(gotA, A)
+            np.testing.assert_array_equal(inner['B'], B)
+            np.testing.assert_array_equal(inner['B2'], 2 * B)
+            np.testing.assert_array_equal(inner['C'], Cc)
+            np.testing.assert_array_equal(inner['big2'], big[:300_001])
+            inner.clear()
+            gotbig = e.to_host(tbig, then=level1)
+            np.testing.assert_array_equal(gotbig, big)
+            np.testing.assert_array_equal(inner['B'], B)
+            np.testing.assert_array_equal(inner['C'], Cc)
+        assert e._dl_depth == 0
+
+        def boom():
+            raise KeyError('hook')
+        with pytest.raises(KeyError):
+            e.to_host(tA, then=boom)
+        assert e._dl_depth == 0                                                # the depth unwinds when a hook raises
+        np.testing.assert_array_equal(e.to_host(tA), A)
 
 
 def test_deferred_reconstruct_on_the_device(eng):

@@ -39,9 +39,14 @@
  *   SPR_QR_ORTH_TILE=0        spr_qr_step_f64 / spr_qr_steps_f64: the Gram-Schmidt passes of a step as chains of loads instead of
  *                             the register-tiled form (A/B only)
  *   SPR_P2P_BLIT=1            spr_p2p_copy / spr_field_gather_p2p: blit kernels instead of the SDMA engines
+ *   SPR_P2P_PROBE=1           spr_field_gather_p2p prints the host time of each of its runtime calls (tools/p2p_push_probe.py)
+ *   SPR_RCCL_LIBRARY=<path>   spr_comm_*: the RCCL library to load (default: the one already in the process, else librccl.so.1)
  * and by the Python layer (openmeasure_amd/): SPR_PROJECT_STREAM=1 (streamed-W projection for every shape),
  * SPR_GAP_FILLER=1|0 (ROM.gap_filler, opt-in: a filler launch in fit()'s host gap), SPR_GATHER=auto|p2p|rccl (field exchange of
- * sharded objects), SPR_P2P_STREAMS / SPR_P2P_BUFFERS / SPR_P2P_MEMORY (openmeasure_amd/p2p.py), SPR_DL_KERNEL=0 (small downloads
+ * sharded objects), SPR_GATHER_TRIAL=0 (no first-exchange trial of the two exchanges: 'auto' = p2p whenever available),
+ * SPR_DEFER_RECONSTRUCT=0|1 (ROM.defer_reconstruct), SPR_NATIVE_COMM=1 (fit()'s all-reduce through spr_fit_gram_pass / this library's
+ * own communicator), SPR_P2P_STREAMS / SPR_P2P_BUFFERS / SPR_P2P_MEMORY / SPR_P2P_JOIN_TIMEOUT_S / SPR_P2P_RELEASE_TIMEOUT_S
+ * (openmeasure_amd/p2p.py), SPR_DL_KERNEL=0 (small downloads
  * by copy + event), SPR_PINNED_RESULT_GB=<g> (budget of page-locked
  * memory for host results still alive, default 8; 0 = pageable copies only), SPR_TRACE=1 (per-phase wall clock of fit(),
  * synchronising), SPR_HIP_LIBRARY=<path> (another build of this library).  None of them is needed in production.
@@ -397,6 +402,41 @@ int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_
 int spr_field_gather_p2p_join(void *const *d_flags, int32_t n_flags, uint64_t arrive_value, double timeout_s, void *d_status,
                               void *stream);
 int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream);
+
+/* ---- the collectives of the sharded path behind this ABI (csrc/comm.hip, round 6) -------------------------------------------
+ * north_star: "a single RCCL all-reduce over xGMI for the Gram matrix and a final all-gather for the reconstructed field"; the
+ * reference has neither (one process, NumPy).  RCCL is reached through dlopen -- the copy that is already in the process
+ * (PyTorch's), else librccl.so.1 of the ROCm installation, else SPR_RCCL_LIBRARY=<path> -- so this library links nothing but the
+ * HIP runtime; where no RCCL can be loaded these calls return SPR_E_UNSUPPORTED with the loader's text.
+ *   spr_comm_unique_id   (one rank) fills spr_comm_unique_id_bytes() bytes; the caller carries them to the other ranks through
+ *                        any channel it has (a file, MPI, torch.distributed);
+ *   spr_comm_init        COLLECTIVE over the `world` callers: a communicator on the CURRENT device; spr_comm_destroy frees it;
+ *   spr_allreduce_f64    in-place sum of `count` doubles over the ranks, enqueued on `stream` (_i64: 64-bit integers -- the
+ *                        digit histograms of the median scaling, :140-141);
+ *   spr_allgather        rank q's bytes_per_rank bytes land at d_recv + q * bytes_per_rank on every rank (the field of
+ *                        reconstruct(), sparse_sensing.py:371-375: whole on every caller);
+ *   spr_fit_gram_pass    the first pass of fit() WITH its collective as one enqueue (SURVEY 8(b) "spr_fit_stats_gram (includes
+ *                        collectives)"): spr_stats_gram + finalize into the rank's slots of d_buf = [F m m Gram | world x F x 3
+ *                        statistics | world first rows] (spr_fit_gram_pass_buffer() bytes; zeroed here), the all-reduce of d_buf
+ *                        over `comm` (NULL: one rank, no collective), spr_gram_combine_f64 -> d_G [m][m], d_feat [F][5],
+ *                        d_scale / d_inv_scale [F].  Replaces np.average / np.std / X0 = (X - cnt)/scl / the X0^T X0 half of
+ *                        np.linalg.svd (:112, :115, :169, :272) for a row block of a sharded X.  m <= SPR_MAX_M; scale_code as
+ *                        for spr_gram_combine_f64; x_is_f32: d_X is float (storage only).  Afterwards d_buf still holds what
+ *                        every rank contributed: rows per (rank, feature) = d_buf[F m m + (q F + f) 3], first rows at the end. */
+size_t spr_comm_unique_id_bytes(void);
+int spr_comm_unique_id(void *h_id);
+int spr_comm_init(const void *h_id, int32_t rank, int32_t world, void **comm);
+int spr_comm_destroy(void *comm);
+int spr_comm_info(void *comm, int32_t *rank, int32_t *world);
+const char *spr_comm_library(void);
+int spr_allreduce_f64(void *comm, double *d_buf, int64_t count, void *stream);
+int spr_allreduce_i64(void *comm, int64_t *d_buf, int64_t count, void *stream);
+int spr_allgather(void *comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream);
+size_t spr_fit_gram_pass_buffer(int32_t m, int32_t n_features, int32_t world);
+int spr_fit_gram_pass(void *comm, const void *d_X, int32_t x_is_f32, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
+                      int64_t n_points, int32_t n_features, int32_t scale_code, double *d_rowmean, double *d_buf,
+                      size_t buf_bytes, double *d_G, double *d_feat, double *d_scale, double *d_inv_scale, void *d_workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* ---- K6 : QR column pivoting of Ur^T (sensor selection) -----------------------------
  * Replaces scipy.linalg.qr(Ur.T, pivoting=True) (:739) -- only the first s pivots are

@@ -109,6 +109,17 @@ PROTOTYPES = {
     'spr_solve_pinv_f64': (C.c_int, [_p, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _dbl, _p, _p, _p, _p, _p]),
     'spr_solve_pinv_workspace': (_sz, [_i32, _i32]),
     'spr_solve_pinv_wide_f64': (C.c_int, [_p, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _dbl, _p, _p, _p, _p, _p, _sz, _p]),
+    'spr_comm_unique_id_bytes': (_sz, []),
+    'spr_comm_unique_id': (C.c_int, [_p]),
+    'spr_comm_init': (C.c_int, [_p, _i32, _i32, _p]),
+    'spr_comm_destroy': (C.c_int, [_p]),
+    'spr_comm_info': (C.c_int, [_p, _p, _p]),
+    'spr_comm_library': (C.c_char_p, []),
+    'spr_allreduce_f64': (C.c_int, [_p, _p, _i64, _p]),
+    'spr_allreduce_i64': (C.c_int, [_p, _p, _i64, _p]),
+    'spr_allgather': (C.c_int, [_p, _p, _p, _i64, _p]),
+    'spr_fit_gram_pass_buffer': (_sz, [_i32, _i32, _i32]),
+    'spr_fit_gram_pass': (C.c_int, [_p, _p, _i32, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p, _p, _p, _p, _p, _sz, _p]),
     'spr_synth_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p]),
     'spr_synth_gather_f64': (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p, _p]),
 }

@@ -408,6 +408,69 @@ class HipEngine:
         return P2PFieldGather(self, world, rank, all_gather, double_buffer=os.environ.get('SPR_P2P_BUFFERS') == '2',
                               loopback=int(os.environ.get('SPR_P2P_LOOPBACK', '0') or 0))
 
+    # ---- collectives behind the C ABI (csrc/comm.hip): the library's own communicator over the RCCL already in the process ----
+    def comm_create(self, world, rank, carry):
+        """A communicator of libspr_hip.so for this rank on the current device (COLLECTIVE).  ``carry(bytes or None) -> bytes``:
+        the caller's channel for rank 0's unique id (torch.distributed, MPI, a file) -- called with the id on rank 0, with
+        None on the others; returns the id everywhere.  -> opaque handle for comm_allreduce / comm_allgather / fit_gram_pass."""
+        import ctypes as C
+        nb = int(self.lib.spr_comm_unique_id_bytes())
+        buf = (C.c_ubyte * nb)()
+        mine = None
+        if rank == 0:
+            _lib.check(self.lib.spr_comm_unique_id(buf), 'spr_comm_unique_id')
+            mine = bytes(buf)
+        got = carry(mine)
+        if len(got) != nb:
+            raise ValueError(f'comm_create: the unique id has {nb} bytes, the channel delivered {len(got)}')
+        idb = (C.c_ubyte * nb).from_buffer_copy(got)
+        comm = C.c_void_p()
+        with self.torch.cuda.device(self.device):
+            _lib.check(self.lib.spr_comm_init(idb, int(rank), int(world), C.byref(comm)), 'spr_comm_init')
+        return comm
+
+    def comm_destroy(self, comm):
+        if comm is not None:
+            _lib.check(self.lib.spr_comm_destroy(comm), 'spr_comm_destroy')
+
+    def comm_allreduce(self, comm, t):
+        """in-place sum over the ranks of a contiguous float64 / int64 tensor, on the current stream"""
+        if not t.is_contiguous():
+            raise ValueError('comm_allreduce: contiguous tensor')
+        fn = {'torch.float64': self.lib.spr_allreduce_f64, 'torch.int64': self.lib.spr_allreduce_i64}.get(str(t.dtype))
+        if fn is None:
+            raise TypeError(f'comm_allreduce: float64 or int64, not {t.dtype}')
+        if t.numel():
+            _lib.check(fn(comm, _ptr(t), t.numel(), self._stream()), 'spr_allreduce')
+        return t
+
+    def comm_allgather(self, comm, t, out):
+        """rank q's tensor t at out[q] on every rank (out: contiguous, world x t's bytes), on the current stream"""
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        if nbytes:
+            _lib.check(self.lib.spr_allgather(comm, _ptr(t), _ptr(out), nbytes, self._stream()), 'spr_allgather')
+        return out
+
+    def fit_gram_pass(self, X, row0, n_points, n_features, scale_type, comm, world):
+        """The first pass of fit() with its collective as ONE library call (spr_fit_gram_pass): Gram kernel, finalize into the
+        rank's slots of the collective buffer, all-reduce over ``comm`` (None: one rank), statistics merge + scaled sum.
+        -> rowmean (n,), buf [F m m | world F 3 | world], packed [m m | 5 F], scale (F,), inv_scale (F,)"""
+        n, m, ld = self._check_matrix(X)
+        F = int(n_features)
+        nbuf = int(self.lib.spr_fit_gram_pass_buffer(m, F, int(world))) // 8
+        rowmean, buf = self.empty((n,)), self.empty((nbuf,))
+        packed, scale, inv_scale = self.empty((m * m + 5 * F,)), self.empty((F,)), self.empty((F,))
+        ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(m, F))
+        tic, toc = self._timed('stats_gram')
+        tic()
+        _lib.check(self.lib.spr_fit_gram_pass(comm, _ptr(X), int(X.dtype == self.torch.float32), n, m, ld, row0, n_points, F,
+                                              self.SCALE_CODES[scale_type], _ptr(rowmean), _ptr(buf), nbuf * 8, _ptr(packed),
+                                              packed.data_ptr() + m * m * 8, _ptr(scale), _ptr(inv_scale), _ptr(ws), ws.numel(),
+                                              self._stream()), 'spr_fit_gram_pass')
+        toc()
+        return rowmean, buf, packed, scale, inv_scale
+
     def stage_to_host(self, stage):
         """The same re-arrangement on the way to the host: block (q, v) of the staged field is copied straight to its place
         in a page-locked (n_p, world * n_loc) result -- no pass over the field on the device.  None: no pinned memory."""

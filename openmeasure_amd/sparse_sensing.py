@@ -87,13 +87,20 @@ class RowShard:
               their block into it with the SDMA engines (openmeasure_amd/p2p.py: no compute unit, so a gather left in
               flight really runs under the next fit(); any block sizes without padding); 'auto' (default) -- 'p2p' when
               its collective self-test passes on every rank, else 'rccl', with the reason on stderr and in
-              ``rom.gather_path_``.  SPR_GATHER=rccl|p2p|auto overrides.
+              ``rom.gather_path_``.  SPR_GATHER=rccl|p2p|auto overrides.  With 'auto' the first full-size exchange also times
+              both paths under a Gram pass and keeps the faster (ROM._gather_trial; SPR_GATHER_TRIAL=0: p2p whenever available).
+    native_comm  the all-reduces and all-gathers run through libspr_hip.so's OWN communicator (include/spr_hip.h: spr_comm_*,
+              spr_fit_gram_pass -- fit()'s Gram pass, all-reduce and statistics merge as one enqueue) over the RCCL library that
+              is already in the process; torch.distributed then only carries the communicator's unique id (and ``group`` says
+              who takes part).  Off by default (SPR_NATIVE_COMM=1 switches it on): the same bits either way, and the default
+              path is the one the gloo tests cover; needs one GPU per rank like any RCCL communicator.
     """
 
     def __init__(self, row0, n_global, group=None, force_collectives=False, broadcast_basis=False, partial=False,
-                 gather='auto'):
+                 gather='auto', native_comm=False):
         if gather not in ('auto', 'p2p', 'rccl'):
             raise ValueError("gather must be 'auto', 'p2p' or 'rccl'")
+        self.native_comm = bool(native_comm)
         self.row0 = int(row0)
         self.n_global = int(n_global)
         self.group = group
@@ -766,7 +773,7 @@ class _DeviceState(dict):
 
 #: attributes that never travel in a pickle: the engine, device state (downloaded instead), events, in-flight work
 _TRANSIENT = ('_eng', '_d', '_trace', '_pending', '_pending_field', '_gram_events', '_gram_events_pending', '_layout_src',
-              '_gap_t0', '_G', '_last_decomp', 'comm_timing', 'last_comm_', '_layout', '_p2p', '_gather_sel', '_basis_checked', '_basis_diverged', '_deferred', '_row0_d')
+              '_gap_t0', '_G', '_last_decomp', 'comm_timing', 'last_comm_', '_layout', '_p2p', '_gather_sel', '_basis_checked', '_basis_diverged', '_deferred', '_row0_d', '_ncomm', '_combined', '_comm_stream')
 
 
 class ROM:
@@ -833,7 +840,7 @@ class ROM:
         state['_d_host'] = d_host
         if self._shard is not None:
             sh = RowShard(self._shard.row0, self._shard.n_global, None, self._shard.force_collectives,
-                          self._shard.broadcast_basis, self._shard.partial, self._shard.gather)
+                          self._shard.broadcast_basis, self._shard.partial, self._shard.gather, self._shard.native_comm)
             state['_shard'] = sh
         return state
 
@@ -1015,11 +1022,46 @@ class ROM:
     #: (name, shape, time.time()) of the last collective this object ENTERED -- what a watchdog prints when a rank hangs
     last_comm_ = None
 
+    def _native_comm(self):
+        """libspr_hip.so's own communicator (RowShard(native_comm=True) / SPR_NATIVE_COMM=1), created at first use -- COLLECTIVE:
+        rank 0's unique id travels through ONE torch.distributed broadcast -- or None: the collectives go through
+        torch.distributed."""
+        if not self._dist():
+            return None
+        nc = self.__dict__.get('_ncomm')
+        if nc is not None:
+            return nc or None
+        import os
+        eng = self._engine()
+        env = os.environ.get('SPR_NATIVE_COMM')
+        if not ((self._shard.native_comm or env == '1') and env != '0') or not hasattr(eng, 'comm_create'):
+            self._ncomm = False
+            return None
+        import time
+        import torch.distributed as dist
+        t = eng.torch
+        nb = int(eng.lib.spr_comm_unique_id_bytes())
+
+        def carry(idb):
+            buf = t.zeros(nb, dtype=t.uint8) if idb is None else t.tensor(list(idb), dtype=t.uint8)
+            if dist.get_backend(self._shard.group) == 'nccl':
+                buf = buf.to(eng.device)
+            src = dist.get_global_rank(self._shard.group, 0) if self._shard.group is not None else 0
+            self.last_comm_ = ('broadcast (unique id of the native communicator)', (nb,), time.time())
+            dist.broadcast(buf, src=src, group=self._shard.group)
+            return bytes(buf.cpu().numpy().tobytes())
+        self._ncomm = eng.comm_create(self._world(), self._shard.rank, carry)
+        self.comm_library_ = eng.lib.spr_comm_library().decode()
+        return self._ncomm
+
     def _all_reduce(self, t):
         if self._dist():
             import time
-            import torch.distributed as dist
             self.last_comm_ = ('all_reduce', tuple(t.shape), time.time())
+            nc = self._native_comm()
+            if nc is not None and t.is_contiguous() and str(t.dtype) in ('torch.float64', 'torch.int64'):
+                return self._engine().comm_allreduce(nc, t)
+            import torch.distributed as dist
             dist.all_reduce(t, group=self._shard.group)
         return t
 
@@ -1028,11 +1070,15 @@ class ROM:
         if not self._dist():
             return t[None]
         import time
-        import torch.distributed as dist
         self.last_comm_ = ('all_gather', tuple(t.shape), time.time())
         flat = t.contiguous().view(-1)                       # concatenated layout: accepted by RCCL and gloo alike
         out = flat.new_empty((self._world() * flat.numel(),))
-        dist.all_gather_into_tensor(out, flat, group=self._shard.group)
+        nc = self._native_comm()
+        if nc is not None:
+            self._engine().comm_allgather(nc, flat, out)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(out, flat, group=self._shard.group)
         return out.view((self._world(),) + tuple(t.shape))
 
     def _lazy(self, key, make):
@@ -1200,10 +1246,11 @@ class ROM:
         Xd = self._Xd()
         F = self.n_features
         tr_ = self._trace = _Trace(eng)
-        rowmean, gram, fs_d = self._gram_collective(Xd)
+        fused = scale_type if (axis_cnt == 1 and scale_type in getattr(eng, 'SCALE_CODES', ())) else None
+        rowmean, gram, fs_d = self._gram_collective(Xd, combine=fused)
         self._merge_stats(gram, fs_d, rowmean, scale_type, axis_cnt)
 
-    def _gram_collective(self, Xd):
+    def _gram_collective(self, Xd, combine=None):
         """The fused stats + Gram pass over the local rows and the ONE collective of fit(): an all-reduce (sum) of a
         buffer [F m m Gram doubles | world x F x 3 statistics | world first rows], every rank writing its (count, mean, M2)
         triples and its first global row into its own slots and zeros elsewhere, so the sum hands every rank all ranks'
@@ -1221,6 +1268,24 @@ class ROM:
             self._trace.mark('stats_gram')
             return rowmean, gram, fstats[None]
         world, rank = self._world(), self._shard.rank
+        self.__dict__.pop('_combined', None)
+        nc = self._native_comm()
+        if nc is not None and combine is not None and m <= 256 and hasattr(eng, 'fit_gram_pass'):
+            # the whole pass -- Gram kernel, finalize, all-reduce, statistics merge + scaled sum -- as ONE call of the library
+            # (spr_fit_gram_pass): nothing of the host between the kernels and the collective; combine = the scale_type
+            close = self._comm_bracket('allreduce')           # (brackets the whole enqueue here)
+            import time
+            self.last_comm_ = ('spr_fit_gram_pass (Gram + all_reduce + combine)', (F, m, m), time.time())
+            rowmean, buf, packed_d, scale_d, inv_d = eng.fit_gram_pass(Xd, self._row0, self.n_points, F, combine, nc, world)
+            close()
+            if fill:
+                self._gram_events = (e0, eng.timing_event())
+            self._trace.mark('stats_gram')
+            self._combined = (packed_d, scale_d, inv_d)
+            fstats_all = buf[F * m * m:F * m * m + world * F * 3].view(world, F, 3)
+            if '_layout' not in self.__dict__:
+                self._layout_src = (fstats_all[:, :, 0], buf[F * m * m + world * F * 3:])
+            return rowmean, buf[:F * m * m].view(F, m, m), fstats_all
         buf = eng.zeros((F * m * m + world * F * 3 + world,))
         # this rank's first row (exact below 2^53), see _shard_layout -- from a resident scalar: assigning a Python float is a
         # synchronous pageable H2D copy, which queues on an SDMA engine BEHIND the pushes of a p2p field exchange in flight
@@ -1312,7 +1377,8 @@ class ROM:
         if axis_cnt == 1 and scale_type in getattr(eng, 'SCALE_CODES', ()) and hasattr(eng, 'gram_combine'):
             # statistics merge, feature scales and G = sum_f G_f / scl_f^2 on the device (csrc/combine.hip): one
             # download of m^2 + 5F doubles, the scales never leave HBM
-            packed_d, scale_d, inv_d = eng.gram_combine(gram, fs_d, scale_type)
+            comb = self.__dict__.pop('_combined', None)       # spr_fit_gram_pass has merged already (native communicator)
+            packed_d, scale_d, inv_d = comb if comb is not None else eng.gram_combine(gram, fs_d, scale_type)
             fill = self._filler_wanted(Xd) and getattr(self, '_fit_fills_gap', False)
 
             def gap_hook():
@@ -1518,6 +1584,10 @@ class ROM:
         """rank 0's float64 vector `pack` (same length on every rank) -> every rank"""
         import torch.distributed as dist
         eng = self._engine()
+        nc = self._native_comm()
+        if nc is not None:                                    # a sum in which only rank 0 contributes (adding zeros is exact)
+            t = eng.to_device(pack if self._shard.rank == 0 else np.zeros_like(pack))
+            return eng.to_host(eng.comm_allreduce(nc, t))
         t = eng.to_device(pack)
         dist.broadcast(t, src=dist.get_global_rank(self._shard.group, 0) if self._shard.group is not None else 0,
                        group=self._shard.group)
@@ -2005,8 +2075,31 @@ class ROM:
             close = self._comm_bracket('gather')              # issue -> join, when the join happens inside this call
             import time
             self.last_comm_ = ('field all_gather (rccl)', (world, n_p, n_loc), time.time())
-            work = dist.all_gather_into_tensor(stage.view(-1), loc.contiguous().view(-1), group=self._shard.group,
-                                               async_op=True)
+            nc = self._native_comm()
+            if nc is not None:
+                # the library's own communicator: the all-gather on a side stream behind the reconstruct kernel, joined by an event
+                t = eng.torch
+                side = self.__dict__.get('_comm_stream')
+                if side is None:
+                    side = self._comm_stream = t.cuda.Stream(eng.device)
+                ev0 = t.cuda.Event()
+                ev0.record(t.cuda.current_stream(eng.device))
+                side.wait_event(ev0)
+                with t.cuda.stream(side):
+                    eng.comm_allgather(nc, loc, stage)
+                    ev1 = t.cuda.Event()
+                    ev1.record(side)
+                loc.record_stream(side)
+                stage.record_stream(side)
+
+                class _Joined:
+                    @staticmethod
+                    def wait():
+                        t.cuda.current_stream(eng.device).wait_event(ev1)
+                work = _Joined()
+            else:
+                work = dist.all_gather_into_tensor(stage.view(-1), loc.contiguous().view(-1), group=self._shard.group,
+                                                   async_op=True)
             if n_p == 1:
                 out = stage.view(1, world * n_loc)
                 if not to_host and not wait:
@@ -2083,6 +2176,10 @@ class ROM:
         if px is not None:
             px.close()
         self.__dict__.pop('_gather_sel', None)
+        nc = self.__dict__.pop('_ncomm', None)
+        if nc:
+            self._engine().torch.cuda.synchronize(self._engine().device)
+            self._engine().comm_destroy(nc)
 
     def use_gather(self, path):
         """Switch the field exchange of later reconstruct() calls ('auto' | 'p2p' | 'rccl'; COLLECTIVE like the calls
@@ -2299,7 +2396,11 @@ class ROM:
         eng.reconstruct(Ur_d, self._row0, self.n_points, self.n_features, rowmean_d, scale_d, A_d, out=mine[:, :n_loc])
         stage = eng.empty((world, n_p, n_max))
         close = self._comm_bracket('gather')
-        dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self._shard.group)
+        nc = self._native_comm()
+        if nc is not None:
+            eng.comm_allgather(nc, mine, stage)
+        else:
+            dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self._shard.group)
         close()
         first = int(lay[0, 0])                                # 0 unless the group holds a slice of a larger job (partial)
         total = int(lay[:, 1].sum())

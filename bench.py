@@ -836,9 +836,35 @@ def run_rank(args):
     wd.beat('cpu baseline / parity leg')
     if rank == 0 and world == 1 and not share and not args.no_cpu:
         from oracle import spr_oracle as orc
-        cc = min(wl['cpu_cells'], n_points)
-        idx = torch.cat([torch.arange(f * n_points, f * n_points + cc, device=eng.device) for f in range(F)])
-        Xs = eng.to_host(Xd[idx])                   # first cc cells of every feature: a valid (cc*F) x m problem
+        # The sample is sized by a TIME budget, not a fixed cell count: the oracle is timed on a small probe
+        # (which also warms the BLAS pool up), its rate -- fit + reconstruct are O(n) at fixed m, r -- gives the number of cells
+        # that fill SPR_BENCH_CPU_BUDGET_S seconds (default 30), capped by the workload and by half of the host's free RAM
+        # (the oracle holds X, X0, U and the field: about 6 copies of the sample)
+        budget_s = float(os.environ.get('SPR_BENCH_CPU_BUDGET_S', '30'))
+        probe_cells = min(n_points, max(2000, wl['cpu_cells'] // 5))
+
+        def sample_of(cells):
+            ix = torch.cat([torch.arange(f * n_points, f * n_points + cells, device=eng.device) for f in range(F)])
+            return eng.to_host(Xd[ix])              # first `cells` cells of every feature: a valid (cells*F) x m problem
+
+        cc = probe_cells
+        probe_note = ''
+        if probe_cells < n_points:
+            Xp = sample_of(probe_cells)
+            wd.stop()
+            t_p = time.perf_counter()
+            orc.fit_reconstruct_timed(Xp.astype(np.float64) if f32 else Xp, F, s)
+            t_p = time.perf_counter() - t_p
+            cc = int(probe_cells * budget_s / max(t_p, 1e-3))
+            try:
+                import psutil
+                cc = min(cc, int(0.5 * psutil.virtual_memory().available / (6.0 * F * m * 8)))
+            except ImportError:
+                pass
+            cc = max(probe_cells, min(n_points, cc // 1000 * 1000))
+            probe_note = f'; sample sized for a {budget_s:.0f} s budget from a {probe_cells}-cell probe ({t_p:.2f} s)'
+            del Xp
+        Xs = sample_of(cc)
         wd.stop()                                   # the oracle runs for 10-30 s of host time; nothing below can hang on a peer
         t1 = time.perf_counter()
         # an f32-stored sample goes to the oracle widened: the reference itself would run in f32 on it
@@ -864,7 +890,7 @@ def run_rank(args):
                    cpu_model=_cpu_model(), host_cpus=os.cpu_count(), physical_cores=phys, blas=blas,
                    sample=f'{cc} cells x {F} features x {m} snapshots ({Xs.nbytes / 1e6:.0f} MB), s={s}: '
                           f'oracle fit+reconstruct {t_cpu:.2f} s (same generator, first {cc} cells per feature)'
-                          + extrap + note)
+                          + extrap + probe_note + note)
         # parity on the same sample: GPU path vs oracle.  The oracle ran in f64 on the stored values widened, which is
         # what the reference computes for a float32 X as well (X_cnt / X_scl are float64: X0, U float64, :106-107, :169)
         Xs_in = DeviceMatrix(eng.to_device(Xs, dtype=torch.float32), basis='f32') if f32 else Xs

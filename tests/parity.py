@@ -382,7 +382,7 @@ def run_documented_idioms(g, engine, monkeypatch):
     """The reference's documented use of the measurement matrix (README.md:160-184 and INTEGRATION.md) run twice: on
     the dense ndarray optimal_placement returns while it is small, and on the OneHotRows it returns above the dense
     limit (46 GB at BASELINE config 3) -- every line must behave the same."""
-    import openmeasure_amd.sparse_sensing as mod
+    import openmeasure_amd.rom as mod
     X = g['X'].astype(np.float64)
     n, m = X.shape
     F = g['n_features']

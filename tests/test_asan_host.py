@@ -27,6 +27,8 @@ for name, (res, args) in sorted(_lib.PROTOTYPES.items()):
         continue
     if name.startswith('spr_p2p_'):           # raw pointers handed straight to the HIP runtime (allocation, IPC mapping, stream
         continue                              # memory operations): no shape to validate, and this build has no runtime to call
+    if name.startswith('spr_comm_'):          # HOST pointers (the 128 bytes of the unique id) that are read / written by design, and
+        continue                              # calls into RCCL; the handle look-up of the collectives IS swept below (spr_allreduce_*, ...)
     fn = getattr(lib, name)
     # all-zero arguments: NULL pointers and empty shapes must be rejected by the validation layer, with a message
     zero = [C.c_void_p(None) if a is C.c_void_p else a(0) for a in args]

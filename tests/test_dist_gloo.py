@@ -425,7 +425,7 @@ def _wide_worker(rank, world, port, out_dir, bcast, perturb):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        import openmeasure_amd.sparse_sensing as ss
+        import openmeasure_amd._eigen as ss
         from openmeasure_amd.sparse_sensing import SPR, RowShard
         from tests.numpy_engine import NumpyEngine
         rng = np.random.default_rng(5)

@@ -56,7 +56,7 @@ def test_conditioning_guard_through_host_logic(decades):   # SURVEY 7 hard part 
 def test_conditioning_guard_wide_matrix_takes_the_top_r_svd(decades, monkeypatch):
     """m >= 96 with r <= m / 2: the refinement pass ends with spr_host_svd_top (all singular values, the r retained right vectors)
     instead of the full dgesdd -- same sensors, spectrum and basis as the oracle; and the same with the route switched off."""
-    from openmeasure_amd import sparse_sensing as ss
+    from openmeasure_amd import _eigen as ss
     calls = []
     real = ss._svd_top_native
     monkeypatch.setattr(ss, '_svd_top_native', lambda M, r: calls.append(M.shape) or real(M, r))
@@ -70,7 +70,7 @@ def test_conditioning_guard_wide_matrix_takes_the_top_r_svd(decades, monkeypatch
 def test_svd_top_native_against_lapack(m, r, decades):
     """spr_host_svd_top on the factor a refinement pass hands it (R diag(d) V^T, R the Cholesky factor of a matrix near I): all
     singular values to the relative accuracy of LAPACK's own, the r leading right singular vectors up to sign, orthonormal."""
-    from openmeasure_amd.sparse_sensing import _svd_top_native
+    from openmeasure_amd._eigen import _svd_top_native
     rng = np.random.default_rng(m + r)
     V, _ = np.linalg.qr(rng.standard_normal((m, m)))
     d = np.concatenate([np.logspace(0, -decades, r), 10 ** (-decades - 0.5) * (1 + 0.1 * rng.random(m - r))])
@@ -91,7 +91,7 @@ def test_svd_top_native_against_lapack(m, r, decades):
 def test_svd_top_native_declines():
     """None (the caller takes np.linalg.svd) for small matrices, r above m / 2, non-finite input -- and for a cluster of equal
     singular values among the r leading ones, where inverse iteration without re-orthogonalisation cannot separate the vectors."""
-    from openmeasure_amd.sparse_sensing import _svd_top_native
+    from openmeasure_amd._eigen import _svd_top_native
     rng = np.random.default_rng(3)
     assert _svd_top_native(rng.standard_normal((40, 40)), 8) is None
     assert _svd_top_native(rng.standard_normal((128, 128)), 65) is None
@@ -275,7 +275,7 @@ def test_pickle_and_deepcopy_round_trip(small, stage):
     attributes, same predictions, and it can be fitted again."""
     import copy
     import pickle
-    from openmeasure_amd.sparse_sensing import _DeviceState
+    from openmeasure_amd.rom import _DeviceState
     X, F, xyz = small
     spr = SPR(X, F, xyz, engine=NumpyEngine())
     if stage != 'constructed':
@@ -382,7 +382,7 @@ def test_native_top_r_eigen_route(m, r):
     """spr_host_eig_top (round 5): dsytrd + dsterf + batched inverse iterations + dormtr in ONE host call of the library, LAPACK
     reached through SciPy's exported function pointers -- against dsyevd; a cluster of equal eigenvalues makes it decline (the
     Python route with dstein / dsyevd takes over); fit() takes it for 32 <= m < 96 when the number of modes is given."""
-    import openmeasure_amd.sparse_sensing as ss
+    import openmeasure_amd._eigen as ss
     rng = np.random.default_rng(m)
     A = rng.standard_normal((6 * m, m)) * (0.9 ** np.arange(m))
     A -= A.mean(axis=1, keepdims=True)
@@ -613,7 +613,7 @@ def test_top_r_eigen_route_matches_full_solve(m, modes, monkeypatch):
     sparse_sensing._eigvecs_top) instead of dsyevd's full decomposition (reference :272 computes all of them and :336
     slices): same rank, spectrum, basis (up to sign), sensors and field -- against the full solve on the same data and
     against the oracle."""
-    import openmeasure_amd.sparse_sensing as ss
+    import openmeasure_amd._eigen as ss
     from oracle import spr_oracle as orc
     X = _synth(400, 3, m, 60, 0.85, 1e-3, seed=m)
     select, n_modes = modes
@@ -651,7 +651,7 @@ def test_top_r_eigen_route_matches_full_solve(m, modes, monkeypatch):
 
 def test_top_r_route_falls_back(monkeypatch):
     """r > m/2, a spectrum that needs the refinement pass, or vectors that fail the orthogonality check: dsyevd as before."""
-    import openmeasure_amd.sparse_sensing as ss
+    import openmeasure_amd._eigen as ss
     X = _synth(300, 2, 128, 100, 0.97, 1e-3, seed=3)
     calls = []
     real_top = ss._eigvecs_top
@@ -697,7 +697,7 @@ def test_fit_chooses_the_precentred_projection_on_large_offsets(axis_cnt):
 def test_rank_beyond_the_kernel_cap_is_a_value_error(monkeypatch):
     """r > SPR_MAX_R_WIDE retained modes: fit and reconstruct take them (:336 slices any r <= m); the placement and solve
     kernels do not -- a ValueError naming the cap, before any device work, instead of a failure inside the engine."""
-    import openmeasure_amd.sparse_sensing as ss
+    import openmeasure_amd.rom as ss
     monkeypatch.setattr(ss, 'SPR_MAX_R_WIDE', 6)
     rng = np.random.default_rng(4)
     X = rng.standard_normal((60, 12))
@@ -777,7 +777,7 @@ def test_clustered_spectrum_takes_dstein(monkeypatch):
     """A Gram matrix with a (numerically) multiple retained eigenvalue: the batched inverse iteration cannot separate the
     cluster, _tridiag_vectors_batched declines (or its result fails the final check) and dstein / dsyevd take over --
     fit() still returns an orthonormal basis with the right spectrum."""
-    import openmeasure_amd.sparse_sensing as ss
+    import openmeasure_amd._eigen as ss
     rng = np.random.default_rng(8)
     m, n = 128, 3000
     Q, _ = np.linalg.qr(rng.standard_normal((m, m)))

@@ -23,12 +23,18 @@ for name, cells in shapes:
     spr = SPR(DeviceMatrix(Xd), F, None, engine=eng)
     spr.gap_filler = True
     spr._GAP_FILL_MIN_MS = 0.0                      # fill whatever gap this host leaves
-    ref, bad, fills = None, 0, 0
+    ref, bad, fills, pend, deferred = None, 0, 0, None, 0
     reps = rounds if (cells < 1_000_000 or len(sys.argv) > 2) else max(rounds // 4, 10)
     t0 = time.time()
     for it in range(reps):
         spr.fit(select_modes='number', n_modes=s)
         fills += int(getattr(spr, '_gap_fill_rows', 0) > 0)
+        if pend is not None:
+            # round 6: the previous round's field once more in the ASYNCHRONOUS form -- deferred by default (ROM.defer_reconstruct):
+            # its kernel ran in the host gap of the fit() above, on the basis of the round it was called in
+            deferred += int(pend.launched)
+            if not np.array_equal(eng.to_host(pend.wait())[0], ref[3]):
+                bad += 1
         C = spr.optimal_placement()
         spr.train(C)
         piv = spr.sensors_
@@ -37,12 +43,13 @@ for name, cells in shapes:
         y[:, 2] = piv // cells
         a, _ = spr.predict(y)
         x = spr.reconstruct(a)
+        pend = spr.reconstruct(a, to_host=False, wait=False) if it % 2 else None     # (a gap holds the deferred launch OR the filler)
         got = (spr.Sigma_r.copy(), piv.copy(), a.copy(), x[:, 0].copy())
         if ref is None:
             ref = got
         elif not all(np.array_equal(u, v) for u, v in zip(got, ref)):
             bad += 1
     print(f'{name} shape, {cells} cells (m = {m}, s = {s}): {reps} rounds, {bad} differing from the first in any bit, '
-          f'filler ran in {fills}, {time.time() - t0:.1f} s', flush=True)
+          f'filler ran in {fills}, deferred reconstructs launched inside the next fit {deferred}, {time.time() - t0:.1f} s', flush=True)
     del spr, Xd
     torch.cuda.empty_cache()

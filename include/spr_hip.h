@@ -6,7 +6,7 @@
  * FFI; its "operator interface" for this path is the set of NumPy/SciPy calls listed in
  * SURVEY.md section 2 (K1..K11).  Each entry point below replaces one of those call
  * sites and says which (file:line of sparse_sensing.py).  The Python class in
- * openmeasure_amd/sparse_sensing.py binds them with ctypes; INTEGRATION.md shows the
+ * openmeasure_amd/rom.py (imported as openmeasure_amd.sparse_sensing) binds them with ctypes; INTEGRATION.md shows the
  * same binding as a maintainer of the reference would add it.
  *
  * Conventions
@@ -112,7 +112,7 @@ int spr_host_tridiag_vectors(const double *h_d, const double *h_e, int32_t m, co
  * 2 when the vectors miss their orthonormality checks (close eigenvalues): the caller then takes dstein / dsyevd.  < 0: SPR_E_*. */
 int spr_host_eig_top(const double *h_G, int32_t m, int32_t r, double *h_lam, double *h_V, void *fn_dsytrd, void *fn_dsterf,
                      void *fn_dormtr);
-/* The same idea for the SVD that ends fit()'s conditioning refinement pass (np.linalg.svd of an m x m factor, sparse_sensing.py
+/* The same idea for the SVD that ends fit()'s conditioning refinement pass (np.linalg.svd of an m x m factor, openmeasure_amd/rom.py
  * _refine_spectrum; reference: the accuracy of np.linalg.svd(X0), :272): ALL singular values (h_S, descending) and the r leading
  * RIGHT singular vectors (h_V, m x r row-major) of the row-major m x m matrix h_M -- dgebrd, dbdsdc (values only), the batched
  * inverse iteration on the Golub-Kahan form of the bidiagonal matrix, dormbr; LAPACK again through the caller's function
@@ -374,7 +374,11 @@ int spr_field_unstage_blocks_f64(const double *d_stage, int32_t world, int32_t n
  *                                  nowhere) and -- an SDMA copy cannot be taken back -- every arrival counter raised while
  *                                  *d_status != 0 carries the poison bit: the peer's join of this gather and this rank's own
  *                                  both fail, nobody is handed a field that was overwritten while it may still have been read.
- *                                  The caller orders streams[p] behind the kernel that wrote the block.
+ *                                  The caller orders streams[p] behind the kernel that wrote the block -- with events, or
+ *                                  (d_ready_flag != NULL) with a counter of its own that it raises to ready_value on its
+ *                                  compute stream behind that kernel (spr_p2p_flags_set: system-scope release): the copy
+ *                                  streams' wait kernels then await it too (index n_peers in the status words if it never
+ *                                  comes) and no event of the compute stream is needed.
  *   spr_field_gather_p2p_join      `stream` waits (one kernel) until every one of the n counters -- the peers' arrivals and
  *                                  this rank's own pushed counters -- has reached arrive_value.
  *   spr_field_gather_p2p_release   *d_peer_release_flag[p] = value for every peer (one kernel), behind everything enqueued
@@ -398,7 +402,8 @@ uint64_t spr_p2p_poison_bit(void);
 int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc, int32_t n_peers,
                          void *const *d_peer_field, void *const *d_release_flag, uint64_t release_value,
                          double release_timeout_s, void *const *d_peer_arrive_flag, uint64_t arrive_value,
-                         void *const *d_pushed_flag, void *const *streams, void *d_status);
+                         void *const *d_pushed_flag, void *const *streams, void *d_status, void *d_ready_flag,
+                         uint64_t ready_value);
 int spr_field_gather_p2p_join(void *const *d_flags, int32_t n_flags, uint64_t arrive_value, double timeout_s, void *d_status,
                               void *stream);
 int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_peers, uint64_t value, void *stream);

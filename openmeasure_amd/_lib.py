@@ -84,7 +84,7 @@ PROTOTYPES = {
     'spr_p2p_flags_wait': (C.c_int, [_p, _i32, _u64, _dbl, _p, _p]),
     'spr_p2p_copy': (C.c_int, [_p, _p, _i64, _p]),
     'spr_p2p_poison_bit': (_u64, []),
-    'spr_field_gather_p2p': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p, _u64, _dbl, _p, _u64, _p, _p, _p]),
+    'spr_field_gather_p2p': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i32, _p, _p, _u64, _dbl, _p, _u64, _p, _p, _p, _p, _u64]),
     'spr_field_gather_p2p_join': (C.c_int, [_p, _i32, _u64, _dbl, _p, _p]),
     'spr_field_gather_p2p_release': (C.c_int, [_p, _i32, _u64, _p]),
     'spr_qr_workspace': (_sz, [_i64]),

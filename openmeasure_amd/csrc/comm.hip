@@ -229,7 +229,7 @@ extern "C" int spr_allgather(void *comm, const void *d_send, void *d_recv, int64
 }
 
 // ---- the first pass of fit() with its collective, as ONE enqueue -------------------------------------------------------------
-// Buffer layout (doubles; the very buffer openmeasure_amd/sparse_sensing.py all-reduces through torch.distributed):
+// Buffer layout (doubles; the very buffer openmeasure_amd/_shard.py all-reduces through torch.distributed):
 //   [ F m m   per-feature Gram blocks | world x F x 3  (count, mean, M2) per rank and feature | world  first global row per rank ]
 // every rank writes its own slots and zeros elsewhere, so that the ONE sum hands every rank all ranks' statistics and row blocks
 // in rank order (adding zeros is exact).

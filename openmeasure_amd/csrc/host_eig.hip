@@ -7,7 +7,7 @@
 // of DIFFERENT eigenvalues are independent, so this routine runs them side by side: every array carries the eigenvalue index
 // as its fastest dimension and the compiler vectorises over it (AVX-512: 8 eigenvalues per instruction).  Same algorithm as
 // dlagtf / dlagts(job = -1) / dstein's iteration, WITHOUT dstein's re-orthogonalisation inside clusters of close eigenvalues:
-// the caller checks the result for orthonormality and takes dstein when that fails (openmeasure_amd/sparse_sensing.py,
+// the caller checks the result for orthonormality and takes dstein when that fails (openmeasure_amd/_eigen.py,
 // _eigvecs_top).  Plain host code: no device memory, no stream.
 #include <math.h>
 #include <stdlib.h>
@@ -259,7 +259,7 @@ extern "C" int spr_host_eig_top(const double *h_G, int32_t m, int32_t r, double 
 
 
 // ---- the r leading RIGHT singular vectors and all singular values of a square matrix ------------------------------------------
-// fit()'s conditioning refinement (sparse_sensing.py, _refine_spectrum) ends with the SVD of an m x m factor M of which only the
+// fit()'s conditioning refinement (openmeasure_amd/rom.py, _refine_spectrum) ends with the SVD of an m x m factor M of which only the
 // singular values and the r retained right singular vectors are used; LAPACK's dgesdd computes all 2 m^2 vector entries (6.1 of the
 // 7 host milliseconds of a refinement pass at m = 256).  Here: dgebrd (M^T = Q B P^T in LAPACK's column-major reading of the
 // row-major M), dbdsdc for the singular values of the bidiagonal B alone, the r leading LEFT vectors of B by the batched inverse

@@ -166,6 +166,7 @@ constexpr unsigned long long kPoison = 1ull << 62;
 struct FlagTable {
   unsigned long long *p[kMaxFlags];
   unsigned short id[kMaxFlags];      // what a failing lane reports as its index (a sub-table keeps the caller's numbering)
+  unsigned short add[kMaxFlags];     // a wait on counter i is for value + add[i] (one launch may await counters of two sequences)
 };
 
 // *t.p[i] = value for all i -- OR value | POISON when the word at `gate` (NULL: no gate) is non-zero: the status word a failed
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(128) void p2p_flags_wait_kernel(FlagTable t, int n,
     for (;;) {
       seen = __hip_atomic_load(t.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (seen & kPoison) { bad = true; break; }
-      if (seen >= value) break;
+      if (seen >= value + t.add[i]) break;
       if (wall_clock64() - t0 > timeout_ticks) { bad = true; break; }
       __builtin_amdgcn_s_sleep(8);
     }
@@ -209,6 +210,7 @@ int fill_table(FlagTable &t, void *const *ptrs, int n, const char *who) {
     SPR_REQUIRE(ptrs[i] && (uintptr_t)ptrs[i] % 8 == 0, SPR_E_INVALID, "%s: counter %d is NULL or unaligned", who, i);
     t.p[i] = static_cast<unsigned long long *>(ptrs[i]);
     t.id[i] = (unsigned short)i;
+    t.add[i] = 0;
   }
   return SPR_OK;
 }
@@ -248,7 +250,8 @@ extern "C" int spr_p2p_flags_wait(void *const *d_flags, int32_t n, uint64_t valu
 extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t n_p, int64_t first, int64_t n_loc,
                                     int32_t n_peers, void *const *d_peer_field, void *const *d_release_flag,
                                     uint64_t release_value, double release_timeout_s, void *const *d_peer_arrive_flag,
-                                    uint64_t arrive_value, void *const *d_pushed_flag, void *const *streams, void *d_status) {
+                                    uint64_t arrive_value, void *const *d_pushed_flag, void *const *streams, void *d_status,
+                                    void *d_ready_flag, uint64_t ready_value) {
   SPR_REQUIRE(d_field && n_p >= 1 && first >= 0 && n_loc >= 0 && ldo >= first + n_loc, SPR_E_INVALID,
               "spr_field_gather_p2p: n_p=%d first=%lld n_loc=%lld ldo=%lld", n_p, (long long)first, (long long)n_loc,
               (long long)ldo);
@@ -257,6 +260,10 @@ extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t 
   SPR_REQUIRE(release_value == 0 || (d_release_flag && release_timeout_s > 0.0 && release_timeout_s <= 3600.0), SPR_E_INVALID,
               "spr_field_gather_p2p: release flags missing / release_timeout_s=%g outside (0, 3600]", release_timeout_s);
   SPR_REQUIRE(d_status == nullptr || (uintptr_t)d_status % 8 == 0, SPR_E_INVALID, "spr_field_gather_p2p: unaligned status");
+  SPR_REQUIRE((uintptr_t)d_ready_flag % 8 == 0 && (!d_ready_flag || (ready_value >= release_value && ready_value - release_value < 65536
+                                                                      && release_timeout_s > 0.0 && release_timeout_s <= 3600.0)),
+              SPR_E_INVALID, "spr_field_gather_p2p: unaligned ready counter / ready_value=%llu not in [release_value, release_value + 65535]",
+              (unsigned long long)ready_value);
   for (int p = 0; p < n_peers; ++p) {
     SPR_REQUIRE(d_peer_field[p] && d_peer_arrive_flag[p] && (uintptr_t)d_peer_arrive_flag[p] % 8 == 0, SPR_E_INVALID,
                 "spr_field_gather_p2p: peer %d has a NULL / unaligned pointer", p);
@@ -288,14 +295,26 @@ extern "C" int spr_field_gather_p2p(const double *d_field, int64_t ldo, int32_t 
       if (done[p] || static_cast<hipStream_t>(streams[p]) != st) continue;
       if (release_value) {
         rel.p[n_rel] = static_cast<unsigned long long *>(d_release_flag[p]);
+        rel.add[n_rel] = 0;
         rel.id[n_rel++] = (unsigned short)p;
       }
       arr.p[n_arr] = static_cast<unsigned long long *>(d_peer_arrive_flag[p]);
+      arr.add[n_arr] = 0;
       arr.id[n_arr++] = (unsigned short)p;
       if (d_pushed_flag && d_pushed_flag[p]) {   // "my push to peer p has left": a counter of THIS rank, raised behind the copies
         arr.p[n_arr] = static_cast<unsigned long long *>(d_pushed_flag[p]);
+        arr.add[n_arr] = 0;
         arr.id[n_arr++] = (unsigned short)p;
       }
+    }
+    if (d_ready_flag) {
+      // "the block is written": a counter of THIS rank that the caller raises on its compute stream behind the kernel that
+      // wrote the block (spr_p2p_flags_set: a system-scope release) -- awaited here instead of an event of the compute stream:
+      // one event record + one stream wait per copy stream cost 0.25 ms of host time per push while the compute stream was busy
+      // (profiles/r06_p2p_push_host.txt).  Index n_peers in the status words if it never comes.
+      rel.p[n_rel] = static_cast<unsigned long long *>(d_ready_flag);
+      rel.add[n_rel] = (unsigned short)(ready_value - release_value);
+      rel.id[n_rel++] = (unsigned short)n_peers;
     }
     if (n_rel) {
       // the peers must have let go of what their buffer held (each raises its slot when it enters its own gather).  The wait

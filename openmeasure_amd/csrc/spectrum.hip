@@ -26,7 +26,7 @@ constexpr int SP_MAXM = 64;
 constexpr int SP_THREADS = 1024;
 constexpr int SP_MAX_SWEEPS = 15;
 
-// scale_type codes shared with openmeasure_amd/sparse_sensing.py
+// scale_type codes shared with openmeasure_amd/rom.py / engine.py
 enum { SC_STD = 0, SC_NONE = 1, SC_PARETO = 2, SC_VAST = 3, SC_LEVEL = 4, SC_VARIANCE = 5, SC_POISSON = 6, SC_L2 = 7 };
 
 __device__ inline double block_sum_all(double v, double *red) {

@@ -52,7 +52,7 @@ _REASON_BYTES = 200                  # a rank's verdict and the reason it gives,
 _BUS_ID_BYTES = 24                   # "0000:c1:00.0" and its terminator, with room
 # 5 counter arrays of `world` uint64 in the 4 KB counter page (world <= 102) AND a join table of 2 (world - 1) counters in one
 # kernel argument of 128 pointers (csrc/p2p.hip kMaxFlags): beyond it the join would be refused mid-gather
-_MAX_WORLD = 65
+_MAX_WORLD = 65                      # (6 counter arrays of 65 words fit the page as well)
 _KINDS = {'coarse': 0, 'fine': 1, 'uncached': 2}
 
 
@@ -121,7 +121,7 @@ class P2PFieldGather:
         self.selftest_report = None
         self._ever_allocated = False                           # ensure() has allocated before (identical on all ranks: it is collective)
         # None until the first full-size exchange through these buffers has been compared, block by block, with what the peers
-        # say they sent (sparse_sensing.py, ROM._p2p_first_exchange); then a short report
+        # say they sent (_shard.py, ROM._p2p_first_exchange); then a short report
         self.verified = None
         self.host_ms = dict(begin=0.0, push=0.0, push_order=0.0, push_call=0.0, join=0.0, calls=0)   # host wall time spent issuing (bench.py reports the means)
         # where a join kernel that gives up leaves (counter index + 1, value seen): page-locked HOST memory the kernel writes
@@ -131,6 +131,9 @@ class P2PFieldGather:
         self._status_np = self._status.numpy()
         self._poison = int(self.lib.spr_p2p_poison_bit())
         self._tabs = {}                                        # pointer tables of the calls, built once per allocation
+        # how the copy streams learn that the block is written: a counter raised on the compute stream (default) or an event of it
+        # (SPR_P2P_ORDER=event: A/B)
+        self._order_by_counter = os.environ.get('SPR_P2P_ORDER', 'counter') != 'event'
 
     # ------------------------------------------------------------------ set-up (COLLECTIVE)
     def ensure(self, n_p, n_total):
@@ -255,10 +258,10 @@ class P2PFieldGather:
             first = f'rank {bad[0]}: {first}'
         return False, first + (f' (ranks {bad} failed)' if len(bad) > 1 else '')
 
-    # counter page (int64 words): arrive[b][src] | release[src] | pushed[peer] | self-test[src]
+    # counter page (int64 words): arrive[b][src] | release[src] | pushed[peer] | self-test[src] | ready[0]
     def _slot(self, kind, idx, b=0):
         w = self.world
-        return {'arrive': b * w + idx, 'release': 2 * w + idx, 'pushed': 3 * w + idx, 'test': 4 * w + idx}[kind]
+        return {'arrive': b * w + idx, 'release': 2 * w + idx, 'pushed': 3 * w + idx, 'test': 4 * w + idx, 'ready': 5 * w + idx}[kind]
 
     def _flag(self, page, kind, idx, b=0):
         """address of a counter in the counter page at `page`"""
@@ -380,12 +383,23 @@ class P2PFieldGather:
         b = self.k % self.n_buf
         n_p, n_total = self.shape
         if self.peers:
-            # (a fresh event per push: re-recording ONE event while its previous record is still awaited by the copy streams
-            #  cost 0.5-1.0 ms of host time per push in the step loop, profiles/r06_p2p_push_host.txt)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(eng.device))
-            for s in self._pool:
-                s.wait_event(ev)
+            ready = 0
+            if self._order_by_counter:
+                # "my block is written": ONE single-wave kernel on the compute stream raises ready = k + 1 in my counter page (a
+                # system-scope release behind the reconstruct kernel); the copy streams' wait kernels poll it next to the peers'
+                # releases.  No event of the compute stream: recording one and making three copy streams wait for it cost 0.25 ms of
+                # host time per push while the compute stream was busy (profiles/r06_p2p_push_host.txt)
+                ready = self._flag(self.fbase, 'ready', 0)
+                tab = self._table('ready', lambda: _ptr_array([ready]))
+                _lib.check(self.lib.spr_p2p_flags_set(tab, 1, self.k + 1, torch.cuda.current_stream(eng.device).cuda_stream),
+                           'spr_p2p_flags_set')
+            else:
+                # (a fresh event per push: re-recording ONE event while its previous record is still awaited by the copy streams
+                #  cost 0.5-1.0 ms of host time per push in the step loop)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(eng.device))
+                for s in self._pool:
+                    s.wait_event(ev)
             t_call = time.perf_counter()
             self.host_ms['push_order'] += 1e3 * (t_call - t_host)
             field = self.base + b * self.field_bytes
@@ -398,7 +412,7 @@ class P2PFieldGather:
                 _ptr_array([s.cuda_stream for s in self.streams])))
             _lib.check(self.lib.spr_field_gather_p2p(
                 field, n_total, n_p, int(first), int(n_loc), len(self.peers), tabs[0], tabs[1], release_value,
-                self.release_timeout_s(), tabs[2], self.k + 1, tabs[3], tabs[4], self._status.data_ptr() + 16),
+                self.release_timeout_s(), tabs[2], self.k + 1, tabs[3], tabs[4], self._status.data_ptr() + 16, ready, self.k + 1),
                 'spr_field_gather_p2p')
             self.host_ms['push_call'] += 1e3 * (time.perf_counter() - t_call)
         joined_k = self.k
@@ -436,7 +450,11 @@ class P2PFieldGather:
             return
         n = len(self.peers)
         msgs = []
-        if st[2]:
+        if st[2] and int(st[2]) - 1 >= n:
+            msgs.append(f'a push of rank {self.rank} gave up waiting for its own counter ready[0] (the kernel that writes the block; at '
+                        f'{int(st[3]) & ~self._poison}) after {self.release_timeout_s():.0f} s; the arrival counters behind it carry '
+                        'the poison bit')
+        elif st[2]:
             q = self.peers[min(int(st[2]) - 1, n - 1)]
             seen = int(st[3])
             msgs.append(f'a push of rank {self.rank} gave up waiting for counter release[{q}] (rank {q} letting go of its copy '

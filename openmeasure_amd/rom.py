@@ -766,7 +766,9 @@ class ROM(ShardedOps):
             def gap_hook():
                 # the download is enqueued, the host is about to block on it: what goes into the gap behind it -- a
                 # reconstruct the caller deferred (useful work), else the filler (discarded work, opt-in)
-                if not self._flush_deferred() and fill:
+                if self._flush_deferred():
+                    self._gap_fill_rows = 0                    # (the gap holds the deferred launch, not a filler)
+                elif fill:
                     self._queue_gap_filler(Xd)
             packed = eng.to_host(packed_d, then=gap_hook)
             if fill:

@@ -954,6 +954,12 @@ def run_rank(args):
                if (backend != 'nccl' or os.environ.get('SPR_BENCH_ONE_GPU') == '1') else {}),
             'roofline': roof, 'cpu_baseline': cpu, 'phases': phases, 'parity': parity,
         }
+        if f32:
+            # BASELINE.md 4 counts the field write as n B bytes (B = 4 for f32 storage); the product writes the field in float64
+            # like the reference (Ur @ Ar.T and unscale_data are float64 for any dtype of X): 8 n here, 4 n more than the model
+            out['byte_model_note'] = ('hbm_roofline_frac_step counts the reconstructed field as float64 (8 bytes per row, what the product '
+                                      'writes and the reference returns); BASELINE.md section 4 models it with B = 4 for this storage: '
+                                      f'{4.0 * n_job / 1e9:.2f} GB of {step_bytes / 1e9:.1f} GB per step more than that model')
         out['rank_timeline_ms'] = {k_: (None if v != v else round(v, 4)) for k_, v in mine.items()}
         out['gaps_ms'] = {k_: (None if (v is None or v != v) else round(v, 4)) for k_, v in gaps_ms.items()}
         out['reconstruct_launch'] = ("deferred (ROM.defer_reconstruct, the library's default for reconstruct(to_host=False, wait=False)): "

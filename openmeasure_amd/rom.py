@@ -555,9 +555,22 @@ class ROM(ShardedOps):
                 raise ValueError(f'could not broadcast input array from shape ({m},) into shape ({self.n_points},)')
             raise NotImplementedError(f"scale_type={scale_type!r} has no device implementation (per-column kurtosis "
                                       'assigned to rows: only defined in the reference when n_points == m); no CPU fallback.')
-        if axis_cnt not in (1, None):
-            raise NotImplementedError(f'axis_cnt={axis_cnt!r}: row centring (1) and scalar centring (None) have a '
-                                      'device implementation; no CPU fallback for the rest.')
+        # axis_cnt is handed to np.average(x, axis=axis_cnt) on an (n_points, m) block whose result is assigned to n_points rows
+        # (:112): 1 and -1 are the row means, None the block mean; 0 / -2 give m column means, which NumPy refuses to put into
+        # n_points rows (ValueError) unless the two counts coincide; any other integer is not an axis of a 2-D block (AxisError)
+        if axis_cnt is None or axis_cnt == 1 and not isinstance(axis_cnt, bool):
+            return axis_cnt
+        if isinstance(axis_cnt, (int, np.integer)) and not isinstance(axis_cnt, bool):
+            if axis_cnt == -1:
+                return 1
+            if axis_cnt in (0, -2):
+                m = self.X.shape[1]
+                if m not in (1, self.n_points):
+                    raise ValueError(f'could not broadcast input array from shape ({m},) into shape ({self.n_points},)')
+            else:
+                raise np.exceptions.AxisError(int(axis_cnt), 2)
+        raise NotImplementedError(f'axis_cnt={axis_cnt!r}: row centring (1, -1) and scalar centring (None) have a '
+                                  'device implementation; no CPU fallback for the rest.')
 
     def _feature_scale(self, scale_type, cnt, mu, var, m):
         """Per-feature scaling factor (:114-161) from the merged block statistics: cnt rows, block mean mu,
@@ -862,7 +875,7 @@ class ROM(ShardedOps):
     def scale_data(self, scale_type='std', axis_cnt=1):
         """Reference :83-171.  Sets X_cnt / X_scl and returns the scaled matrix X0."""
         self._flush_deferred()
-        self._check_scaling(scale_type, axis_cnt)
+        axis_cnt = self._check_scaling(scale_type, axis_cnt)
         self._stats_pass(scale_type, axis_cnt)
         return self.X0
 
@@ -903,10 +916,16 @@ class ROM(ShardedOps):
         t = eng.torch
         return (eng.to_device(indptr, dtype=t.int64), eng.to_device(indices, dtype=t.int64), eng.to_device(vals))
 
-    def _sampled(self, sampling):
+    def _sampled(self, sampling, matmul=False):
         """S.Ur, S.X_cnt, S.X_scl for a sampling matrix S (s, n) -- reference :233, :366."""
         if sampling.shape[1] != self._n_global:
-            raise ValueError('The number of columns of sampling does not match the number of rows of X.')
+            # NumPy's own text, as the reference's first product with S raises it: sampling.dot(X_cnt) in reconstruct (:366-368),
+            # sampling @ X_cnt in unscale_data (:233)
+            n, c = self._n_global, sampling.shape[1]
+            if matmul:
+                raise ValueError('matmul: Input operand 1 has a mismatch in its core dimension 0, with gufunc signature '
+                                 f'(n?,k),(k,m?)->(n?,m?) (size {n} is different from {c})')
+            raise ValueError(f'shapes {tuple(sampling.shape)} and {(n, 1)} not aligned: {c} (dim 1) != {n} (dim 0)')
         eng = self._engine()
         ip, ix, v = self._csr_device(sampling)
         Th, cnt, scl = eng.measure_csr(ip, ix, v, self._fitted('Ur', 'Ur'), self._row0, self._fitted('rowmean', 'X_cnt'),
@@ -922,7 +941,7 @@ class ROM(ShardedOps):
             raise NotImplementedError('unscale_data of a cvxpy expression is outside the device path.')
         eng = self._engine()
         if sampling is not None:
-            _, cnt, scl = self._sampled(sampling)
+            _, cnt, scl = self._sampled(sampling, matmul=True)
             ones = eng.to_device(np.ones(1))
             t = eng.unscale(eng.to_device(x0), 0, x0.shape[0], 1, cnt, ones, rowscale=scl)
         else:
@@ -1222,7 +1241,7 @@ class ROM(ShardedOps):
     # ------------------------------------------------------------------ a5 fit
     def fit(self, scale_type='std', axis_cnt=1, select_modes='variance', n_modes=99, basis=None):
         """Reference :463-511."""
-        self._check_scaling(scale_type, axis_cnt)
+        axis_cnt = self._check_scaling(scale_type, axis_cnt)
         if basis is None and select_modes not in ('variance', 'number'):
             raise ValueError('The select_mode value is wrong.')
         eng = self._engine()

@@ -159,8 +159,20 @@ def test_unsupported_options_raise_not_fallback(small):
         sq.fit(scale_type='vast_2')
     with pytest.raises(NotImplementedError):
         spr.fit(scale_type='bogus')                    # :164
+    # axis_cnt goes to np.average(x, axis=axis_cnt) whose result is assigned to n_points rows (:112) -- checked against the
+    # imported reference: 0 / -2 -> ValueError (broadcast), 2 / 7 / -3 -> AxisError, -1 = 1 (round 6)
+    for ax in (0, -2):
+        with pytest.raises(ValueError, match=r'could not broadcast input array from shape \(5,\) into shape \(10,\)'):
+            spr.fit(axis_cnt=ax)
+    for ax in (2, 7, -3):
+        with pytest.raises(np.exceptions.AxisError, match=f'axis {ax} is out of bounds for array of dimension 2'):
+            spr.fit(axis_cnt=ax)
+    spr.fit(axis_cnt=-1, n_modes=100)
+    xc = spr.X_cnt.copy()
+    spr.fit(axis_cnt=1, n_modes=100)
+    np.testing.assert_array_equal(xc, spr.X_cnt)
     with pytest.raises(NotImplementedError):
-        spr.fit(axis_cnt=0)
+        sq.fit(axis_cnt=0)                             # m == n_points: defined in the reference (column means), not here
     spr.fit(n_modes=100)
     Cg = spr.optimal_placement(calc_type='gem', n_sensors=spr.r + 2)  # > r-1: deterministic ridge stand-in for the noise
     assert Cg.shape == (spr.r + 2, 20) and len(set(spr.sensors_.tolist())) == spr.r + 2
@@ -170,8 +182,10 @@ def test_unsupported_options_raise_not_fallback(small):
         spr.optimal_placement(calc_type='bogus')       # :752-754
     with pytest.raises(NotImplementedError):
         spr.train(np.eye(20), method='COLS')
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match=r'shapes \(19, 19\) and \(20, 1\) not aligned: 19 \(dim 1\) != 20 \(dim 0\)'):   # NumPy's text (:366)
         spr.reconstruct(np.zeros(5), sampling=np.eye(19))
+    with pytest.raises(ValueError, match=r'matmul: Input operand 1 has a mismatch in its core dimension 0.*size 20 is different from 19'):
+        spr.unscale_data(np.zeros(19), sampling=np.eye(19))                                                               # (:233)
 
 
 @pytest.mark.parametrize('n_points,F,m,seed', [(7, 2, 3, 0), (10, 3, 4, 1), (33, 1, 5, 2), (64, 4, 1, 3)])

@@ -267,6 +267,16 @@ class HipEngine:
             live = self._pinned_live = []
         live[:] = [(w, b) for w, b in live if w() is not None]
         if nbytes + sum(b for _, b in live) > budget:
+            if budget > 0 and not self.__dict__.get('_pinned_warned'):
+                # said once: from here on results come back as ordinary (pageable) arrays, at a fifth of the rate -- the caller is
+                # holding on to more page-locked results than SPR_PINNED_RESULT_GB allows (pinning host RAM is a
+                # machine-wide resource a library must not take without bound, nor give up silently)
+                import warnings
+                self._pinned_warned = True
+                warnings.warn(f'openmeasure_amd: {sum(b for _, b in live) / 2 ** 30:.1f} GiB of page-locked results are still '
+                              f'referenced; a further {nbytes / 2 ** 30:.1f} GiB would exceed SPR_PINNED_RESULT_GB = '
+                              f'{budget / 2 ** 30:.0f}: this and later results are pageable copies (slower) until earlier ones are '
+                              'released', RuntimeWarning, stacklevel=4)
             return None
         try:
             return torch.empty(shape, dtype=dtype, pin_memory=True)

@@ -1375,6 +1375,9 @@ class ROM(ShardedOps):
         if self._defers() and not to_host and not wait:
             # defer_reconstruct: record the launch instead (the captured tensors stay alive with it)
             n_loc, n_p = Ur_d.shape[0], A_d.shape[0]
+            if hasattr(Ar, 'is_cuda'):
+                A_d = A_d.clone()                             # the caller's own tensor: what it holds NOW (n_p x r doubles), whatever
+                                                              # the caller writes into it before the launch
             total = int(self._shard_layout(n_loc)[:, 1].sum()) if self._dist() else n_loc
             pf = self._deferred = PendingField(None, launch=lambda: self._reconstruct_now(A_d, state, False, False),
                                                shape=(n_p, total), needs_cus=False)

@@ -457,4 +457,10 @@ def run_deferred_reconstruct(eng):
     pf4 = spr.reconstruct(spr.Ar[:1], to_host=False, wait=False)
     assert not pf4.launched
     np.testing.assert_array_equal(_np(pf4.wait()).T, want5)
+    # a DEVICE tensor of coefficients is captured by value: what the caller writes into it after the call does not reach the launch
+    a_dev = eng.to_device(spr.Ar[:1].copy())
+    pf5 = spr.reconstruct(a_dev, to_host=False, wait=False)
+    a_dev.mul_(3.0)
+    assert not pf5.launched
+    np.testing.assert_array_equal(_np(pf5.wait()).T, want5)
     assert isinstance(spr.reconstruct(spr.Ar[:1], to_host=False, wait=True), type(pf4.wait()))

@@ -1767,7 +1767,15 @@ def test_pinned_result_budget(eng, monkeypatch):
     eng.__dict__.pop('_pinned_budget', None)                                  # (the variable is read once per engine)
     a = eng.to_host(t)
     assert len([1 for w, _ in eng._pinned_live if w() is not None]) >= 1
-    b = eng.to_host(t)                                                        # 160 MB alive > 0.1 GiB: pageable
+    eng.__dict__.pop('_pinned_warned', None)
+    with pytest.warns(RuntimeWarning, match='page-locked results are still referenced'):      # said once, not silently (round 6)
+        b = eng.to_host(t)                                                    # 160 MB alive > 0.1 GiB: pageable
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        b2 = eng.to_host(t)                                                   # ... and only once per engine
+    np.testing.assert_array_equal(b, b2)
+    del b2
     n_live = len([1 for w, _ in eng._pinned_live if w() is not None])
     np.testing.assert_array_equal(a, b)
     del a

@@ -623,6 +623,9 @@ def run_rank(args):
         # the first exchange through the mapped buffers was compared block by block with what the peers sent (ROM._p2p_first_exchange)
         comm['p2p_first_exchange'] = px.verified
         comm['p2p_memory'] = px.memory                      # 'coarse' (plain device memory) unless the self-test asked for 'uncached'
+    if dist_on:
+        # the library's own first-exchange trial of the two paths (ROM._gather_trial): what RowShard(gather='auto') decided from
+        comm['gather_trial'] = getattr(spr, 'gather_trial_', None)
     # never print a number for a run that computed garbage: spectrum, basis sample and field must be finite
     fld = field if torch.is_tensor(field) else None
     if not (np.all(np.isfinite(spr.S_[:s])) and bool(torch.isfinite(spr._d['Ur'][:4096].double()).all())

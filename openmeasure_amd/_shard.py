@@ -453,19 +453,23 @@ class ShardedOps:
         if all_ok:
             px.verified = dict(blocks=int(lay.shape[0]), bytes_per_block=int(n_p * n_loc * 8), check='per-block int64 sums')
             if want == 'auto' and os.environ.get('SPR_GATHER_TRIAL', '1') != '0' and 'gather_trial_' not in self.__dict__:
-                if self._gather_trial(A_d, state) == 'rccl':
+                verdict = self._gather_trial(A_d, state)
+                if verdict == 'rccl':
                     return self._reconstruct_now(A_d, state, to_host, wait)
-                return self._reconstruct_p2p(A_d, state, lay, to_host, wait)        # (the trial's gathers reused the buffer)
-            if to_host:
+                if verdict == 'p2p':
+                    return self._reconstruct_p2p(A_d, state, lay, to_host, wait)    # (the trial's gathers reused the buffer)
+                all_ok, why = False, verdict                  # the trial's p2p legs failed on some rank: as for a failed first exchange
+            elif to_host:
                 return eng.to_host(out, result=True).T
-            return out if wait else PendingField(out)
+            else:
+                return out if wait else PendingField(out)
         px.abandon()
         self._p2p_dropped = self.__dict__.pop('_p2p')          # stays allocated: peers have it mapped; never used again
         if want == 'p2p':
             self.__dict__.pop('_gather_sel', None)
             raise RuntimeError(f"RowShard(gather='p2p'): the first full-size exchange failed -- {why}")
         self._gather_sel = 'rccl'
-        self.gather_path_ = f'rccl (p2p failed its first full-size exchange: {why})'
+        self.gather_path_ = f'rccl (p2p failed its first full-size exchange: {why})' if not str(why).startswith('failed: ') else f'rccl (p2p {why})'
         if rank == 0:
             print(f'[openmeasure_amd] field exchange falls back to the RCCL all-gather: {why}', file=sys.stderr)
         return self._reconstruct_now(A_d, state, to_host, wait)
@@ -523,14 +527,37 @@ class ShardedOps:
                 return 'p2p'
         saved = self.comm_timing
         self.comm_timing = None                               # the trial's brackets are not the caller's
+        px = self._p2p
+        keep = px.JOIN_TIMEOUT_S
+        px.JOIN_TIMEOUT_S = min(keep, px.FIRST_TIMEOUT_S)     # like the first exchange: nobody waits ten minutes inside a trial
+        ok, why = True, ''
+        best = {'p2p': np.inf, 'rccl': np.inf}
         try:
             once('rccl')                                      # the communicator's first all-gather of this size: not timed
-            best = {'p2p': np.inf, 'rccl': np.inf}
             for _ in range(self._GATHER_TRIAL_REPS):
                 for path in ('p2p', 'rccl'):
-                    best[path] = min(best[path], once(path))
+                    if path == 'p2p':
+                        if not ok:                            # this rank's p2p leg has failed: it still meets the others ...
+                            sync_all()
+                            continue
+                        try:
+                            best[path] = min(best[path], once(path))
+                        except Exception as exc:              # noqa: BLE001 -- ... and the verdict is agreed on below
+                            ok, why = False, f'rank {self._shard.rank}: {exc}'
+                    else:
+                        best[path] = min(best[path], once(path))
+            if ok:
+                try:
+                    px.check()                                # a join of the trial that gave up / read a poisoned counter
+                except RuntimeError as exc:
+                    ok, why = False, str(exc)
         finally:
             self.comm_timing = saved
+            px.JOIN_TIMEOUT_S = keep
+        all_ok, why = px._agree(ok, why, 'the p2p legs of the first-exchange trial failed')
+        if not all_ok:
+            self.gather_trial_ = dict(chosen='rccl', failed=why)
+            return 'failed: ' + why
         mine = eng.to_device(np.array([best['p2p'], best['rccl']]))
         worst = eng.to_host(self._all_gather(mine)).max(axis=0)
         t_p2p, t_rccl = float(worst[0]), float(worst[1])

@@ -331,7 +331,7 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
         from tests.conftest import load_golden
         eng = HipEngine('cuda:0')
         res = {}
-        if case != 'first_deferred':
+        if case not in ('first_deferred', 'trial_failure'):
             # these cases are about the p2p exchange itself: without the first-exchange trial 'auto' keeps p2p whenever it is
             # available (several processes on ONE GPU are time-sliced, so the trial's verdict here says nothing about a node)
             os.environ['SPR_GATHER_TRIAL'] = '0'
@@ -528,6 +528,38 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
                        sigma_same=bool(np.array_equal(spr.Sigma_r, ref.Sigma_r)), Ur_same=bool(np.array_equal(spr.Ur, ref.Ur)),
                        X3=got, again=bool(np.array_equal(spr.reconstruct(A3), want)))
             spr.close()
+        elif case == 'trial_failure':
+            # the p2p legs of the library's first-exchange trial fail on ONE rank (its pushes stop after the verified first exchange):
+            # every rank keeps meeting the others, the verdict is agreed on, all drop to the collective path with the reason -- and
+            # the field this very call returns is that path's
+            g = load_golden('g3_num8')
+            X = g['X']
+            n = X.shape[0]
+            n_loc = n // world
+            row0 = rank * n_loc
+            real_push = P2PFieldGather.push
+            P2PFieldGather.FIRST_TIMEOUT_S = 1.0
+            calls = []
+
+            def flaky_push(self, first, n_rows):
+                calls.append(1)
+                if len(calls) == 1:
+                    return real_push(self, first, n_rows)           # the first exchange: verified
+                k = self.k                                          # afterwards: this rank never pushes again
+                self.k += 1
+                return k
+            try:
+                if rank == world - 1:
+                    P2PFieldGather.push = flaky_push
+                spr = SPR(np.ascontiguousarray(X[row0:row0 + n_loc]), g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+                spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+                sgn = np.sign(np.sum(spr.Ar * g['Ar'], axis=0))
+                X3 = spr.reconstruct(g['Ar_pred3'] * sgn)
+                X3b = spr.reconstruct(g['Ar_pred3'] * sgn)
+                res = dict(path=str(spr.gather_path_), X3=X3, same=bool(np.array_equal(X3, X3b)), dropped='_p2p' not in spr.__dict__,
+                           trial=str(spr.gather_trial_))
+            finally:
+                P2PFieldGather.push = real_push
         elif case == 'stalled_release':
             # round 6: a rank that is SLOW, not dead -- it sits between two gathers (still reading the field
             # it was handed) for longer than the pusher's release timeout.  The pusher's copy cannot be taken back, so the arrival
@@ -606,7 +638,7 @@ def _p2p_edge_worker(rank, world, port, out_dir, case):
 
 
 @pytest.mark.parametrize('case', ['fallback', 'no_peer_access', 'uncached', 'knob:SPR_P2P_BUFFERS=2', 'knob:SPR_P2P_STREAMS=1',
-                                  'knob:SPR_P2P_BLIT=1', 'timeout', 'first_mismatch', 'first_timeout', 'stalled_release', 'first_deferred'])
+                                  'knob:SPR_P2P_BLIT=1', 'timeout', 'first_mismatch', 'first_timeout', 'stalled_release', 'first_deferred', 'trial_failure'])
 def test_p2p_exchange_edges(tmp_path, case):
     """round 5: the p2p field exchange when it cannot be had (one rank cannot map its peers -> every rank on the collective path,
     or every rank raising when p2p was demanded), when a peer never pushes (the join kernel's wall-clock exit + check()), and
@@ -653,6 +685,13 @@ def test_p2p_exchange_edges(tmp_path, case):
             assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO and bool(o['same']) and bool(o['dropped'])
             assert str(o['forced']).startswith("RuntimeError: RowShard(gather='p2p'): the first full-size exchange failed"), o['forced']
             assert str(o['path3']).startswith('p2p') and 'per-block int64 sums' in str(o['verified']) and bool(o['same3'])
+    elif case == 'trial_failure':
+        from tests.conftest import load_golden
+        from tests.parity import REL_FRO, rel_fro
+        g = load_golden('g3_num8')
+        for o in outs:
+            assert str(o['path']).startswith('rccl (p2p failed: ') and 'failed' in str(o['trial']), (o['path'], o['trial'])
+            assert rel_fro(o['X3'], g['X_rec3']) <= REL_FRO and bool(o['same']) and bool(o['dropped'])
     elif case == 'first_deferred':
         from tests.conftest import load_golden
         from tests.parity import REL_FRO, rel_fro

@@ -495,9 +495,15 @@ class ShardedOps:
         Xd = self._Xd()
         can_fill = hasattr(eng, 'gram_filler')
 
+        on_gpu = hasattr(eng, 'device') and eng.device.type == 'cuda'     # (the NumPy test double runs this on the CPU)
+
+        def device_sync():
+            if on_gpu:
+                torch.cuda.synchronize(eng.device)
+
         def sync_all():
             self._all_gather(eng.zeros((1,)))                 # the ranks meet: every repetition starts together
-            torch.cuda.synchronize(eng.device)
+            device_sync()
 
         def once(path):
             sync_all()
@@ -507,13 +513,13 @@ class ShardedOps:
                 eng.gram_filler(Xd, Xd.shape[0], self._row0, self.n_points, self.n_features)
             if isinstance(pf, PendingField):
                 pf.wait()
-            torch.cuda.synchronize(eng.device)
+            device_sync()
             return time.perf_counter() - t0
 
         # HBM first: the all-gather leg stages the gathered field (world blocks) next to the block itself and RCCL allocates
         # buffers of its own at its first call of this size; a shard that fills the GPU (config 5 at N = 8: 9 GB left) must not
         # find out by running out of memory in one rank.  Decided together from the tightest rank.
-        if hasattr(eng, 'device') and eng.device.type == 'cuda':
+        if on_gpu:
             lay = self._shard_layout(state[0].shape[0])
             need = (lay.shape[0] + 1) * int(lay[:, 1].max()) * A_d.shape[0] * 8 + (2 << 30)
             free = (torch.cuda.mem_get_info(eng.device)[0] + torch.cuda.memory_reserved(eng.device)

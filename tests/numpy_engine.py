@@ -457,3 +457,93 @@ class CandidateEngine(NumpyEngine):
             visited[:] = True
             self.log.append(('full', j_e, j))
         self._draw(st, visited, tau_floor if pool else -2.0)
+
+
+class ExchangeDoubleEngine(NumpyEngine):
+    """NumpyEngine + a stand-in for the p2p field exchange (openmeasure_amd/p2p.py) -- TEST DOUBLE.  The product's sharded
+    reconstruct drives an exchange object through ensure / begin / push / join / check (+ verified, abandon, close, _agree); the
+    real one moves blocks with SDMA pushes into peer-mapped buffers and needs GPUs.  This one keeps the same interface and
+    moves the blocks with a gloo all-gather at JOIN time, so that the host logic around the exchange -- path selection, the
+    verified first exchange, the first-exchange trial and its agreement across ranks, the fall-back of all ranks together,
+    deferred first launches -- runs on the CPU at any world size.  ``faults``: {'drop_after': k} makes THIS rank's pushes
+    stop after its k-th (its peers then miss its block: every rank's next check() raises, as the join kernels' status words
+    make the real one do)."""
+
+    def __init__(self, faults=None):
+        super().__init__()
+        self.faults = dict(faults or {})
+        self.exchanges = []
+
+    def gram_filler(self, X, rows, row0, n_points, n_features):       # the trial queues a Gram pass behind the exchange
+        self.filler_calls = getattr(self, 'filler_calls', 0) + 1
+
+    def p2p_field_gather(self, world, rank, all_gather):
+        from openmeasure_amd.p2p import P2PFieldGather
+
+        eng = self
+
+        class Exchange(P2PFieldGather):                      # inherits _agree (the ranks' verdicts and reasons, one all-gather)
+            def __init__(self):                              # noqa: D401 -- none of the real set-up (library, streams, pinned words)
+                self.eng, self.world, self.rank = eng, int(world), int(rank)
+                self._all_gather = all_gather
+                self.peers = [q for q in range(self.world) if q != self.rank]
+                self.loopback, self.n_buf, self.k = 0, 1, 0
+                self.base = self.buf = None
+                self.shape, self.verified, self.memory = None, None, 'test double'
+                self.host_ms = dict(begin=0.0, push=0.0, join=0.0, calls=0)
+                self.pushed, self.joined, self.failed = {}, set(), ''
+                self.pushes = 0
+
+            def ensure(self, n_p, n_total):
+                if self.buf is None or self.buf.shape[0] < n_p or self.buf.shape[1] != n_total:
+                    self.buf = torch.zeros((int(n_p), int(n_total)), dtype=torch.float64)
+                    self.base, self.k, self.verified = 1, 0, None
+                self.shape = (int(n_p), int(n_total))
+
+            def begin(self):
+                self.check()
+                return self.buf[:self.shape[0]]
+
+            def push(self, first, n_loc):
+                self.pushes += 1
+                drop = eng.faults.get('drop_after')
+                live = drop is None or self.pushes <= drop
+                self.pushed[self.k] = (int(first), int(n_loc), live)
+                k = self.k
+                self.k += 1
+                self.host_ms['calls'] += 1
+                return k
+
+            def join(self, k):
+                """every rank's block of gather k into every rank's copy: one padded all-gather (collective at join time)"""
+                if k in self.joined:
+                    return
+                self.joined.add(k)
+                first, n_loc, live = self.pushed.pop(k)
+                n_p, n_total = self.shape
+                blk = torch.zeros((n_p, n_total + 3), dtype=torch.float64)
+                blk[:, :n_loc] = self.buf[:n_p, first:first + n_loc]
+                blk[:, n_total:] = torch.tensor([float(first), float(n_loc), 1.0 if live else 0.0], dtype=torch.float64)
+                every = self._all_gather(blk)
+                for q in range(self.world):
+                    f, c, ok = (int(v) for v in every[q, 0, n_total:].tolist())
+                    if not ok:
+                        self.failed = self.failed or (f'rank {self.rank} gave up waiting for counter arrive[{q}] (the block of rank {q})'
+                                                      if q != self.rank else f'my own pushes never left (rank {q})')
+                    elif q != self.rank:
+                        self.buf[:n_p, f:f + c] = every[q, :, :c]
+
+            def check(self):
+                if self.failed:
+                    why, self.failed = self.failed, ''
+                    raise RuntimeError('p2p field exchange (test double): ' + why)
+
+            def abandon(self):
+                self.failed = ''
+
+            def close(self, collective=True, rendezvous=None):
+                self.buf = self.base = None
+
+        ex = Exchange()
+        self.exchanges.append(ex)
+        return ex

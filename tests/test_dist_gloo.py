@@ -530,3 +530,75 @@ def test_sharded_epoch_sweeps_on_the_candidate_model(tmp_path, world, heavy):
         assert int(o['n_calls']) == int(outs[0]['n_calls'])            # the same collectives on every rank
     if heavy:
         assert sum(int(o['pool']) for o in outs) >= 1
+
+
+def _exchange_worker(rank, world, port, fixture, out_dir, uneven, drop_after):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from openmeasure_amd.sparse_sensing import SPR, RowShard
+        from tests.conftest import load_golden
+        from tests.numpy_engine import ExchangeDoubleEngine, NumpyEngine
+        g = load_golden(fixture)
+        X = g['X']
+        n = X.shape[0]
+        cuts = _cuts(n, world, uneven)
+        row0, n_loc = cuts[rank], cuts[rank + 1] - cuts[rank]
+        Xl = np.ascontiguousarray(X[row0:row0 + n_loc])
+        ref = SPR(Xl, g['n_features'], None, shard=RowShard(row0, n), engine=NumpyEngine())       # no exchange object: the all-gather
+        ref.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        A3 = g['Ar_pred3'] * np.sign(np.sum(ref.Ar * g['Ar'], axis=0))
+        want = ref.reconstruct(A3)
+        want1 = ref.reconstruct(A3[:1])                                  # (one vector: BLAS takes another route than for three)
+        eng = ExchangeDoubleEngine(faults=dict(drop_after=drop_after) if (drop_after is not None and rank == world - 1) else None)
+        spr = SPR(Xl, g['n_features'], None, shard=RowShard(row0, n), engine=eng)
+        assert spr.defer_reconstruct
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        pf = spr.reconstruct(A3, to_host=False, wait=False)              # the object's FIRST sharded reconstruct, deferred:
+        assert not pf.launched and '_p2p' not in spr.__dict__             # nothing of the exchange exists yet
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])     # ... set-up, first exchange and trial run inside this fit
+        assert pf.launched
+        got = pf.wait().numpy().T.copy()
+        again = spr.reconstruct(A3)                                      # ... and the path chosen carries the next one
+        one = spr.reconstruct(A3[:1], to_host=False, wait=False)
+        spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
+        one = one.wait().numpy().copy()
+        tr = spr.__dict__.get('gather_trial_', {})
+        np.savez(os.path.join(out_dir, f'ex{rank}.npz'), path=str(spr.gather_path_), ok=bool(np.array_equal(got, want)),
+                 ok2=bool(np.array_equal(again, want)), ok1=bool(np.array_equal(one[0], want1[:, 0])),
+                 trial=np.array([tr.get('p2p_ms', -1.0), tr.get('rccl_ms', -1.0)]), chosen=str(tr.get('chosen')),
+                 failed=str(tr.get('failed', '')), has_px='_p2p' in spr.__dict__, fills=int(getattr(eng, 'filler_calls', 0)),
+                 pushes=int(eng.exchanges[0].pushes) if eng.exchanges else -1,
+                 sigma_same=bool(np.array_equal(spr.Sigma_r, ref.Sigma_r)))
+        spr.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,uneven,drop_after', [(2, False, None), (3, True, None), (8, False, None), (8, True, None),
+                                                     (2, False, 1), (4, True, 1), (8, False, 1), (3, False, 0)])
+def test_field_exchange_logic_on_the_exchange_double(tmp_path, world, uneven, drop_after):
+    """round 6: the host logic AROUND the p2p field exchange at any world size on the CPU (tests/numpy_engine.py,
+    ExchangeDoubleEngine: the exchange object's interface, its blocks moved by gloo at join time) -- 'auto' sets the exchange
+    up inside a DEFERRED first reconstruct, verifies the first exchange block by block, times both paths (the trial) and every
+    rank holds the same two numbers and the same verdict; with a rank whose pushes stop after the first exchange
+    (drop_after = 1) the trial's p2p legs fail and ALL ranks drop to the all-gather with the reason; with a rank that never
+    pushes (0) the first exchange itself fails, same fall-back; the fields equal the all-gather path's bit for bit throughout."""
+    fixture = 'g7_f9_num6' if world == 8 else 'g3_num8'
+    mp.spawn(_exchange_worker, args=(world, _free_port(), fixture, str(tmp_path), uneven, drop_after), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f'ex{r}.npz') for r in range(world)]
+    for o in outs:
+        assert bool(o['ok']) and bool(o['ok2']) and bool(o['ok1']) and bool(o['sigma_same']), (str(o['path']), o['ok'], o['ok2'], o['ok1'])
+        assert str(o['path']) == str(outs[0]['path']) and str(o['chosen']) == str(outs[0]['chosen'])
+        np.testing.assert_array_equal(o['trial'], outs[0]['trial'])
+    o = outs[0]
+    if drop_after is None:
+        assert 'first-exchange trial' in str(o['path']) and str(o['chosen']) in ('p2p', 'rccl') and o['trial'].min() > 0
+        assert str(o['path']).startswith(str(o['chosen'])) and bool(o['has_px']) and int(o['fills']) == 5   # 1 + 2 x 2 trial legs
+    elif drop_after == 1:
+        assert str(o['path']).startswith('rccl (p2p failed: ') and 'arrive' in str(o['failed']) and not bool(o['has_px']), str(o['path'])
+    else:
+        assert str(o['path']).startswith('rccl (p2p failed its first full-size exchange'), str(o['path'])
+        assert not bool(o['has_px'])

@@ -568,7 +568,7 @@ class ROM(ShardedOps):
                 if m not in (1, self.n_points):
                     raise ValueError(f'could not broadcast input array from shape ({m},) into shape ({self.n_points},)')
             else:
-                raise np.exceptions.AxisError(int(axis_cnt), 2)
+                raise np.exceptions.AxisError(int(axis_cnt), 2, 'axis')      # (np.average names its argument: 'axis: axis 2 is out of ...')
         raise NotImplementedError(f'axis_cnt={axis_cnt!r}: row centring (1, -1) and scalar centring (None) have a '
                                   'device implementation; no CPU fallback for the rest.')
 
@@ -925,7 +925,7 @@ class ROM(ShardedOps):
             if matmul:
                 raise ValueError('matmul: Input operand 1 has a mismatch in its core dimension 0, with gufunc signature '
                                  f'(n?,k),(k,m?)->(n?,m?) (size {n} is different from {c})')
-            raise ValueError(f'shapes {tuple(sampling.shape)} and {(n, 1)} not aligned: {c} (dim 1) != {n} (dim 0)')
+            raise ValueError(f'shapes ({sampling.shape[0]},{c}) and ({n},1) not aligned: {c} (dim 1) != {n} (dim 0)')
         eng = self._engine()
         ip, ix, v = self._csr_device(sampling)
         Th, cnt, scl = eng.measure_csr(ip, ix, v, self._fitted('Ur', 'Ur'), self._row0, self._fitted('rowmean', 'X_cnt'),

@@ -182,7 +182,7 @@ def test_unsupported_options_raise_not_fallback(small):
         spr.optimal_placement(calc_type='bogus')       # :752-754
     with pytest.raises(NotImplementedError):
         spr.train(np.eye(20), method='COLS')
-    with pytest.raises(ValueError, match=r'shapes \(19, 19\) and \(20, 1\) not aligned: 19 \(dim 1\) != 20 \(dim 0\)'):   # NumPy's text (:366)
+    with pytest.raises(ValueError, match=r'shapes \(19,19\) and \(20,1\) not aligned: 19 \(dim 1\) != 20 \(dim 0\)'):   # NumPy's text (:366)
         spr.reconstruct(np.zeros(5), sampling=np.eye(19))
     with pytest.raises(ValueError, match=r'matmul: Input operand 1 has a mismatch in its core dimension 0.*size 20 is different from 19'):
         spr.unscale_data(np.zeros(19), sampling=np.eye(19))                                                               # (:233)

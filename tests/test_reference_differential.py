@@ -82,6 +82,44 @@ def test_fit_errors_match_the_reference(sps, kw, exc):
         assert str(e_mine.value) == str(e_ref.value)          # NumPy's broadcast message, shapes included
 
 
+@pytest.mark.parametrize('axis_cnt', [0, 2, -1, -2, 7, -3])
+def test_axis_cnt_values_behave_like_the_reference(sps, axis_cnt):
+    """round 6: axis_cnt goes to np.average(x, axis=axis_cnt) (:112) -- whatever the reference does with a
+    value (row means for -1, NumPy's broadcast ValueError for 0 / -2, its AxisError beyond), type AND text, happens here too."""
+    from openmeasure_amd.sparse_sensing import SPR
+    from tests.numpy_engine import NumpyEngine
+    X = _data(60, 2, 12, 6, 0.7, seed=2)
+    ref, mine = sps.SPR(X.copy(), 2, None), SPR(X.copy(), 2, None, engine=NumpyEngine())
+    try:
+        ref.fit(axis_cnt=axis_cnt, select_modes='number', n_modes=3)
+        err = None
+    except Exception as exc:                                  # noqa: BLE001 -- whatever the reference raises is the specification
+        err = exc
+    if err is None:
+        mine.fit(axis_cnt=axis_cnt, select_modes='number', n_modes=3)
+        np.testing.assert_allclose(mine.X_cnt, ref.X_cnt, rtol=1e-13)
+        np.testing.assert_allclose(mine.Sigma_r, ref.Sigma_r, rtol=1e-9)
+    else:
+        with pytest.raises(type(err)) as e_mine:
+            mine.fit(axis_cnt=axis_cnt, select_modes='number', n_modes=3)
+        assert str(e_mine.value) == str(err)
+
+
+def test_misshaped_sampling_matrix_raises_numpys_text(sps):
+    from openmeasure_amd.sparse_sensing import SPR
+    from tests.numpy_engine import NumpyEngine
+    X = _data(10, 2, 5, 4, 0.7, seed=3)
+    ref, mine = sps.SPR(X.copy(), 2, None), SPR(X.copy(), 2, None, engine=NumpyEngine())
+    for o in (ref, mine):
+        o.fit(select_modes='number', n_modes=3)
+    for call in (lambda o: o.reconstruct(np.zeros(3), sampling=np.eye(19)), lambda o: o.unscale_data(np.zeros(19), sampling=np.eye(19))):
+        with pytest.raises(ValueError) as e_ref:
+            call(ref)
+        with pytest.raises(ValueError) as e_mine:
+            call(mine)
+        assert str(e_mine.value) == str(e_ref.value)
+
+
 def test_every_attribute_of_a_used_reference_object_exists_here(sps):
     """After fit -> optimal_placement -> train(cond=True) -> predict the reference object carries 22 instance attributes
     (X, X0, X_cnt, X_scl, Ur, Ar, Vr, Sigma_r, r, C, Theta, cnt_vector, scl_vector, k, limits, method, solver, verbose, ...):

@@ -127,6 +127,17 @@ def pivot_loop(eng, st, s, all_gather=None, start=0, near=None, pools=False, sta
     return sweeps
 
 
+def _check_mask(mask, n_rows):
+    """The search mask of optimal_placement is used as ``Ur[~mask, :] = 0`` (:737-738) / ``Ur[mask]`` (:621): a boolean vector of
+    another length is NumPy's IndexError (its text); anything that is not a boolean vector has no meaning as a mask here (an integer
+    array would index rows in the reference) and is refused."""
+    if mask.dtype == np.bool_ and mask.ndim == 1 and mask.shape[0] != n_rows:
+        raise IndexError(f'boolean index did not match indexed array along axis 0; size of axis is {n_rows} but size of '
+                         f'corresponding boolean axis is {mask.shape[0]}')
+    if mask.dtype != np.bool_ or mask.shape != (n_rows,):
+        raise IndexError('mask must be a boolean array with one entry per (local) row')
+
+
 class GemPlacement:
     """calc_type='gem' of SPR.optimal_placement and the public SPR.gem (mixed into rom.SPR)."""
 
@@ -231,15 +242,24 @@ class GemPlacement:
         Ur_d = self._fitted('Ur', 'Ur')
         r = self.r
         self._check_rank_cap("optimal_placement('gem')")
-        if type(n_sensors) is not int or n_sensors < 1:
-            raise ValueError('n_sensors must be a positive integer.')
+        # the reference loops `for s in range(n_sensors)` (:637): a non-integer is range()'s TypeError, zero or a negative count an
+        # empty placement -- C of shape (0, n) (:748-749)
+        if not isinstance(n_sensors, (int, np.integer)):
+            raise TypeError(f"'{type(n_sensors).__name__}' object cannot be interpreted as an integer")
+        n_sensors = int(n_sensors)
+        if n_sensors < 1:
+            self.sensors_ = np.zeros(0, dtype=np.int64)
+            self.pivot_gap_ = np.zeros(0)
+            self.pivot_sweeps_ = 0
+            C = np.zeros((0, self._n_global))
+            self._placed = (C, self.sensors_)
+            return C
         if r < 3:
             raise NotImplementedError('gem needs at least three modes (row variances over r entries, r-1 >= 2 picks).')
         mask_d = None
         if mask is not None:
             mask = np.asarray(mask)
-            if mask.dtype != np.bool_ or mask.shape != (Ur_d.shape[0],):
-                raise IndexError('mask must be a boolean array with one entry per (local) row')
+            _check_mask(mask, Ur_d.shape[0])
             mask_d = eng.to_device(mask.astype(np.uint8), dtype=eng.torch.uint8)
         near = None
         if d_min > 0:

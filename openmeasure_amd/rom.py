@@ -8,7 +8,7 @@ import numpy as np
 
 from . import _eigen
 from ._lib import SPR_MAX_R_WIDE
-from ._placement import GemPlacement, pivot_loop
+from ._placement import GemPlacement, _check_mask, pivot_loop
 from ._shard import PendingField, RowShard, ShardedOps
 
 __all__ = ['ROM', 'SPR', 'RowShard', 'DeviceMatrix', 'PendingField', 'OneHotRows']
@@ -440,9 +440,12 @@ class ROM(ShardedOps):
                 self._d['X'] = self.X.tensor
             else:
                 if self.X.ndim < 2:
-                    raise IndexError('tuple index out of range')    # what the reference's X.shape[1] raises for a 1-D X
+                    # the reference's first touch of X's columns is x = X[i n_points:(i+1) n_points, :] (:110): NumPy's text
+                    raise IndexError(f'too many indices for array: array is {self.X.ndim}-dimensional, but 2 were indexed')
                 if self.X.ndim != 2:
-                    raise ValueError('X must be a 2-D array.')
+                    # ... and for more dimensions np.average(x, axis=1) no longer fits the n_points rows it is assigned to (:112)
+                    shp = ','.join(str(d) for d in (self.n_points,) + tuple(self.X.shape[2:]))
+                    raise ValueError(f'could not broadcast input array from shape ({shp}) into shape ({self.n_points},)')
                 # a float32 snapshot matrix stays float32 in HBM (storage only, see DeviceMatrix)
                 self._d['X'] = eng.to_device(self.X, dtype=eng.torch.float32 if self.X.dtype == np.float32 else None)
         return self._d['X']
@@ -946,7 +949,7 @@ class ROM(ShardedOps):
             t = eng.unscale(eng.to_device(x0), 0, x0.shape[0], 1, cnt, ones, rowscale=scl)
         else:
             t = eng.unscale(eng.to_device(x0), self._row0, self.n_points, self.n_features,
-                            self._fitted('rowmean', 'X_cnt'), self._d['scale'])
+                            self._fitted('rowmean', 'X_scl'), self._d['scale'])        # (:235 reads X_scl first)
         return eng.to_host(t)
 
     # ------------------------------------------------------------------ a4 reduction
@@ -1504,8 +1507,7 @@ class SPR(GemPlacement, ROM):
         self._check_rank_cap('optimal_placement')
         if mask is not None:
             mask = np.asarray(mask)
-            if mask.dtype != np.bool_ or mask.shape != (Ur_d.shape[0],):
-                raise IndexError('mask must be a boolean array with one entry per (local) row')
+            _check_mask(mask, Ur_d.shape[0])
             eng.mask_rows(Ur_d, eng.to_device(mask.astype(np.uint8), dtype=eng.torch.uint8))   # :737-738
             self._host.pop('Ur', None)
             self._d.pop('nrm0', None)                         # rows were zeroed: the norms fit() left no longer hold

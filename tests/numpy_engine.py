@@ -474,6 +474,9 @@ class ExchangeDoubleEngine(NumpyEngine):
         self.faults = dict(faults or {})
         self.exchanges = []
 
+    def to_host(self, t, then=None, result=False):                    # a HOST COPY like the real engine's (the exchange buffer is
+        return np.array(super().to_host(t, then=then, result=result))  # persistent: a view of it would change under the caller)
+
     def gram_filler(self, X, rows, row0, n_points, n_features):       # the trial queues a Gram pass behind the exchange
         self.filler_calls = getattr(self, 'filler_calls', 0) + 1
 

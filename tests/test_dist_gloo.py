@@ -532,7 +532,7 @@ def test_sharded_epoch_sweeps_on_the_candidate_model(tmp_path, world, heavy):
         assert sum(int(o['pool']) for o in outs) >= 1
 
 
-def _exchange_worker(rank, world, port, fixture, out_dir, uneven, drop_after):
+def _exchange_worker(rank, world, port, fixture, out_dir, uneven, drop_after, force=None):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -555,6 +555,8 @@ def _exchange_worker(rank, world, port, fixture, out_dir, uneven, drop_after):
         eng = ExchangeDoubleEngine(faults=dict(drop_after=drop_after) if (drop_after is not None and rank == world - 1) else None)
         spr = SPR(Xl, g['n_features'], None, shard=RowShard(row0, n), engine=eng)
         assert spr.defer_reconstruct
+        if force is not None:                                             # the trial's verdict, whatever the clocks say: both branches
+            spr._GATHER_TRIAL_MARGIN = 0.0 if force == 'p2p' else 1e9
         spr.fit(select_modes=g['select_modes'], n_modes=g['n_modes'])
         pf = spr.reconstruct(A3, to_host=False, wait=False)              # the object's FIRST sharded reconstruct, deferred:
         assert not pf.launched and '_p2p' not in spr.__dict__             # nothing of the exchange exists yet
@@ -577,9 +579,10 @@ def _exchange_worker(rank, world, port, fixture, out_dir, uneven, drop_after):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,uneven,drop_after', [(2, False, None), (3, True, None), (8, False, None), (8, True, None),
-                                                     (2, False, 1), (4, True, 1), (8, False, 1), (3, False, 0)])
-def test_field_exchange_logic_on_the_exchange_double(tmp_path, world, uneven, drop_after):
+@pytest.mark.parametrize('world,uneven,drop_after,force', [(2, False, None, None), (3, True, None, 'p2p'), (8, False, None, 'rccl'),
+                                                           (8, True, None, 'p2p'), (4, False, None, 'rccl'), (2, False, 1, None),
+                                                           (4, True, 1, None), (8, False, 1, None), (3, False, 0, None)])
+def test_field_exchange_logic_on_the_exchange_double(tmp_path, world, uneven, drop_after, force):
     """round 6: the host logic AROUND the p2p field exchange at any world size on the CPU (tests/numpy_engine.py,
     ExchangeDoubleEngine: the exchange object's interface, its blocks moved by gloo at join time) -- 'auto' sets the exchange
     up inside a DEFERRED first reconstruct, verifies the first exchange block by block, times both paths (the trial) and every
@@ -587,7 +590,7 @@ def test_field_exchange_logic_on_the_exchange_double(tmp_path, world, uneven, dr
     (drop_after = 1) the trial's p2p legs fail and ALL ranks drop to the all-gather with the reason; with a rank that never
     pushes (0) the first exchange itself fails, same fall-back; the fields equal the all-gather path's bit for bit throughout."""
     fixture = 'g7_f9_num6' if world == 8 else 'g3_num8'
-    mp.spawn(_exchange_worker, args=(world, _free_port(), fixture, str(tmp_path), uneven, drop_after), nprocs=world, join=True)
+    mp.spawn(_exchange_worker, args=(world, _free_port(), fixture, str(tmp_path), uneven, drop_after, force), nprocs=world, join=True)
     outs = [np.load(tmp_path / f'ex{r}.npz') for r in range(world)]
     for o in outs:
         assert bool(o['ok']) and bool(o['ok2']) and bool(o['ok1']) and bool(o['sigma_same']), (str(o['path']), o['ok'], o['ok2'], o['ok1'])
@@ -597,6 +600,7 @@ def test_field_exchange_logic_on_the_exchange_double(tmp_path, world, uneven, dr
     if drop_after is None:
         assert 'first-exchange trial' in str(o['path']) and str(o['chosen']) in ('p2p', 'rccl') and o['trial'].min() > 0
         assert str(o['path']).startswith(str(o['chosen'])) and bool(o['has_px']) and int(o['fills']) == 5   # 1 + 2 x 2 trial legs
+        assert force is None or str(o['chosen']) == force
     elif drop_after == 1:
         assert str(o['path']).startswith('rccl (p2p failed: ') and 'arrive' in str(o['failed']) and not bool(o['has_px']), str(o['path'])
     else:

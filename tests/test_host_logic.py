@@ -176,8 +176,10 @@ def test_unsupported_options_raise_not_fallback(small):
     spr.fit(n_modes=100)
     Cg = spr.optimal_placement(calc_type='gem', n_sensors=spr.r + 2)  # > r-1: deterministic ridge stand-in for the noise
     assert Cg.shape == (spr.r + 2, 20) and len(set(spr.sensors_.tolist())) == spr.r + 2
-    with pytest.raises(ValueError):
-        spr.optimal_placement(calc_type='gem', n_sensors=0)
+    C0 = spr.optimal_placement(calc_type='gem', n_sensors=0)                 # the reference loops range(n_sensors): an empty placement
+    assert C0.shape == (0, 20) and spr.sensors_.shape == (0,)
+    with pytest.raises(TypeError, match="'float' object cannot be interpreted as an integer"):
+        spr.optimal_placement(calc_type='gem', n_sensors=2.0)
     with pytest.raises(NotImplementedError):
         spr.optimal_placement(calc_type='bogus')       # :752-754
     with pytest.raises(NotImplementedError):

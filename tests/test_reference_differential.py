@@ -177,3 +177,120 @@ def test_every_public_method_of_the_reference_exists_with_its_signature(sps):
         o.CPOD({})
     with pytest.raises(NotImplementedError):
         o.adaptive_sampling(np.zeros((2, 1)))
+
+
+def _differential_cases(sps):
+    """-> {name: (outcome with the reference, outcome here)}; an outcome is ('ok', repr of the value) or (exception type name, text)"""
+    from openmeasure_amd.sparse_sensing import ROM, SPR
+    from tests.numpy_engine import NumpyEngine
+    rng=np.random.default_rng(0)
+    def data(n_points=30,F=2,m=8):
+        X=rng.standard_normal((n_points*F,4))@rng.standard_normal((4,m))+0.01*rng.standard_normal((n_points*F,m))
+        X[n_points:]+=5
+        return X
+    def run(make, steps):
+        out=[]
+        for which in ('ref','mine'):
+            try:
+                o=make(which)
+                res=None
+                for st in steps:
+                    res=st(o)
+                out.append(('ok', res))
+            except Exception as e:
+                out.append((type(e).__name__, str(e)[:160]))
+        return out
+    X=data(); xyz=rng.random((30,3))
+    def mk(which, X=X, F=2, xyz=xyz):
+        return sps.SPR(X.copy(),F,xyz) if which=='ref' else SPR(X.copy(),F,xyz,engine=NumpyEngine())
+    def mkrom(which, X=X, F=2, xyz=xyz):
+        return sps.ROM(X.copy(),F,xyz) if which=='ref' else ROM(X.copy(),F,xyz,engine=NumpyEngine())
+    cases={}
+    cases['ctor list']=run(lambda w:(sps.SPR if w=='ref' else (lambda *a:SPR(*a,engine=NumpyEngine())))([[1,2],[3,4]],2,None),[])
+    cases['ctor F float']=run(lambda w:(sps.SPR if w=='ref' else (lambda *a:SPR(*a,engine=NumpyEngine())))(X,2.0,None),[])
+    cases['ctor F bool']=run(lambda w:(sps.SPR if w=='ref' else (lambda *a:SPR(*a,engine=NumpyEngine())))(X,True,None),[])
+    cases['ctor not multiple']=run(lambda w:(sps.SPR if w=='ref' else (lambda *a:SPR(*a,engine=NumpyEngine())))(X[:59],2,None),[])
+    cases['ctor 1-D X']=run(lambda w:(sps.SPR if w=='ref' else (lambda *a:SPR(*a,engine=NumpyEngine())))(X[:,0].copy(),2,None),[lambda o:o.fit()])
+    cases['ctor 3-D X']=run(lambda w:(sps.SPR if w=='ref' else (lambda *a:SPR(*a,engine=NumpyEngine())))(np.zeros((4,2,2)),2,None),[lambda o:o.fit()])
+    cases['ctor F=0']=run(lambda w:(sps.SPR if w=='ref' else (lambda *a:SPR(*a,engine=NumpyEngine())))(X,0,None),[])
+    for nm in (True, 1, 8, 9, 0, -1, 3.0, '3', None):
+        cases[f'fit number {nm!r}']=run(mk,[lambda o,nm=nm:(o.fit(select_modes='number',n_modes=nm), o.r)[1]])
+    for nm in (0, 100, 99.999, -1, 100.5, 50, '50', None, True):
+        cases[f'fit variance {nm!r}']=run(mk,[lambda o,nm=nm:(o.fit(select_modes='variance',n_modes=nm), o.r)[1]])
+    cases['fit select None']=run(mk,[lambda o:o.fit(select_modes=None)])
+    cases['fit basis tuple']=run(mk,[lambda o:(o.fit(basis=(np.eye(60,3),np.eye(8,3))), o.r, o.Sigma_r.tolist())[1:]])
+    cases['fit basis bad']=run(mk,[lambda o:o.fit(basis=(np.eye(60,3),))])
+    cases['fit basis mismatched r']=run(mk,[lambda o:(o.fit(basis=(np.eye(60,3),np.eye(8,4))), o.r)[1]])
+    fit=lambda o:o.fit(select_modes='number',n_modes=3)
+    cases['placement bogus']=run(mk,[fit,lambda o:o.optimal_placement(calc_type='bogus')])
+    cases['placement before fit']=run(mk,[lambda o:o.optimal_placement()])
+    cases['placement mask wrong len']=run(mk,[fit,lambda o:o.optimal_placement(mask=np.ones(10,bool)).shape])
+    cases['placement mask int']=run(mk,[fit,lambda o:np.argmax(np.asarray(o.optimal_placement(mask=np.ones(60,int))),axis=1).tolist()])
+    cases['placement mask all false']=run(mk,[fit,lambda o:np.asarray(o.optimal_placement(mask=np.zeros(60,bool))).shape])
+    cases['placement n_sensors ignored']=run(mk,[fit,lambda o:np.asarray(o.optimal_placement(n_sensors=1)).shape])
+    cases['train wrong cols']=run(mk,[fit,lambda o:o.train(np.eye(3,59))])
+    cases['train before fit']=run(mk,[lambda o:o.train(np.eye(3,60))])
+    cases['train theta wrong cols']=run(mk,[fit,lambda o:o.train(np.eye(3,4),is_Theta=True)])
+    cases['train theta ok']=run(mk,[fit,lambda o:(o.train(np.eye(5,3),is_Theta=True), o.Theta.shape)[1]])
+    cases['train method bogus']=run(mk,[fit,lambda o:(o.train(np.eye(3,60),method='bogus'), o.method)[1]])
+    cases['train 1-D C']=run(mk,[fit,lambda o:o.train(np.ones(60))])
+    cases['train list C']=run(mk,[fit,lambda o:o.train(np.eye(3,60).tolist())])
+    def placed(o):
+        o.fit(select_modes='number',n_modes=3); C=o.optimal_placement(); o.train(C); return C
+    def yvec(o,rows=3,cols=3):
+        y=np.zeros((rows,cols)); y[:,0]=1.0; return y
+    cases['predict wrong rows']=run(mk,[placed,lambda o:o.predict(yvec(o,4))])
+    cases['predict wrong cols']=run(mk,[placed,lambda o:o.predict(yvec(o,3,2))])
+    cases['predict list empty']=run(mk,[placed,lambda o:[a.shape for a in o.predict([])]])
+    cases['predict method bogus']=run(mk,[lambda o:(o.fit(select_modes='number',n_modes=3), o.train(o.optimal_placement(),method='bogus'), o.predict(yvec(o)))[2]])
+    cases['predict before train']=run(mk,[fit,lambda o:o.predict(yvec(o))])
+    cases['predict feature id 5']=run(mk,[placed,lambda o:o.predict(np.array([[1,0,5],[1,0,0],[1,0,0.]]))])
+    cases['predict feature id -1']=run(mk,[placed,lambda o:np.round(o.predict(np.array([[1,0,-1],[1,0,0],[1,0,0.]]))[0],6).shape])
+    cases['predict tuple']=run(mk,[placed,lambda o:[a.shape for a in o.predict((yvec(o),))]])
+    cases['predict 1-D y']=run(mk,[placed,lambda o:o.predict(np.zeros(3))])
+    cases['predict after is_Theta']=run(mk,[fit,lambda o:(o.train(np.eye(3,3),is_Theta=True), o.predict(yvec(o)))[1]])
+    cases['reconstruct wrong r']=run(mk,[fit,lambda o:o.reconstruct(np.zeros(4))])
+    cases['reconstruct 2-D']=run(mk,[fit,lambda o:o.reconstruct(np.zeros((2,3))).shape])
+    cases['reconstruct before fit']=run(mk,[lambda o:o.reconstruct(np.zeros(3))])
+    cases['reconstruct list']=run(mk,[fit,lambda o:np.asarray(o.reconstruct([0.,0.,0.])).shape])
+    cases['reconstruct empty']=run(mk,[fit,lambda o:o.reconstruct(np.zeros((0,3))).shape])
+    cases['reconstruct sampling 1-D']=run(mk,[fit,lambda o:o.reconstruct(np.zeros(3),sampling=np.ones(60))])
+    cases['unscale wrong len']=run(mk,[fit,lambda o:o.unscale_data(np.zeros(59))])
+    cases['unscale list']=run(mk,[fit,lambda o:o.unscale_data([0.]*60)])
+    cases['unscale before fit']=run(mk,[lambda o:o.unscale_data(np.zeros(60))])
+    cases['scale_data bogus']=run(mkrom,[lambda o:o.scale_data('bogus')])
+    cases['scale_limits']=run(mkrom,[lambda o:(o.scale_data(), [np.round(a[:2],6).tolist() for a in o.scale_limits([np.array([0.,1.]),np.array([2.,3.])])])[1]])
+    cases['scale_limits before']=run(mkrom,[lambda o:o.scale_limits([np.array([0.,1.])])])
+    cases['reduction bad select']=run(mkrom,[lambda o:o.reduction(np.eye(60,8),np.eye(8),np.linspace(50,100,8),'bogus',3)])
+    cases['decomposition']=run(mkrom,[lambda o:[a.shape for a in o.decomposition(o.scale_data(),'number',3)]])
+    cases['decomposition foreign X0']=run(mkrom,[lambda o:[a.shape for a in o.decomposition(np.asarray(data()),'variance',90)]])
+    cases['gem n_sensors 0']=run(mk,[fit,lambda o:o.optimal_placement(calc_type='gem',n_sensors=0)])
+    cases['scale_vector']=run(mk,[placed,lambda o:np.round(o.scale_vector(yvec(o)),8).tolist()])
+    cases['scale_vector wrong rows']=run(mk,[placed,lambda o:o.scale_vector(yvec(o,5))])
+    
+    return cases
+
+
+#: outcomes that differ ON PURPOSE (documented in the module docstring of sparse_sensing.py / INTEGRATION.md)
+_KNOWN_DEVIATIONS = {
+    'placement mask int',        # an integer "mask" indexes rows in the reference (Ur[~mask, :] = 0 with ~1 = -2): refused here
+    'reconstruct list',          # a list of coefficients is accepted here (the reference needs an ndarray)
+    'unscale list',              # the reference hands back a cvxpy expression for a non-ndarray; no such object on the device path
+    'unscale wrong len',         # the text comes from cvxpy in the real reference (the fixtures' stand-in gives NumPy's, operands swapped)
+}
+
+
+def test_seventy_host_logic_cases_against_the_imported_reference(sps):
+    """round 6: constructor / fit / optimal_placement / train / predict / reconstruct / unscale_data / scale_limits / decomposition
+    called the wrong and the right way, the product's classes (over the NumPy test double) next to the imported reference: same
+    outcome -- value, or exception TYPE AND TEXT -- in every case but the four documented deviations."""
+    cases = _differential_cases(sps)
+    assert len(cases) >= 70
+    bad = []
+    for name, (a, b) in cases.items():
+        same = a[0] == b[0] and (repr(a[1]) == repr(b[1]))
+        if name in _KNOWN_DEVIATIONS:
+            assert not same, f'{name}: no longer deviates -- take it off the list'
+        elif not same:
+            bad.append((name, a, b))
+    assert not bad, bad

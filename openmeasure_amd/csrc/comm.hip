@@ -40,16 +40,15 @@ int find_loaded(struct dl_phdr_info *info, size_t, void *out) {
   return 0;
 }
 
-// -> the table, or nullptr with the reason in spr_last_error()
-const Rccl *rccl() {
-  static Rccl r;
-  static int state = 0;   // 0 not tried, 1 ok, -1 failed
-  static char why[400] = "";
-  if (state == 1) return &r;
-  if (state == -1) {
-    spr_set_error("%s", why);
-    return nullptr;
-  }
+struct Loaded {
+  Rccl r;
+  bool ok = false;
+  char why[400] = "";
+};
+
+// one attempt per process (function-local static: initialised once, also with several threads calling in)
+Loaded load_rccl() {
+  Loaded L;
   void *h = nullptr;
   char path[256] = "";
   if (const char *e = getenv("SPR_RCCL_LIBRARY")) {
@@ -63,20 +62,18 @@ const Rccl *rccl() {
     strncpy(path, names[i], 255);
   }
   if (!h) {
-    snprintf(why, sizeof why, "spr_comm: no RCCL library could be loaded (%s); SPR_RCCL_LIBRARY=<path> names one", dlerror());
-    state = -1;
-    spr_set_error("%s", why);
-    return nullptr;
+    const char *de = dlerror();
+    snprintf(L.why, sizeof L.why, "spr_comm: no RCCL library could be loaded (%s); SPR_RCCL_LIBRARY=<path> names one",
+             de ? de : "no loader message");
+    return L;
   }
-  r.handle = h;
-  strncpy(r.where, path, 255);
+  L.r.handle = h;
+  strncpy(L.r.where, path, 255);
 #define SPR_SYM(field, name)                                                                  \
-  r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name));                              \
-  if (!r.field) {                                                                             \
-    snprintf(why, sizeof why, "spr_comm: %s has no symbol %s", path, name);                   \
-    state = -1;                                                                               \
-    spr_set_error("%s", why);                                                                 \
-    return nullptr;                                                                           \
+  L.r.field = reinterpret_cast<decltype(L.r.field)>(dlsym(h, name));                          \
+  if (!L.r.field) {                                                                           \
+    snprintf(L.why, sizeof L.why, "spr_comm: %s has no symbol %s", path, name);               \
+    return L;                                                                                 \
   }
   SPR_SYM(GetUniqueId, "ncclGetUniqueId")
   SPR_SYM(CommInitRank, "ncclCommInitRank")
@@ -85,8 +82,16 @@ const Rccl *rccl() {
   SPR_SYM(AllGather, "ncclAllGather")
   SPR_SYM(GetErrorString, "ncclGetErrorString")
 #undef SPR_SYM
-  state = 1;
-  return &r;
+  L.ok = true;
+  return L;
+}
+
+// -> the table, or nullptr with the reason in spr_last_error()
+const Rccl *rccl() {
+  static const Loaded L = load_rccl();
+  if (L.ok) return &L.r;
+  spr_set_error("%s", L.why);
+  return nullptr;
 }
 
 struct SprComm {

@@ -189,12 +189,21 @@ __global__ __launch_bounds__(128) void p2p_flags_wait_kernel(FlagTable t, int n,
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     unsigned long long seen;
     bool bad = false;
+    int polls = 0;
     for (;;) {
       seen = __hip_atomic_load(t.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (seen & kPoison) { bad = true; break; }
       if (seen >= value + t.add[i]) break;
       if (wall_clock64() - t0 > timeout_ticks) { bad = true; break; }
-      __builtin_amdgcn_s_sleep(8);
+      // back off: a counter that is about to arrive is seen within a fraction of a microsecond; a copy stream's wait for the
+      // NEXT gather's block sits here for most of a step (13.8 of 21 ms on one rank's block of config 4,
+      // profiles/r06_c4share8_p2p_deferred_timeline.txt) and should not poll 2 000 times per millisecond next to the Gram waves
+      if (polls < 64) {
+        ++polls;
+        __builtin_amdgcn_s_sleep(8);
+      } else {
+        __builtin_amdgcn_s_sleep(127);
+      }
     }
     if (bad && status) {
       __hip_atomic_store(status + 1, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

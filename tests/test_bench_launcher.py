@@ -24,6 +24,11 @@ def test_default_workload_and_scaling():
     assert (a1.gpus, a1.workload) == (1, 'c3')
     a8 = bench.parse_args(['--gpus', '8'])
     assert a8.workload == 'c4'
+    # round 6: the headline of an N > 1 line is the exchange the LIBRARY chose; deferred launches are the library's default (the old
+    # flag is still accepted, --no-defer-reconstruct switches them off); --ballast-gb is a developer aid and off
+    assert a8.headline_gather == 'library' and a8.gather == 'auto' and not a8.no_defer_reconstruct and a8.ballast_gb == 0.0
+    assert bench.parse_args(['--defer-reconstruct']).defer_reconstruct and bench.parse_args(['--no-defer-reconstruct']).no_defer_reconstruct
+    assert bench.parse_args(['--workload', 'c5', '--share-of', '8', '--p2p-loopback', '7', '--ballast-gb', '10']).ballast_gb == 10.0
     assert bench.parse_args(['--gpus', '8', '--workload', 'c5']).workload == 'c5'
     wl = bench.WORKLOADS['c4']
     for world in (1, 2, 4, 8):

@@ -1616,7 +1616,9 @@ class SPR(GemPlacement, ROM):
         s, r = Theta_d.shape
         if s >= r and r <= getattr(eng, 'ols_max_r', r):      # the normal-equations kernel keeps its factor in LDS
             Ar_d, As_d, y0_d, info_d = eng.solve_ols(Theta_d, cnt_d, self._d['scale'], Y)
-            info = eng.to_host(info_d)
+            many = getattr(eng, 'to_host_views', None)        # the four outputs in ONE download (they share a buffer)
+            got = many(info_d, Ar_d, As_d, y0_d) if many is not None else None
+            info = got[0] if got is not None else eng.to_host(info_d)
             if np.any(info[:, 0] == 2):
                 # an uncertainty that is zero (or NaN) for SOME sensors of a vector: W = diag(1/0) (:872) and
                 # np.linalg.pinv(W @ Theta) (:873) raises -- flagged by the kernel, no second solve
@@ -1625,13 +1627,19 @@ class SPR(GemPlacement, ROM):
             # cond(W Theta)^2 eps < 1; info[:, 1] estimates cond^2 from the Cholesky pivots
             if not (np.any(info[:, 0] != 0) or np.any(info[:, 1] > 1e13) or not np.all(np.isfinite(info[:, 1]))):
                 self.solve_path_ = 'cholesky'
+                if got is not None:
+                    return got[1], got[2], got[3]
                 return eng.to_host(Ar_d), eng.to_host(As_d), eng.to_host(y0_d)
         Ar_d, As_d, y0_d, info_d = eng.solve_pinv(Theta_d, cnt_d, self._d['scale'], Y, rcond=self._PINV_RCOND)
-        info = eng.to_host(info_d)
+        many = getattr(eng, 'to_host_views', None)
+        got = many(info_d, Ar_d, As_d, y0_d) if many is not None else None
+        info = got[0] if got is not None else eng.to_host(info_d)
         if np.any(info[:, 0] < 0):
             raise np.linalg.LinAlgError('SVD did not converge')           # what np.linalg.pinv raises
         self.solve_path_ = 'pinv'
         self.solve_rank_ = info[:, 1].astype(int)
+        if got is not None:
+            return got[1], got[2], got[3]
         return eng.to_host(Ar_d), eng.to_host(As_d), eng.to_host(y0_d)
 
     def scale_vector(self, y):

@@ -1992,3 +1992,35 @@ def test_deferred_reconstruct_on_the_device(eng):
     host gap (behind the Gram download, before the projection overwrites the basis) with the basis it was called after."""
     from tests.parity import run_deferred_reconstruct
     run_deferred_reconstruct(eng)
+
+
+def test_predict_outputs_in_one_download(eng):
+    """round 6: the four outputs of the solve kernels (info, Ar, Ar_sigma, y0) are views of ONE buffer, each on a 256-byte boundary,
+    and predict() brings them to the host in one download (HipEngine.to_host_views) -- same values as one download each, for odd r / s
+    and several vectors, on both solve paths."""
+    rng = np.random.default_rng(12)
+    for s_, r, n_p in ((7, 5, 3), (64, 64, 1), (33, 9, 4)):
+        Theta = rng.standard_normal((s_, r))
+        Y = np.zeros((n_p, s_, 3))
+        Y[:, :, 0] = rng.standard_normal((n_p, s_))
+        Y[:, :, 1] = 0.1 + rng.random((n_p, s_))
+        args = (eng.to_device(Theta), eng.to_device(np.zeros(s_)), eng.to_device(np.ones(1)), eng.to_device(Y))
+        for solve in (eng.solve_ols, eng.solve_pinv):
+            Ar, As, y0, info = solve(*args)
+            assert all(t._base is Ar._base and t.data_ptr() % 256 == 0 for t in (Ar, As, y0, info))
+            calls = []
+            real = eng.to_host
+            eng.to_host = lambda t, **kw: (calls.append(1), real(t, **kw))[1]
+            try:
+                got = eng.to_host_views(info, Ar, As, y0)
+            finally:
+                eng.to_host = real
+            assert len(calls) == 1
+            for a, t in zip(got, (info, Ar, As, y0)):
+                np.testing.assert_array_equal(a, eng.to_host(t))
+                assert a.shape == tuple(t.shape) and a.flags['OWNDATA']
+    # tensors that do NOT share a buffer: one download each, same values
+    a, b = eng.to_device(np.arange(6.0)), eng.to_device(np.arange(4.0))
+    ga, gb = eng.to_host_views(a, b)
+    np.testing.assert_array_equal(ga, np.arange(6.0))
+    np.testing.assert_array_equal(gb, np.arange(4.0))

@@ -14,14 +14,20 @@ touches the GPU -- waits for them and relays rank 0's JSON line; a failed rank e
 non-zero exit code.  The default workload for N > 1 is BASELINE config 4: the SAME 10M-cell x 9 x 256
 matrix as config 3, row-sharded over the N GPUs (strong scaling: 90M/N rows per rank, features
 straddle the shards); `--scaling weak` gives every rank a full workload-sized shard instead.
-Per step there is one RCCL all-reduce (per-feature Gram) and one all-gather (field).
+Per step there is one RCCL all-reduce (per-feature Gram) and one exchange of the field -- the one RowShard(gather='auto') chose
+(SDMA pushes into peer-mapped buffers, or RCCL's all-gather: the library times both at its first exchange); the other one is
+timed as well when the HBM allows it (comm.paths).  N = 1: ms_per_step / value are the SYNCHRONOUS step (fit, then reconstruct
+launched and complete before the next fit); ms_per_step_pipelined / value_pipelined the same K steps with the asynchronous
+reconstruct(to_host=False, wait=False), whose launch the library defers into the next fit()'s host gap.
 
 The JSON line also carries
   roofline      the dominant kernel (the fused stats+Gram pass), timed live with HIP events on
                 its launch stream; algorithmic flops/bytes per launch from SURVEY.md 8(d);
                 roofline_per_rank repeats it for every rank when N > 1;
   cpu_baseline  the NumPy/LAPACK oracle (oracle/spr_oracle.py) timed on this host's cores on a
-                bounded sample of the same workload (rank 0, N=1 only);
+                sample of the same workload sized for about SPR_BENCH_CPU_BUDGET_S = 30 s from a
+                short probe (rank 0, N=1 only);
+  hbm           hipMemGetInfo at the end of the run, PyTorch's peaks, the exchange buffers;
   phases, parity  extra evidence (per-kernel ms, GPU-vs-oracle agreement on the sample).
 """
 import argparse

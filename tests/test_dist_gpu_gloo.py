@@ -734,8 +734,11 @@ def _native_comm_worker(rank, world, port, out_dir):
         from tests.conftest import load_golden
         eng = HipEngine('cuda:0')
         res = {}
-        for fixture in ('g7_f9_num6', 'g5_median', 'f32_g3_num8', 'cond_1e7'):
-            g = load_golden(fixture)
+        rng = np.random.default_rng(21)
+        wide = dict(X=rng.standard_normal((600, 8)) @ rng.standard_normal((8, 300)) + 0.01 * rng.standard_normal((600, 300)),
+                    n_features=3, scale_type='std', axis_cnt=1, select_modes='number', n_modes=6, ys=None, piv=None)
+        for fixture in ('g7_f9_num6', 'g5_median', 'f32_g3_num8', 'cond_1e7', 'wide_m300'):
+            g = load_golden(fixture) if fixture != 'wide_m300' else wide     # m = 300: the column-split Gram path (no fused pass)
             X = g['X']
             n = X.shape[0]
             outs = []
@@ -750,6 +753,12 @@ def _native_comm_worker(rank, world, port, out_dir):
                     spr.fit(scale_type=g['scale_type'], axis_cnt=g['axis_cnt'], select_modes=g['select_modes'], n_modes=g['n_modes'])
                     C = spr.optimal_placement()
                     spr.train(C)
+                    if g['ys'] is None:                                   # (the synthetic case: three held-out states of its own)
+                        piv_ = spr.sensors_
+                        ys_ = np.zeros((3, len(piv_), 3))
+                        ys_[:, :, 0] = X[piv_][:, :3].T
+                        ys_[:, :, 2] = piv_ // (n // g['n_features'])
+                        g['ys'] = ys_
                     A3, _ = spr.predict(list(g['ys']))
                     X3 = spr.reconstruct(A3)
                     x1 = spr.reconstruct(A3[:1], to_host=False, wait=False).wait().cpu().numpy()
@@ -762,7 +771,7 @@ def _native_comm_worker(rank, world, port, out_dir):
             a, b = outs
             same = all(np.array_equal(a[k], b[k]) for k in ('Sigma', 'Ur', 'piv', 'X3', 'x1', 'X_cnt'))
             res[fixture] = dict(same=bool(same), torch_calls=len(a['calls']), native_calls=b['calls'], lib=b['lib'],
-                                piv_ok=bool(np.array_equal(b['piv'], g['piv'])))
+                                piv_ok=bool(g['piv'] is None or np.array_equal(b['piv'], g['piv'])))
         import json
         with open(os.path.join(out_dir, 'native.json'), 'w') as f:
             json.dump(res, f)

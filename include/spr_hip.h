@@ -425,7 +425,9 @@ int spr_field_gather_p2p_release(void *const *d_peer_release_flag, int32_t n_pee
  *                        statistics | world first rows] (spr_fit_gram_pass_buffer() bytes; zeroed here), the all-reduce of d_buf
  *                        over `comm` (NULL: one rank, no collective), spr_gram_combine_f64 -> d_G [m][m], d_feat [F][5],
  *                        d_scale / d_inv_scale [F].  Replaces np.average / np.std / X0 = (X - cnt)/scl / the X0^T X0 half of
- *                        np.linalg.svd (:112, :115, :169, :272) for a row block of a sharded X.  m <= SPR_MAX_M; scale_code as
+ *                        np.linalg.svd (:112, :115, :169, :272) for a row block of a sharded X.  m <= SPR_MAX_M_WIDE (beyond 256 the
+ *                        column-split path with its three launches, BASELINE config 5's m = 512); workspace:
+ *                        spr_fit_gram_pass_workspace(m, n_features, n_rows) bytes, 256-byte aligned; scale_code as
  *                        for spr_gram_combine_f64; x_is_f32: d_X is float (storage only).  Afterwards d_buf still holds what
  *                        every rank contributed: rows per (rank, feature) = d_buf[F m m + (q F + f) 3], first rows at the end. */
 size_t spr_comm_unique_id_bytes(void);
@@ -438,6 +440,7 @@ int spr_allreduce_f64(void *comm, double *d_buf, int64_t count, void *stream);
 int spr_allreduce_i64(void *comm, int64_t *d_buf, int64_t count, void *stream);
 int spr_allgather(void *comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream);
 size_t spr_fit_gram_pass_buffer(int32_t m, int32_t n_features, int32_t world);
+size_t spr_fit_gram_pass_workspace(int32_t m, int32_t n_features, int64_t n_rows);
 int spr_fit_gram_pass(void *comm, const void *d_X, int32_t x_is_f32, int64_t n_rows, int32_t m, int64_t ldx, int64_t row0,
                       int64_t n_points, int32_t n_features, int32_t scale_code, double *d_rowmean, double *d_buf,
                       size_t buf_bytes, double *d_G, double *d_feat, double *d_scale, double *d_inv_scale, void *d_workspace,

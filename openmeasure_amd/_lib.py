@@ -119,6 +119,7 @@ PROTOTYPES = {
     'spr_allreduce_i64': (C.c_int, [_p, _p, _i64, _p]),
     'spr_allgather': (C.c_int, [_p, _p, _p, _i64, _p]),
     'spr_fit_gram_pass_buffer': (_sz, [_i32, _i32, _i32]),
+    'spr_fit_gram_pass_workspace': (_sz, [_i32, _i32, _i64]),
     'spr_fit_gram_pass': (C.c_int, [_p, _p, _i32, _i64, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _sz, _p, _p, _p, _p, _p, _sz, _p]),
     'spr_synth_f64': (C.c_int, [_p, _i64, _i32, _i64, _i64, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p]),
     'spr_synth_gather_f64': (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _i32, _dbl, _u64, _p, _p]),

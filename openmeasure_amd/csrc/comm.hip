@@ -243,6 +243,26 @@ extern "C" size_t spr_fit_gram_pass_buffer(int32_t m, int32_t n_features, int32_
   return ((size_t)n_features * m * m + (size_t)world * n_features * 3 + (size_t)world) * sizeof(double);
 }
 
+// Workspace of spr_fit_gram_pass: m <= 256 the Gram workspace; 256 < m <= 512 (the column-split path: BASELINE config 5 has m = 512)
+// the larger of the Gram / cross / row-statistics workspaces, then n_rows doubles (raw row sums of the second slice) and 3 F doubles.
+namespace {
+size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+size_t wide_kernel_ws(int32_t m, int32_t F) {
+  size_t a = spr_stats_gram_workspace(SPR_MAX_M, F), b = spr_stats_gram_workspace(m - SPR_MAX_M, F);
+  size_t c = spr_gram_cross_workspace(m, F), d = spr_rowstats_workspace(F);
+  size_t w = a > b ? a : b;
+  if (c > w) w = c;
+  if (d > w) w = d;
+  return align256(w);
+}
+}  // namespace
+
+extern "C" size_t spr_fit_gram_pass_workspace(int32_t m, int32_t n_features, int64_t n_rows) {
+  if (m < 1 || n_features < 1 || n_rows < 1 || m > SPR_MAX_M_WIDE) return 0;
+  if (m <= SPR_MAX_M) return spr_stats_gram_workspace(m, n_features);
+  return wide_kernel_ws(m, n_features) + align256((size_t)n_rows * sizeof(double)) + align256((size_t)n_features * 3 * sizeof(double));
+}
+
 extern "C" int spr_fit_gram_pass(void *comm, const void *d_X, int32_t x_is_f32, int64_t n_rows, int32_t m, int64_t ldx,
                                  int64_t row0, int64_t n_points, int32_t n_features, int32_t scale_code, double *d_rowmean,
                                  double *d_buf, size_t buf_bytes, double *d_G, double *d_feat, double *d_scale,
@@ -257,26 +277,66 @@ extern "C" int spr_fit_gram_pass(void *comm, const void *d_X, int32_t x_is_f32, 
   }
   SPR_REQUIRE(d_X && d_rowmean && d_buf && d_G && d_feat && d_scale && d_inv_scale, SPR_E_INVALID,
               "spr_fit_gram_pass: NULL pointer");
-  SPR_REQUIRE(m >= 1 && m <= SPR_MAX_M, SPR_E_UNSUPPORTED, "spr_fit_gram_pass: m=%d (1..%d: wider matrices go slice by slice)", m,
-              SPR_MAX_M);
+  SPR_REQUIRE(m >= 1 && m <= SPR_MAX_M_WIDE, SPR_E_UNSUPPORTED,
+              "spr_fit_gram_pass: m=%d (1..%d: wider matrices go slice by slice, spr_rowstats / spr_gram_cross_pair)", m, SPR_MAX_M_WIDE);
   SPR_REQUIRE(n_features >= 1 && n_rows >= 1, SPR_E_INVALID, "spr_fit_gram_pass: n_rows=%lld n_features=%d", (long long)n_rows,
               n_features);
   const size_t need = spr_fit_gram_pass_buffer(m, n_features, world);
   SPR_REQUIRE(buf_bytes >= need, SPR_E_WORKSPACE, "spr_fit_gram_pass: buffer of %zu bytes, %zu needed", buf_bytes, need);
+  const size_t ws_need = spr_fit_gram_pass_workspace(m, n_features, n_rows);
+  SPR_REQUIRE(d_workspace && workspace_bytes >= ws_need, SPR_E_WORKSPACE, "spr_fit_gram_pass: workspace of %zu bytes, %zu needed",
+              workspace_bytes, ws_need);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t n_gram = (size_t)n_features * m * m;
   double *fstats_all = d_buf + n_gram;
   double *fstats_mine = fstats_all + (size_t)rank * n_features * 3;
   double *rows_all = fstats_all + (size_t)world * n_features * 3;
   SPR_HIP_TRY(hipMemsetAsync(d_buf, 0, need, st));
-  int rc = x_is_f32 ? spr_stats_gram_x32(static_cast<const float *>(d_X), n_rows, m, ldx, row0, n_points, n_features, 1, d_rowmean,
-                                         d_workspace, workspace_bytes, stream)
-                    : spr_stats_gram_f64(static_cast<const double *>(d_X), n_rows, m, ldx, row0, n_points, n_features, 1,
-                                         d_rowmean, d_workspace, workspace_bytes, stream);
-  if (rc) return rc;
-  rc = spr_stats_gram_finalize_f64(n_rows, m, row0, n_points, n_features, d_workspace, workspace_bytes, fstats_mine, d_buf, m, 0,
-                                   stream);
-  if (rc) return rc;
+  int rc;
+  if (m <= SPR_MAX_M) {
+    rc = x_is_f32 ? spr_stats_gram_x32(static_cast<const float *>(d_X), n_rows, m, ldx, row0, n_points, n_features, 1, d_rowmean,
+                                       d_workspace, workspace_bytes, stream)
+                  : spr_stats_gram_f64(static_cast<const double *>(d_X), n_rows, m, ldx, row0, n_points, n_features, 1,
+                                       d_rowmean, d_workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = spr_stats_gram_finalize_f64(n_rows, m, row0, n_points, n_features, d_workspace, workspace_bytes, fstats_mine, d_buf, m, 0,
+                                     stream);
+    if (rc) return rc;
+  } else {
+    // 256 < m <= 512: columns A = [0, 256), B = [256, m).  Every launch shifts the rows by the mean of their FIRST 256 columns --
+    // formed for free by the symmetric launch on A --, P G P afterwards gives the Gram blocks of the row-centred data and the
+    // true row means (include/spr_hip.h, "K1 + K3a for 256 < m <= 512"); the statistics of the row means come last.
+    const int mA = SPR_MAX_M, mB = m - SPR_MAX_M;
+    const size_t kws = wide_kernel_ws(m, n_features);
+    char *base = static_cast<char *>(d_workspace);
+    double *rowsum_b = reinterpret_cast<double *>(base + kws);
+    double *scratch = reinterpret_cast<double *>(base + kws + align256((size_t)n_rows * sizeof(double)));
+    const size_t esz = x_is_f32 ? sizeof(float) : sizeof(double);
+    const char *xb = static_cast<const char *>(d_X) + (size_t)mA * esz;
+    rc = x_is_f32 ? spr_stats_gram_x32(static_cast<const float *>(d_X), n_rows, mA, ldx, row0, n_points, n_features, 1, d_rowmean,
+                                       d_workspace, kws, stream)
+                  : spr_stats_gram_f64(static_cast<const double *>(d_X), n_rows, mA, ldx, row0, n_points, n_features, 1,
+                                       d_rowmean, d_workspace, kws, stream);
+    if (rc) return rc;
+    rc = spr_stats_gram_finalize_f64(n_rows, mA, row0, n_points, n_features, d_workspace, kws, scratch, d_buf, m, 0, stream);
+    if (rc) return rc;
+    rc = x_is_f32 ? spr_gram_cross_x32(static_cast<const float *>(d_X), n_rows, m, ldx, row0, n_points, n_features, 2, d_rowmean,
+                                       d_buf, d_workspace, kws, stream)
+                  : spr_gram_cross_f64(static_cast<const double *>(d_X), n_rows, m, ldx, row0, n_points, n_features, 2, d_rowmean,
+                                       d_buf, d_workspace, kws, stream);
+    if (rc) return rc;
+    rc = x_is_f32 ? spr_stats_gram_shifted_x32(reinterpret_cast<const float *>(xb), n_rows, mB, ldx, row0, n_points, n_features,
+                                               d_rowmean, rowsum_b, d_workspace, kws, stream)
+                  : spr_stats_gram_shifted_f64(reinterpret_cast<const double *>(xb), n_rows, mB, ldx, row0, n_points, n_features,
+                                               d_rowmean, rowsum_b, d_workspace, kws, stream);
+    if (rc) return rc;
+    rc = spr_stats_gram_finalize_f64(n_rows, mB, row0, n_points, n_features, d_workspace, kws, scratch, d_buf, m, mA, stream);
+    if (rc) return rc;
+    rc = spr_gram_shift_finish_f64(d_rowmean, rowsum_b, n_rows, mA, m, d_buf, n_features, stream);
+    if (rc) return rc;
+    rc = spr_rowmean_stats_f64(d_rowmean, n_rows, row0, n_points, n_features, fstats_mine, d_workspace, kws, stream);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(set_slot_kernel, dim3(1), dim3(1), 0, st, rows_all + rank, (double)row0);   // exact below 2^53
   SPR_LAUNCH_CHECK();
   if (c) {   // (a one-rank communicator reduces onto itself: the same call path, which is what one GPU can test)

@@ -471,7 +471,7 @@ class HipEngine:
         nbuf = int(self.lib.spr_fit_gram_pass_buffer(m, F, int(world))) // 8
         rowmean, buf = self.empty((n,)), self.empty((nbuf,))
         packed, scale, inv_scale = self.empty((m * m + 5 * F,)), self.empty((F,)), self.empty((F,))
-        ws = self._workspace('gram', self.lib.spr_stats_gram_workspace(m, F))
+        ws = self._workspace('gram', self.lib.spr_fit_gram_pass_workspace(m, F, n))
         tic, toc = self._timed('stats_gram')
         tic()
         _lib.check(self.lib.spr_fit_gram_pass(comm, _ptr(X), int(X.dtype == self.torch.float32), n, m, ld, row0, n_points, F,

@@ -668,7 +668,7 @@ class ROM(ShardedOps):
         world, rank = self._world(), self._shard.rank
         self.__dict__.pop('_combined', None)
         nc = self._native_comm()
-        if nc is not None and combine is not None and m <= 256 and hasattr(eng, 'fit_gram_pass'):
+        if nc is not None and combine is not None and m <= 512 and hasattr(eng, 'fit_gram_pass'):
             # the whole pass -- Gram kernel, finalize, all-reduce, statistics merge + scaled sum -- as ONE call of the library
             # (spr_fit_gram_pass): nothing of the host between the kernels and the collective; combine = the scale_type
             close = self._comm_bracket('allreduce')           # (brackets the whole enqueue here)

@@ -149,7 +149,8 @@ int main(void) {
   CK(spr_comm_info(comm, &rank, &w));
   if (rank != 0 || w != 1) return 2;
   printf("RCCL from %s\n", spr_comm_library());
-  size_t wsb = spr_stats_gram_workspace(m, F), bufb = spr_fit_gram_pass_buffer(m, F, world);
+  size_t wsb = spr_fit_gram_pass_workspace(m, F, n), bufb = spr_fit_gram_pass_buffer(m, F, world);
+  if (wsb != spr_stats_gram_workspace(m, F)) return 9;                    /* m <= 256: the Gram workspace */
   double *dX, *dmean, *dmean2, *dbuf, *dG, *dfeat, *dsc, *dinv, *dfs, *dgram, *dG2, *dfeat2, *dsc2, *dinv2; void *ws;
   CK(hipMalloc((void **)&dX, sizeof(double) * n * m)); CK(hipMalloc((void **)&dmean, sizeof(double) * n)); CK(hipMalloc((void **)&dmean2, sizeof(double) * n));
   CK(hipMalloc((void **)&dbuf, bufb)); CK(hipMalloc((void **)&dG, sizeof(double) * m * m)); CK(hipMalloc((void **)&dG2, sizeof(double) * m * m));

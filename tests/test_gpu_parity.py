@@ -2058,3 +2058,25 @@ def test_integration_doc_binding_runs(eng, tmp_path):
         assert torch.equal(inv, inv_ref)
     finally:
         assert eng.lib.spr_comm_destroy(comm) == 0
+
+
+@pytest.mark.parametrize('m,f32', [(40, False), (256, True), (257, False), (300, False), (512, True)])
+def test_fit_gram_pass_matches_the_separate_calls(eng, m, f32):
+    """spr_fit_gram_pass (round 6: the first pass of fit() as ONE library call -- Gram kernel(s), finalize, [all-reduce], statistics
+    merge; beyond 256 snapshots the column-split path with its three launches, BASELINE config 5's width) against the same steps
+    called one by one through the engine: row means, Gram blocks, statistics slots, scaled Gram matrix and scales bit for bit;
+    a row block that starts inside a feature; f64 and f32 storage."""
+    import torch
+    rng = np.random.default_rng(m)
+    n_points, F, row0, n = 1500, 3, 700, 3300                     # rows 700 .. 3999 of 4500: three features, the first and last cut
+    X = rng.standard_normal((n, 6)) @ rng.standard_normal((6, m)) + 0.05 * rng.standard_normal((n, m)) + 2.0
+    Xd = eng.to_device(X.astype(np.float32) if f32 else X, dtype=torch.float32 if f32 else None)
+    rowmean, buf, packed, scale, inv = eng.fit_gram_pass(Xd, row0, n_points, F, 'std', None, 1)
+    rm, fs, gr = eng.stats_gram(Xd, row0, n_points, F)
+    pk, sc, iv = eng.gram_combine(gr, fs[None], 'std')
+    torch.cuda.synchronize()
+    assert torch.equal(rowmean, rm)
+    assert torch.equal(buf[:F * m * m].view(F, m, m), gr)
+    assert torch.equal(buf[F * m * m:F * m * m + F * 3].view(F, 3), fs) and float(buf[-1]) == float(row0)
+    assert torch.equal(packed, pk) and torch.equal(scale, sc) and torch.equal(inv, iv)
+    assert bool(torch.isfinite(packed).all())
